@@ -1,0 +1,96 @@
+"""Build + ctypes binding of libdkt_hip.so (the C ABI declared in include/dkt_abi.h).
+
+There is NO CPU fallback: every entry point of `ops` goes through this library, and `load()`
+raises if the shared object is missing or a symbol of the header is absent.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
+SOURCES = ["dkt_gram.hip", "dkt_mll.hip", "dkt_predict.hip"]
+HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(INCLUDE, "dkt_abi.h")]
+
+_c_p = ctypes.c_void_p
+_c_i = ctypes.c_int
+_c_f = ctypes.c_float
+
+# name -> (restype, argtypes); must list EVERY function of include/dkt_abi.h (tests check this).
+SIGNATURES = {
+    "dkt_abi_version": (_c_i, []),
+    "dkt_device_cu_count": (_c_i, []),
+    "dkt_gram_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "dkt_mll_workspace_bytes": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
+    "dkt_mll_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_i,
+                           ctypes.c_uint, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                           _c_p, ctypes.c_size_t, _c_p]),
+    "dkt_gram_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "dkt_rbf_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
+    "dkt_predict_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_predict_var_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> deep-kernel-transfer_amd/libdkt_hip.so (in-tree).
+    Cross-compiles without a GPU."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the HIP library and bind every declared symbol; raises (never falls back) on failure."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdkt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "-- the DKT hot path has no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise RuntimeError("libdkt_hip.so lacks symbol %s declared in include/dkt_abi.h" % name) from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+STATUS = {0: "DKT_OK", -1: "DKT_ERR_BAD_ARG", -2: "DKT_ERR_TOO_LARGE", -3: "DKT_ERR_WORKSPACE", -4: "DKT_ERR_LAUNCH"}
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, STATUS.get(status, "?"), status))

@@ -1,0 +1,347 @@
+// dkt_gram.hip -- base-kernel (Gram) matrix build and its backward, fp32-exact MFMA (gfx950).
+//
+//   gram_nt_kernel : E[b] = k(A[b], Bm[b]),  A:[M,D], Bm:[N,D]  (NT contraction over D)
+//   gram_bwd_kernel: dZ[b] = s_b (W[b] + W[b]^T) Z[b]           (NN contraction over N)
+//
+// Both use v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue): a 64x64 output tile per 256-thread
+// workgroup, 2x2 waves, each wave 2x2 MFMA fragments.  Operand tiles are staged global -> registers
+// -> LDS (double buffered, one barrier per K step) with 16-byte loads; fragment reads are
+// ds_read_b128 with a k-permutation (lane group q holds k = 4q..4q+3 of each 16-wide K slice, the
+// t-th MFMA of the slice contracts k = {t, 4+t, 8+t, 12+t}), row stride 40 floats = conflict-free
+// for the b128 lane groups.
+//
+// Replaces ExactGPLayer.forward -> covar_module(x) (reference methods/DKT.py:375-378,
+// methods/DKT_regression.py:126-129) and autograd through it (DKT.py:163).
+#include "dkt_common.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+constexpr int GT = 64;         // output tile edge
+constexpr int GBK = 32;        // K per stage
+constexpr int GLD = GBK + 8;   // LDS row stride (floats) of a [64][GBK] operand tile
+constexpr int BLD = GT + 4;    // LDS row stride of the [GBK][64] NN operand tile
+
+__device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// E = k(A, Bm).  grid = (tiles over N, tiles over M, B).  SYM: Bm == A, upper tiles skipped and
+// the lower tiles mirrored on store.  KIND 1 (RBF): operands are shifted by row 0 of A (any common
+// shift leaves |a-b| unchanged; it removes the shared offset of ReLU features the way GPyTorch's
+// mean-centring does), squared row norms are accumulated while staging, and the epilogue forms
+// d2 = |a|^2 + |b|^2 - 2 a.b (clamped at 0) and E = exp(-0.5 d2 / l^2).
+// ------------------------------------------------------------------------------------------
+template <int KIND, bool SYM>
+__global__ __launch_bounds__(256) void gram_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                      float* __restrict__ E, int M, int N, int D,
+                                                      const float* __restrict__ lengthscale) {
+    const int tn = blockIdx.x, tm = blockIdx.y, b = blockIdx.z;
+    if (SYM && tn > tm) return;
+    const bool diag = SYM && (tn == tm);
+    const float* Ab = A + (size_t)b * M * D;
+    const float* Bb = SYM ? Ab : Bm + (size_t)b * N * D;
+    float* Eb = E + (size_t)b * M * N;
+    const int m0 = tm * GT, n0 = tn * GT;
+
+    __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
+    __shared__ float nrmA[GT], nrmB[GT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int lr = tid >> 3;          // staging row 0..31 (and +32)
+    const int lc = (tid & 7) * 4;     // staging k offset within the stage
+    const bool vec_ok = ((D & 3) == 0) && ((((uintptr_t)Ab) & 15) == 0) && ((((uintptr_t)Bb) & 15) == 0);
+
+    float4 ra[2], rb[2];
+    float na[2] = {0.f, 0.f}, nb[2] = {0.f, 0.f};
+
+    auto gload = [&](int k0) {
+        const int k = k0 + lc;
+        float4 ref = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == DKT_KERNEL_RBF) ref = load4_guard(Ab, k, D, true, vec_ok);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rowa = m0 + lr + 32 * h;
+            const bool oka = rowa < M;
+            ra[h] = load4_guard(Ab + (size_t)rowa * D, k, D, oka, vec_ok);
+            if (KIND == DKT_KERNEL_RBF && oka) {
+                if (k + 0 < D) ra[h].x -= ref.x;
+                if (k + 1 < D) ra[h].y -= ref.y;
+                if (k + 2 < D) ra[h].z -= ref.z;
+                if (k + 3 < D) ra[h].w -= ref.w;
+                na[h] += ra[h].x * ra[h].x + ra[h].y * ra[h].y + ra[h].z * ra[h].z + ra[h].w * ra[h].w;
+            }
+            if (!diag) {
+                const int rowb = n0 + lr + 32 * h;
+                const bool okb = rowb < N;
+                rb[h] = load4_guard(Bb + (size_t)rowb * D, k, D, okb, vec_ok);
+                if (KIND == DKT_KERNEL_RBF && okb) {
+                    if (k + 0 < D) rb[h].x -= ref.x;
+                    if (k + 1 < D) rb[h].y -= ref.y;
+                    if (k + 2 < D) rb[h].z -= ref.z;
+                    if (k + 3 < D) rb[h].w -= ref.w;
+                    nb[h] += rb[h].x * rb[h].x + rb[h].y * rb[h].y + rb[h].z * rb[h].z + rb[h].w * rb[h].w;
+                }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&As[buf][(lr + 32 * h) * GLD + lc]) = ra[h];
+            if (!diag) *reinterpret_cast<float4*>(&Bs[buf][(lr + 32 * h) * GLD + lc]) = rb[h];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (D + GBK - 1) / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GBK);
+        const float* as = As[buf];
+        const float* bs = diag ? As[buf] : Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < GBK / 16; ++kk) {
+            const int ko = kk * 16 + 4 * q;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&as[(wm * 32 + r16) * GLD + ko]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&as[(wm * 32 + 16 + r16) * GLD + ko]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&bs[(wn * 32 + r16) * GLD + ko]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&bs[(wn * 32 + 16 + r16) * GLD + ko]);
+            mfma4(acc[0][0], a0, b0);
+            mfma4(acc[0][1], a0, b1);
+            mfma4(acc[1][0], a1, b0);
+            mfma4(acc[1][1], a1, b1);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float inv_l2 = 0.f;
+    if (KIND == DKT_KERNEL_RBF) {
+        // reduce the per-thread partial norms over the 8 threads sharing a staging row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float va = na[h], vb = nb[h];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                va += __shfl_xor(va, o, DKT_WAVE);
+                vb += __shfl_xor(vb, o, DKT_WAVE);
+            }
+            if ((tid & 7) == 0) {
+                nrmA[lr + 32 * h] = va;
+                nrmB[lr + 32 * h] = diag ? va : vb;
+            }
+        }
+        __syncthreads();
+        const float l = lengthscale[0];
+        inv_l2 = 1.0f / (l * l);
+    }
+
+    // epilogue: C/D layout of 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane & 15
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int lm = wm * 32 + fi * 16 + 4 * q + reg;
+                const int ln = wn * 32 + fj * 16 + r16;
+                const int gm = m0 + lm, gn = n0 + ln;
+                if (gm >= M || gn >= N) continue;
+                float v = acc[fi][fj][reg];
+                if (KIND == DKT_KERNEL_RBF) {
+                    float d2 = nrmA[lm] + nrmB[ln] - 2.0f * v;
+                    d2 = d2 > 0.f ? d2 : 0.f;
+                    if (SYM && gm == gn) d2 = 0.f;
+                    v = expf(-0.5f * d2 * inv_l2);
+                }
+                if (SYM) {
+                    if (diag && gn > gm) continue;  // keep the matrix exactly symmetric
+                    Eb[(size_t)gm * N + gn] = v;
+                    if (gm != gn) Eb[(size_t)gn * N + gm] = v;
+                } else {
+                    Eb[(size_t)gm * N + gn] = v;
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// dZ[b] = s_b (W + W^T) Z.   grid = (tiles over D, tiles over N, B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+                                                       float* __restrict__ dZ, int N, int D,
+                                                       const float* __restrict__ ep_scale) {
+    const int td = blockIdx.x, tm = blockIdx.y, b = blockIdx.z;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* dZb = dZ + (size_t)b * N * D;
+    const int m0 = tm * GT, d0 = td * GT;
+
+    __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];   // [i][k]  (W + W^T)
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * BLD];  // [k][d]  Z
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;    // A staging: rows lr, lr+32; k offset lc
+    const int kr = tid >> 4, dc = (tid & 15) * 4;   // B staging: k rows kr, kr+16; d offset dc
+    const bool vec_ok = ((D & 3) == 0) && ((((uintptr_t)Zb) & 15) == 0);
+
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = m0 + lr + 32 * h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + lc + e;
+                v[e] = (i < N && k < N) ? (Wb[(size_t)i * N + k] + Wb[(size_t)k * N + i]) : 0.f;
+            }
+            ra[h] = make_float4(v[0], v[1], v[2], v[3]);
+            const int k = k0 + kr + 16 * h;
+            rb[h] = load4_guard(Zb + (size_t)k * D, d0 + dc, D, k < N, vec_ok);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&As[buf][(lr + 32 * h) * GLD + lc]) = ra[h];
+            *reinterpret_cast<float4*>(&Bs[buf][(kr + 16 * h) * BLD + dc]) = rb[h];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (N + GBK - 1) / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GBK);
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < GBK / 16; ++kk) {
+            const int ko = kk * 16 + 4 * q;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&as[(wm * 32 + r16) * GLD + ko]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&as[(wm * 32 + 16 + r16) * GLD + ko]);
+            f32x4 b0, b1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                b0[t] = bs[(ko + t) * BLD + wn * 32 + r16];
+                b1[t] = bs[(ko + t) * BLD + wn * 32 + 16 + r16];
+            }
+            mfma4(acc[0][0], a0, b0);
+            mfma4(acc[0][1], a0, b1);
+            mfma4(acc[1][0], a1, b0);
+            mfma4(acc[1][1], a1, b1);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float s = ep_scale ? ep_scale[b] : 1.0f;
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gm = m0 + wm * 32 + fi * 16 + 4 * q + reg;
+                const int gd = d0 + wn * 32 + fj * 16 + r16;
+                if (gm < N && gd < D) dZb[(size_t)gm * D + gd] = s * acc[fi][fj][reg];
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// RBF chain rule: Wp = diag(A 1) - A, A = -(Ws o E)/l^2;  dl = sum Ws E d2 / l^3.
+// one workgroup per episode, one row per thread (strided).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rbf_bwd_kernel(const float* __restrict__ W, const float* __restrict__ E,
+                                                      const float* __restrict__ lengthscale, float* __restrict__ Wp,
+                                                      float* __restrict__ dl, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Eb = E + (size_t)b * N * N;
+    float* Wpb = Wp + (size_t)b * N * N;
+    const float l = lengthscale[0];
+    const float inv_l2 = 1.0f / (l * l);
+    float dl_part = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float rowsum = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float ws = 0.5f * (Wb[(size_t)i * N + j] + Wb[(size_t)j * N + i]);
+            const float e = Eb[(size_t)i * N + j];
+            const float a = -(ws * e) * inv_l2;
+            rowsum += a;
+            if (j != i) Wpb[(size_t)i * N + j] = -a;
+            if (e > 0.f) dl_part += ws * e * (-2.0f * logf(e));  // = ws e d2 / l^2
+        }
+        const float wsd = Wb[(size_t)i * N + i];
+        const float ad = -(wsd * Eb[(size_t)i * N + i]) * inv_l2;
+        Wpb[(size_t)i * N + i] = rowsum - ad;
+    }
+    const float tot = block_sum_256(dl_part, red);
+    if (threadIdx.x == 0) dl[b] = tot / l;
+}
+
+}  // namespace
+
+extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, int M, int N, int D, int kind,
+                            const float* lengthscale, void* stream) {
+    if (!A || !E || B <= 0 || M <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if (kind != DKT_KERNEL_LINEAR && kind != DKT_KERNEL_RBF) return DKT_ERR_BAD_ARG;
+    if (kind == DKT_KERNEL_RBF && !lengthscale) return DKT_ERR_BAD_ARG;
+    const bool sym = (Bm == nullptr);
+    if (sym && M != N) return DKT_ERR_BAD_ARG;
+    if (B > 65535) return DKT_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, B), block(256);
+    if (kind == DKT_KERNEL_LINEAR) {
+        if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_LINEAR, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_LINEAR, false>), grid, block, 0, st, A, Bm, E, M, N, D, lengthscale);
+    } else {
+        if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_RBF, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_RBF, false>), grid, block, 0, st, A, Bm, E, M, N, D, lengthscale);
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
+                                const float* ep_scale, void* stream) {
+    if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if (B > 65535) return DKT_ERR_TOO_LARGE;
+    dim3 grid((D + GT - 1) / GT, (N + GT - 1) / GT, B), block(256);
+    hipLaunchKernelGGL(gram_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, Z, dZ, N, D, ep_scale);
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_rbf_bwd_f32(const float* W, const float* E, const float* lengthscale, float* Wp,
+                               float* dlengthscale, int B, int N, void* stream) {
+    if (!W || !E || !lengthscale || !Wp || !dlengthscale || B <= 0 || N <= 0) return DKT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rbf_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, W, E, lengthscale, Wp,
+                       dlengthscale, N);
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -1,0 +1,255 @@
+// dkt_mll.hip -- exact-GP marginal log likelihood of the C one-vs-rest models of an episode:
+// noise add, jittered Cholesky, log-det, mean cache alpha = K^-1 (y - m), and (training) the
+// gradient pieces W = d obj / d E, d logp / d(sv, mean, noise).
+//
+// GENERIC path (any N): one 256-thread workgroup per episode, classes processed in sequence
+// (the episode's W is accumulated by the same threads class after class -- no atomics, bitwise
+// reproducible).  The (N+1) x N working matrix lives in LDS when it fits (N <= ~190) and in a
+// caller-provided global workspace otherwise (N = 320/420 stress shapes).
+//
+// Working matrix Mw (row-major, leading dimension LD odd):
+//   rows 0..N-1 : lower triangle (p >= j) = K_c, overwritten by L;  strict upper triangle (p < j)
+//                 = the rows of an appended identity, which the same column sweep turns into
+//                 U = L^-T (so K^-1 = U U^T and alpha = U w need no separate triangular solve);
+//   row  N      : r = y_c - m_c, turned into w = L^-1 r by the sweep.
+// Right-looking sweep, column k:  d = Mw[k][k] (fail if !(d > 0), as LAPACK potrf / torch.cholesky);
+//   Mw[:,k] *= 1/sqrt(d);  Mw[p][j] -= Mw[p][k] Mw[j][k]  for j > k and (p >= j or p <= k).
+//
+// Replaces `-self.mll(output, targets)` + backward + the eval-mode mean cache
+// (reference methods/DKT.py:161-163, 177, 187, 252-254, 265, 330; methods/DKT_regression.py:53-56, 92),
+// i.e. GPyTorch psd_safe_cholesky / inv_quad_logdet / cholesky_solve.
+#include "dkt_common.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+struct MllArgs {
+    const float* E;
+    const float* Y;
+    long y_bstride;
+    const float* sv;
+    const float* mean;
+    const float* noise;
+    const float* cls_weight;
+    float* logp;
+    float* alpha;
+    float* L;
+    float* W;
+    float* dsv;
+    float* dmean;
+    float* dnoise;
+    float* jitter_used;
+    int32_t* info;
+    float* ws;
+    int B, C, N, LD;
+    float jitter0;
+    int max_tries;
+    unsigned flags;
+};
+
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+constexpr size_t MLL_LDS_LIMIT = 150 * 1024;
+
+__host__ __device__ inline int mll_ld(int N) { return N | 1; }
+inline size_t mll_vec_floats(int N) { return (size_t)3 * (N + 1) + 32; }
+inline size_t mll_mat_floats(int N) { return (size_t)(N + 1) * mll_ld(N); }
+inline bool mll_fits_lds(int N) { return (mll_vec_floats(N) + mll_mat_floats(N)) * 4 <= MLL_LDS_LIMIT; }
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int N = a.N, C = a.C, LD = a.LD, R = N + 1;
+    float* cs = smem;            // [R]  scaled column of the current sweep step
+    float* ldiag = cs + R;       // [R]  diag(L)
+    float* al = ldiag + R;       // [R]  alpha
+    float* red = al + R;         // [32] reduction scratch
+    float* Mw = GLOBAL ? (a.ws + (size_t)b * R * LD) : (red + 32);
+#define MW(p, j) Mw[(p) * LD + (j)]
+
+    const float* Eb = a.E + (size_t)b * N * N;
+    const bool want_grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
+    const bool want_chol = (a.flags & DKT_MLL_WANT_CHOL) != 0;
+    float* Wb = want_grad ? a.W + (size_t)b * N * N : nullptr;
+
+    for (int c = 0; c < C; ++c) {
+        const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
+        const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
+        int fail_at = 0;
+        float jit = 0.f;
+        for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
+            jit = 0.f;
+            if (attempt > 0) {
+                jit = a.jitter0;
+                for (int i = 1; i < attempt; ++i) jit *= 10.f;
+            }
+            __syncthreads();
+            // ---- form the working matrix ----
+            for (int idx = tid; idx < N * N; idx += 256) {
+                const int p = idx / N, j = idx - p * N;
+                float v = 0.f;
+                if (p >= j) {
+                    v = svc * Eb[idx];
+                    if (p == j) v += nzc + jit;
+                }
+                MW(p, j) = v;
+            }
+            for (int j = tid; j < N; j += 256) MW(N, j) = yc[j] - mc;
+            __syncthreads();
+            // ---- right-looking sweep ----
+            fail_at = 0;
+            for (int k = 0; k < N; ++k) {
+                const float d = MW(k, k);
+                if (!(d > 0.f)) { fail_at = k + 1; break; }   // block-uniform (same LDS/global word)
+                const float lkk = sqrtf(d);
+                const float rinv = 1.0f / lkk;
+                // column k (all rows but the pivot itself, which stays untouched until after the sweep,
+                // so the pivot read above needs no extra barrier)
+                for (int p = tid; p < R; p += 256) {
+                    if (p != k) {
+                        const float v = MW(p, k) * rinv;
+                        cs[p] = v;
+                        MW(p, k) = v;
+                    } else {
+                        cs[p] = rinv;
+                        ldiag[k] = lkk;
+                    }
+                }
+                __syncthreads();
+                for (int p = ty; p < R; p += 16) {
+                    const bool low = p <= k;
+                    const float cp = cs[p];
+                    for (int j = k + 1 + tx; j < N; j += 16) {
+                        if (low || p >= j) MW(p, j) -= cp * cs[j];
+                    }
+                }
+                __syncthreads();
+            }
+            if (fail_at == 0) break;
+        }
+        __syncthreads();
+        const size_t bc = (size_t)b * C + c;
+        if (fail_at != 0) {
+            // not positive definite after every jitter retry: poison the outputs (GPyTorch raises NotPSDError)
+            const float qnan = __int_as_float(0x7fc00000);
+            if (tid == 0) {
+                a.logp[bc] = qnan;
+                a.jitter_used[bc] = jit;
+                a.info[bc] = fail_at;
+                if (want_grad) { a.dsv[bc] = qnan; a.dmean[bc] = qnan; a.dnoise[bc] = qnan; }
+            }
+            for (int i = tid; i < N; i += 256) a.alpha[bc * N + i] = qnan;
+            if (want_grad)
+                for (int idx = tid; idx < N * N; idx += 256) Wb[idx] = qnan;
+            if (want_chol)
+                for (int idx = tid; idx < N * N; idx += 256) a.L[bc * N * N + idx] = qnan;
+            continue;
+        }
+        for (int k = tid; k < N; k += 256) MW(k, k) = 1.0f / ldiag[k];   // U_kk = 1 / L_kk
+        __syncthreads();
+        // ---- quad form, log-det, alpha = U w ----
+        float qpart = 0.f, lpart = 0.f;
+        for (int k = tid; k < N; k += 256) {
+            const float w = MW(N, k);
+            qpart += w * w;
+            lpart += logf(ldiag[k]);
+        }
+        const float quad = block_sum_256(qpart, red);
+        const float logdet_half = block_sum_256(lpart, red);
+        float apart = 0.f;
+        for (int i = tid; i < N; i += 256) {
+            float s = 0.f;
+            for (int m = i; m < N; ++m) s += MW(i, m) * MW(N, m);
+            al[i] = s;
+            a.alpha[bc * N + i] = s;
+            apart += s;
+        }
+        const float asum = block_sum_256(apart, red);   // also orders al[] before the readers below
+        if (tid == 0) {
+            a.logp[bc] = -0.5f * quad - logdet_half - (float)N * HALF_LOG_2PI;
+            a.jitter_used[bc] = jit;
+            a.info[bc] = 0;
+        }
+        if (want_chol) {
+            float* Lb = a.L + bc * N * N;
+            for (int idx = tid; idx < N * N; idx += 256) {
+                const int p = idx / N, j = idx - p * N;
+                Lb[idx] = (p > j) ? MW(p, j) : (p == j ? ldiag[p] : 0.f);
+            }
+        }
+        if (want_grad) {
+            const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
+            const float coef = cw * svc;
+            float dsv_part = 0.f, tr_part = 0.f;
+            for (int i = ty; i < N; i += 16) {
+                for (int j = tx; j <= i; j += 16) {
+                    float kinv = 0.f;
+                    for (int m = i; m < N; ++m) kinv += MW(i, m) * MW(j, m);
+                    const float mcv = 0.5f * (al[i] * al[j] - kinv);
+                    const float e = Eb[(size_t)i * N + j];
+                    if (i == j) { dsv_part += mcv * e; tr_part += mcv; }
+                    else dsv_part += 2.0f * mcv * e;
+                    const float wv = coef * mcv;
+                    if (c == 0) {
+                        Wb[(size_t)i * N + j] = wv;
+                        if (i != j) Wb[(size_t)j * N + i] = wv;
+                    } else {
+                        Wb[(size_t)i * N + j] += wv;
+                        if (i != j) Wb[(size_t)j * N + i] += wv;
+                    }
+                }
+            }
+            const float dsv = block_sum_256(dsv_part, red);
+            const float trm = block_sum_256(tr_part, red);
+            if (tid == 0) {
+                a.dsv[bc] = dsv;
+                a.dmean[bc] = asum;
+                a.dnoise[bc] = trm;
+            }
+        }
+    }
+#undef MW
+}
+
+}  // namespace
+
+extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
+    (void)C;
+    if (B <= 0 || N <= 0) return 0;
+    if (mll_fits_lds(N)) return 0;
+    return (size_t)B * mll_mat_floats(N) * sizeof(float);
+}
+
+extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv, const float* mean,
+                           const float* noise, int B, int C, int N, float jitter0, int max_tries,
+                           unsigned flags, const float* cls_weight, float* logp, float* alpha, float* L,
+                           float* W, float* dsv, float* dmean, float* dnoise, float* jitter_used,
+                           int32_t* info, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!E || !Y || !sv || !mean || !noise || !logp || !alpha || !jitter_used || !info) return DKT_ERR_BAD_ARG;
+    if (B <= 0 || C <= 0 || N <= 0 || max_tries < 0 || max_tries > 8 || y_bstride < 0) return DKT_ERR_BAD_ARG;
+    if ((flags & DKT_MLL_WANT_GRAD) && (!W || !dsv || !dmean || !dnoise)) return DKT_ERR_BAD_ARG;
+    if ((flags & DKT_MLL_WANT_CHOL) && !L) return DKT_ERR_BAD_ARG;
+    MllArgs a;
+    a.E = E; a.Y = Y; a.y_bstride = y_bstride; a.sv = sv; a.mean = mean; a.noise = noise;
+    a.cls_weight = cls_weight; a.logp = logp; a.alpha = alpha; a.L = L; a.W = W; a.dsv = dsv;
+    a.dmean = dmean; a.dnoise = dnoise; a.jitter_used = jitter_used; a.info = info;
+    a.ws = (float*)workspace; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
+    a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
+    hipStream_t st = (hipStream_t)stream;
+    if (mll_fits_lds(N)) {
+        const size_t lds = (mll_vec_floats(N) + mll_mat_floats(N)) * sizeof(float);
+        if (lds > 48 * 1024) {
+            if (hipFuncSetAttribute((const void*)mll_generic_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return DKT_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(mll_generic_kernel<false>, dim3(B), dim3(256), lds, st, a);
+    } else {
+        const size_t need = dkt_mll_workspace_bytes(B, C, N);
+        if (!workspace || workspace_bytes < need) return DKT_ERR_WORKSPACE;
+        const size_t lds = mll_vec_floats(N) * sizeof(float);
+        hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(B), dim3(256), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -1,0 +1,134 @@
+"""Episode-parallel data parallelism: one process per GPU, episodes sharded by rank, ONE all-reduce
+per optimizer step over a flat fp32 gradient bucket (backbone + bn_out + GP hyper-parameters).
+
+The reference is single-process / single-GPU (no torch.distributed anywhere); this
+is the build's addition.  Backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+Bucket sizes: Conv4 + bn_out(1600) + 10 hypers = 116 298 floats = 465 KB -> latency-bound on xGMI
+(one collective, not one per tensor); ResNet18 = 44.7 MB -> ~0.5 ms ring over one 153 GB/s link.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """torchrun-style bring-up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns the local rank.  No-op when WORLD_SIZE is unset or 1."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return local
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend)
+    return local
+
+
+def shard_episodes(n_episodes: int, rank_: Optional[int] = None, world: Optional[int] = None) -> range:
+    """Contiguous split of an episode list (test time: 600 episodes) -- rank r gets
+    [r*n/W, (r+1)*n/W)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    lo = (n_episodes * r) // w
+    hi = (n_episodes * (r + 1)) // w
+    return range(lo, hi)
+
+
+class GradBucket:
+    """Flat fp32 bucket over the parameters that require grad (each tensor once, aliases de-duplicated).
+    `allreduce_mean()` averages the gradients over ranks with ONE collective."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        seen, self.params = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        self.numel = sum(p.numel() for p in self.params)
+        self._flat: Optional[torch.Tensor] = None
+
+    def _buffer(self) -> torch.Tensor:
+        p0 = self.params[0]
+        if self._flat is None or self._flat.device != p0.device:
+            self._flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
+        return self._flat
+
+    def allreduce_mean(self) -> None:
+        if not is_distributed() or not self.params:
+            return
+        flat = self._buffer()
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].reshape(p.shape).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].reshape(p.shape))
+            off += n
+
+
+def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def gather_accuracies(acc_local: Sequence[float], device=None) -> List[float]:
+    """Test time: every rank evaluates its shard of the episode list; all ranks get the full list
+    (rank order = episode order for the contiguous split of shard_episodes)."""
+    if not is_distributed():
+        return list(acc_local)
+    w = dist.get_world_size()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n_local = torch.tensor([len(acc_local)], device=device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n_local) for _ in range(w)]
+    dist.all_gather(sizes, n_local)
+    mx = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(mx, device=device, dtype=torch.float64)
+    if len(acc_local):
+        buf[:len(acc_local)] = torch.tensor(list(acc_local), device=device, dtype=torch.float64)
+    bufs = [torch.zeros_like(buf) for _ in range(w)]
+    dist.all_gather(bufs, buf)
+    out: List[float] = []
+    for s, b in zip(sizes, bufs):
+        out += b[:int(s.item())].tolist()
+    return out
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
+    """Same initial weights / buffers on every rank."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)

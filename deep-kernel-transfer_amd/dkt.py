@@ -1,0 +1,333 @@
+"""Classification DKT on the HIP hot path -- keeps the method surface of the reference's
+`methods/DKT.py` (class DKT :32-335) so it drops into train.py / test.py / test_uncertainty.py:
+
+    DKT(model_func, n_way, n_support)        train.py:145, test.py:80
+    .init_summary()                          train.py:146
+    .train_loop(epoch, loader, optimizer)    train.py:50     (optimizer ignored, Adam re-created: DKT.py:114)
+    .test_loop(loader, record=None, return_std=False)        train.py:56, test.py:161
+    .correct(x, N=0, laplace=False) -> (top1_correct, count, avg_loss)       DKT.py:199-272
+    .get_logits(x) -> [n_way*n_query, n_way]                 test_uncertainty.py:197
+    .set_forward / .set_forward_loss         stubs (DKT.py:73-77)
+    .feature / .feature_extractor / .model / .likelihood / .mll / .normalize / .iteration / .writer
+
+What changed underneath: the n_way GPyTorch ExactGP models + SumMarginalLogLikelihood are replaced by
+stacked hyper-parameters (gp.ExactGPHypers) and the HIP kernels behind ops.* -- ONE Gram per episode
+instead of one per class, all class Choleskys in one launch, gradients produced in the same launch,
+no per-class host syncs (DKT.py:151-154, 180, 190).
+"""
+from __future__ import annotations
+
+from time import gmtime, strftime
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import configs, distributed, ops
+from .gp import ExactGPHypers, LINEAR_KINDS, RBF_KINDS
+from .meta_template import MetaTemplate
+
+try:  # optional, as in the reference (DKT.py:16-21)
+    from tensorboardX import SummaryWriter
+    IS_TBX_INSTALLED = True
+except ImportError:
+    IS_TBX_INSTALLED = False
+
+
+class _LikelihoodView(nn.Module):
+    """`model.likelihood`: the Gaussian noise lives in ExactGPHypers.raw_noise (shared storage)."""
+
+    def __init__(self, hypers: ExactGPHypers):
+        super().__init__()
+        object.__setattr__(self, "_hypers", hypers)
+
+    @property
+    def noise(self):
+        return self._hypers.noise
+
+
+class _MllView(nn.Module):
+    """`model.mll`: callable kept for surface parity; evaluates the exact MLL of stored train data."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, z, targets):
+        loss, _ = self._owner._episode_loss(z, targets)
+        return -loss
+
+
+class DKT(MetaTemplate):
+    def __init__(self, model_func, n_way, n_support, kernel_type=None):
+        super(DKT, self).__init__(model_func, n_way, n_support)
+        self.kernel_type = configs.kernel_type if kernel_type is None else kernel_type
+        self.leghtscale_list = None
+        self.noise_list = None
+        self.outputscale_list = None
+        self.iteration = 0
+        self.writer = None
+        self.feature_extractor = self.feature          # same module under two names (DKT.py:41)
+        self.get_model_likelihood_mll()
+        if self.kernel_type == "cossim":
+            self.normalize = True
+        elif self.kernel_type == "bncossim":
+            self.normalize = True
+            latent_size = int(np.prod(self.feature_extractor.final_feat_dim))
+            self.feature_extractor.trunk.add_module("bn_out", nn.BatchNorm1d(latent_size))
+        else:
+            self.normalize = False
+        self.jitter0 = 1e-6       # gpytorch psd_safe_cholesky fp32 default
+        self.max_tries = 3
+        self._target_cache = {}
+        self._grad_bucket = None
+        self._last = {}
+
+    # ------------------------------------------------------------------ construction
+    def init_summary(self):
+        if IS_TBX_INSTALLED:
+            time_string = strftime("%d%m%Y_%H%M%S", gmtime())
+            self.writer = SummaryWriter(log_dir="./log/" + time_string)
+
+    def get_model_likelihood_mll(self, train_x_list=None, train_y_list=None):
+        """n_way exact GPs sharing the deep kernel; noise = 0.1 frozen (DKT.py:58-71, 346-347)."""
+        self.model = ExactGPHypers(self.n_way, self.kernel_type, fixed_noise=0.1)
+        self.likelihood = _LikelihoodView(self.model)
+        self.mll = _MllView(self)
+        return self.model, self.likelihood, self.mll
+
+    def set_forward(self, x, is_feature=False):
+        pass
+
+    def set_forward_loss(self, x):
+        pass
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def device(self):
+        return self.model.mean_constant.device
+
+    def _targets(self, n_way, per_class, device):
+        """+-1 one-vs-rest targets [C, N], built on the device once per shape (DKT.py:129-136)."""
+        key = (n_way, per_class, str(device))
+        y = self._target_cache.get(key)
+        if y is None:
+            cls = torch.arange(n_way, device=device).repeat_interleave(per_class)
+            y = torch.where(cls.unsqueeze(0) == torch.arange(n_way, device=device).unsqueeze(1), 1.0, -1.0)
+            y = y.to(torch.float32).contiguous()
+            self._target_cache[key] = y
+        return y
+
+    def _check_way(self, n_way):
+        if n_way != self.model.n_models:
+            raise RuntimeError("DKT was built with %d GP models but the episode has %d classes "
+                               "(train_n_way must equal test_n_way for DKT)" % (self.model.n_models, n_way))
+
+    def _embed(self, x):
+        z = self.feature_extractor.forward(x)
+        if self.normalize:
+            z = F.normalize(z, p=2, dim=1)
+        return z
+
+    def _hypers(self):
+        m = self.model
+        return m.scale_times_variance(), m.mean, m.noise
+
+    def _episode_loss(self, z, y):
+        """loss = -(1/C) sum_c logp_c / N for ONE episode z:[N,D] (or a batch [B,N,D] -> mean over B)."""
+        zb = z if z.dim() == 3 else z.unsqueeze(0)
+        n = zb.shape[1]
+        c = y.shape[-2]
+        sv, mean, noise = self._hypers()
+        cw = torch.full((c,), -1.0 / (c * n), device=zb.device, dtype=torch.float32)
+        if self.kernel_type in LINEAR_KINDS:
+            obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zb, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+        else:
+            e = ops.base_matrix(zb, self.kernel_type, self.model.lengthscale)
+            obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
+        return obj.mean(), aux
+
+    def _posterior(self, z_cond, y, z_star, e_cond=None):
+        """Mean cache on the conditioning set, posterior means [C,M] and labels [M] at z_star."""
+        sv, mean, noise = self._hypers()
+        kind = ops.kind_id(self.kernel_type)
+        ls = self.model.lengthscale
+        zc = z_cond.detach().unsqueeze(0)
+        if e_cond is None or kind == ops.KERNEL_RBF:
+            e_cond = ops.gram(zc, None, kind, ls)
+        out = ops.mll(e_cond, y, sv.detach(), mean.detach(), noise.detach(), jitter0=self.jitter0, max_tries=self.max_tries)
+        ex = ops.gram(z_star.detach().unsqueeze(0), zc, kind, ls)
+        mu, labels = ops.predict(ex, out["alpha"], sv.detach(), mean.detach())
+        return mu[0], labels[0], out
+
+    def _sync_grads(self):
+        if distributed.is_distributed():
+            if self._grad_bucket is None:
+                self._grad_bucket = distributed.GradBucket(self.parameters())
+            self._grad_bucket.allreduce_mean()
+
+    # ------------------------------------------------------------------ training
+    def train_loop(self, epoch, train_loader, optimizer, print_freq=10):
+        # the optimizer argument is ignored and Adam re-created every call, as the reference does
+        optimizer = torch.optim.Adam([{'params': self.model.parameters(), 'lr': 1e-4},
+                                      {'params': self.feature_extractor.parameters(), 'lr': 1e-3}])
+        dev = self.device
+        for i, (x, _) in enumerate(train_loader):
+            self.n_query = x.size(1) - self.n_support
+            if self.change_way:
+                self.n_way = x.size(0)
+            self._check_way(self.n_way)
+            per = self.n_support + self.n_query
+            x_all = x.contiguous().view(self.n_way * per, *x.size()[2:]).to(dev, non_blocking=True)
+            y_targets = self._targets(self.n_way, per, dev)
+
+            self.model.train()
+            self.likelihood.train()
+            self.feature_extractor.train()
+            z_train = self._embed(x_all)
+
+            # hyper-parameter means for the log line, read BEFORE the step (DKT.py:145-157); kept on
+            # the device, converted to Python floats only when printed
+            with torch.no_grad():
+                log_outputscale = self.model.outputscale.mean()
+                log_noise = self.model.noise.mean()
+                ls = self.model.lengthscale
+                log_lengthscale = ls.mean() if ls is not None else torch.zeros((), device=dev)
+
+            optimizer.zero_grad()
+            loss, aux = self._episode_loss(z_train, y_targets)
+            loss.backward()
+            self._sync_grads()
+            optimizer.step()
+
+            self.iteration = i + (epoch * len(train_loader))
+            if self.writer is not None:
+                self.writer.add_scalar('loss', loss, self.iteration)
+
+            # evaluation on support / query with eval-mode features, conditioning on the (stale)
+            # train-mode features and the post-step hyper-parameters (DKT.py:170-192)
+            with torch.no_grad():
+                self.model.eval()
+                self.likelihood.eval()
+                self.feature_extractor.eval()
+                z_eval = self._embed(x_all).detach().view(self.n_way, per, -1)
+                z_support = z_eval[:, :self.n_support].reshape(self.n_way * self.n_support, -1)
+                z_query = z_eval[:, self.n_support:].reshape(self.n_way * self.n_query, -1)
+                z_star = torch.cat([z_support, z_query], 0)
+                _, labels, _ = self._posterior(z_train, y_targets, z_star, e_cond=aux["e"])
+                cls = torch.arange(self.n_way, device=dev, dtype=torch.int32)
+                ns = self.n_way * self.n_support
+                acc_support = (labels[:ns] == cls.repeat_interleave(self.n_support)).float().mean() * 100.0
+                acc_query = (labels[ns:] == cls.repeat_interleave(self.n_query)).float().mean() * 100.0
+                if self.writer is not None:
+                    self.writer.add_scalar('GP_support_accuracy', acc_support, self.iteration)
+                    self.writer.add_scalar('GP_query_accuracy', acc_query, self.iteration)
+            self._last = dict(loss=loss.detach(), acc_support=acc_support, acc_query=acc_query, info=aux["info"])
+
+            if i % print_freq == 0:
+                if self.writer is not None:
+                    self.writer.add_histogram('z_support', z_support, self.iteration)
+                if int(aux["info"].abs().max().item()) != 0:
+                    raise RuntimeError("DKT: kernel matrix not positive definite after jitter retries "
+                                       "(GPyTorch raises NotPSDError here)")
+                print('Epoch [{:d}] [{:d}/{:d}] | Outscale {:f} | Lenghtscale {:f} | Noise {:f} | Loss {:f} | Supp. {:f} | Query {:f}'.format(
+                    epoch, i, len(train_loader), log_outputscale.item(), log_lengthscale.item(), log_noise.item(),
+                    loss.item(), acc_support.item(), acc_query.item()))
+
+    # ------------------------------------------------------------------ evaluation
+    def _split(self, x):
+        dev = self.device
+        x_support = x[:, :self.n_support].contiguous().view(self.n_way * self.n_support, *x.size()[2:]).to(dev)
+        x_query = x[:, self.n_support:].contiguous().view(self.n_way * self.n_query, *x.size()[2:]).to(dev)
+        return x_support, x_query
+
+    def correct(self, x, N=0, laplace=False):
+        self._check_way(self.n_way)
+        x_support, x_query = self._split(x)
+        y_query = np.repeat(range(self.n_way), self.n_query)
+
+        if laplace:   # sklearn Laplace GPC, "not the method used in the paper" (DKT.py:207-222)
+            from sklearn.gaussian_process import GaussianProcessClassifier
+            from sklearn.gaussian_process.kernels import RBF
+            y_support = np.repeat(range(self.n_way), self.n_support)
+            kernel = 1.0 * RBF(length_scale=0.1, length_scale_bounds=(0.1, 10.0))
+            gp = GaussianProcessClassifier(kernel=kernel, optimizer=None)
+            with torch.no_grad():
+                z_support = self._embed(x_support).detach()
+                z_query = self._embed(x_query).detach()
+            gp.fit(z_support.cpu().numpy(), y_support)
+            y_pred = gp.predict(z_query.cpu().numpy())
+            return float(np.sum(y_pred == y_query)), len(y_query), 0.0
+
+        dev = self.device
+        y_targets = self._targets(self.n_way, self.n_support, dev)
+        z_train = self._embed(x_support).detach()
+
+        self.model.train()
+        self.likelihood.train()
+        self.feature_extractor.eval()
+
+        avg_loss = 0.0
+        if N > 0:   # test-time adaptation of the GP hyper-parameters only (DKT.py:242-256)
+            optimizer = torch.optim.Adam([{'params': self.model.parameters()}], lr=1e-3)
+            for _ in range(0, N):
+                optimizer.zero_grad()
+                loss, _ = self._episode_loss(z_train, y_targets)
+                loss.backward()
+                optimizer.step()
+                avg_loss = avg_loss + loss.item()
+
+        with torch.no_grad():
+            self.model.eval()
+            self.likelihood.eval()
+            self.feature_extractor.eval()
+            z_query = self._embed(x_query).detach()
+            _, labels, out = self._posterior(z_train, y_targets, z_query)
+            y_q = torch.arange(self.n_way, device=dev, dtype=torch.int32).repeat_interleave(self.n_query)
+            stats = torch.stack([(labels == y_q).sum().float(), out["info"].abs().max().float()]).cpu()
+            if stats[1].item() != 0:
+                raise RuntimeError("DKT.correct: kernel matrix not positive definite after jitter retries")
+            top1_correct = float(stats[0].item())
+            count_this = len(y_query)
+        return float(top1_correct), count_this, avg_loss / float(N + 1e-10)
+
+    def test_loop(self, test_loader, record=None, return_std=False):
+        acc_all = []
+        iter_num = len(test_loader)
+        for i, (x, _) in enumerate(test_loader):
+            self.n_query = x.size(1) - self.n_support
+            if self.change_way:
+                self.n_way = x.size(0)
+            correct_this, count_this, loss_value = self.correct(x)
+            acc_all.append(correct_this / count_this * 100)
+            if i % 100 == 0:
+                acc_mean = np.mean(np.asarray(acc_all))
+                print('Test | Batch {:d}/{:d} | Loss {:f} | Acc {:f}'.format(i, len(test_loader), loss_value, acc_mean))
+        if distributed.is_distributed():   # every rank evaluated its own shard of the episode list
+            acc_all = distributed.gather_accuracies(acc_all)
+            iter_num = len(acc_all)
+        acc_all = np.asarray(acc_all)
+        acc_mean = np.mean(acc_all)
+        acc_std = np.std(acc_all)
+        print('%d Test Acc = %4.2f%% +- %4.2f%%' % (iter_num, acc_mean, 1.96 * acc_std / np.sqrt(iter_num)))
+        if self.writer is not None:
+            self.writer.add_scalar('test_accuracy', acc_mean, self.iteration)
+        if return_std:
+            return acc_mean, acc_std
+        return acc_mean
+
+    def get_logits(self, x):
+        self.n_query = x.size(1) - self.n_support
+        self._check_way(self.n_way)
+        x_support, x_query = self._split(x)
+        y_targets = self._targets(self.n_way, self.n_support, self.device)
+        z_train = self._embed(x_support).detach()
+        with torch.no_grad():
+            self.model.eval()
+            self.likelihood.eval()
+            self.feature_extractor.eval()
+            z_query = self._embed(x_query).detach()
+            mu, _, _ = self._posterior(z_train, y_targets, z_query)
+        return mu.t().contiguous()    # [n_way*n_query, n_way] raw posterior means (DKT.py:331-335)

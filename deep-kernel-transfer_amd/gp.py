@@ -1,0 +1,148 @@
+"""Hyper-parameters of the C independent exact GPs, stored STACKED ([C] tensors) so one kernel launch
+serves every class model of an episode.
+
+Mirrors what the reference builds from GPyTorch objects (reference methods/DKT.py:58-71, 337-378;
+methods/DKT_regression.py:25-37, 112-129):
+  * ConstantMean            -> `mean_constant` [C], init 0, learned
+  * ScaleKernel             -> `raw_outputscale` [C], outputscale = softplus(raw), init raw 0 -> ln 2
+  * LinearKernel.variance   -> `raw_variance` [1]; cossim/bncossim: variance = 1.0 and frozen (DKT.py:366-370)
+  * RBFKernel.lengthscale   -> `raw_lengthscale` [1], lengthscale = softplus(raw), init ln 2
+  * GaussianLikelihood      -> `raw_noise` [C], noise = softplus(raw) + 1e-4 (GreaterThan(1e-4));
+                               classification: noise forced to 0.1 and frozen (DKT.py:346-347);
+                               regression: learned, init softplus(0) + 1e-4.
+`models[c]` exposes the attribute paths the reference's logging code reads
+(`single_model.covar_module.base_kernel.lengthscale`, `.likelihood.noise`, `.covar_module.outputscale`,
+DKT.py:148-154).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+NOISE_LOWER_BOUND = 1e-4
+LINEAR_KINDS = ("linear", "cossim", "bncossim")
+RBF_KINDS = ("rbf", "RBF")
+SUPPORTED_CLASSIFICATION = LINEAR_KINDS + RBF_KINDS
+
+
+def inv_softplus(y: float) -> float:
+    return math.log(math.expm1(y)) if y < 30.0 else y
+
+
+class ExactGPHypers(nn.Module):
+    def __init__(self, n_models: int, kernel: str = "bncossim", fixed_noise: Optional[float] = 0.1):
+        super().__init__()
+        if kernel not in SUPPORTED_CLASSIFICATION:
+            raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
+        self.n_models = n_models
+        self.kernel = kernel
+        self.mean_constant = nn.Parameter(torch.zeros(n_models))
+        self.raw_outputscale = nn.Parameter(torch.zeros(n_models))
+        if kernel in ("cossim", "bncossim"):
+            # variance = 1.0, frozen
+            self.raw_variance = nn.Parameter(torch.full((1,), inv_softplus(1.0)), requires_grad=False)
+        elif kernel == "linear":
+            self.raw_variance = nn.Parameter(torch.zeros(1))
+        else:
+            self.register_parameter("raw_variance", None)
+        if kernel in RBF_KINDS:
+            self.raw_lengthscale = nn.Parameter(torch.zeros(1))
+        else:
+            self.register_parameter("raw_lengthscale", None)
+        if fixed_noise is not None:
+            raw = inv_softplus(fixed_noise - NOISE_LOWER_BOUND)
+            self.raw_noise = nn.Parameter(torch.full((n_models,), raw), requires_grad=False)
+        else:
+            self.raw_noise = nn.Parameter(torch.zeros(n_models))
+
+    # ---- constrained values (differentiable torch ops on [C]-sized tensors) ----
+    @property
+    def outputscale(self) -> torch.Tensor:
+        return F.softplus(self.raw_outputscale)
+
+    @property
+    def variance(self) -> Optional[torch.Tensor]:
+        return None if self.raw_variance is None else F.softplus(self.raw_variance)
+
+    @property
+    def lengthscale(self) -> Optional[torch.Tensor]:
+        return None if self.raw_lengthscale is None else F.softplus(self.raw_lengthscale)
+
+    @property
+    def noise(self) -> torch.Tensor:
+        return F.softplus(self.raw_noise) + NOISE_LOWER_BOUND
+
+    @property
+    def mean(self) -> torch.Tensor:
+        return self.mean_constant
+
+    def scale_times_variance(self) -> torch.Tensor:
+        """sv[c] = outputscale[c] * variance: the factor of the base matrix E in K_c."""
+        s = self.outputscale
+        v = self.variance
+        return s if v is None else s * v
+
+    @property
+    def models(self):
+        return [_ModelView(self, c) for c in range(self.n_models)]
+
+    def __len__(self):
+        return self.n_models
+
+    # ---- reference (GPyTorch IndependentModelList) checkpoint keys ----
+    def load_reference_state_dict(self, state: dict, prefix: str = "model.") -> int:
+        """Copy hyper-parameters out of a reference DKT `state_dict()` (GPyTorch 1.0.1 key names:
+        `model.models.{c}.mean_module.constant`, `.covar_module.raw_outputscale`,
+        `.covar_module.base_kernel.raw_variance|raw_lengthscale`, `.likelihood.noise_covar.raw_noise`).
+        Returns the number of tensors consumed.  Key names could not be diffed against GPyTorch here."""
+        used = 0
+        with torch.no_grad():
+            for c in range(self.n_models):
+                base = "%smodels.%d." % (prefix, c)
+                for key, (dst, idx) in {
+                    base + "mean_module.constant": (self.mean_constant, c),
+                    base + "covar_module.raw_outputscale": (self.raw_outputscale, c),
+                    base + "likelihood.noise_covar.raw_noise": (self.raw_noise, c),
+                }.items():
+                    if key in state:
+                        dst[idx] = state[key].reshape(-1)[0].to(dst)
+                        used += 1
+                for key, dst in {
+                    base + "covar_module.base_kernel.raw_variance": self.raw_variance,
+                    base + "covar_module.base_kernel.raw_lengthscale": self.raw_lengthscale,
+                }.items():
+                    if key in state and dst is not None and c == 0:
+                        dst[0] = state[key].reshape(-1)[0].to(dst)
+                        used += 1
+        return used
+
+
+class _Attr:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _ModelView:
+    """Read-only view of class model c with GPyTorch-like attribute paths."""
+
+    def __init__(self, hyp: ExactGPHypers, c: int):
+        self._h, self._c = hyp, c
+
+    @property
+    def covar_module(self):
+        h, c = self._h, self._c
+        ls = h.lengthscale
+        return _Attr(outputscale=h.outputscale[c], raw_outputscale=h.raw_outputscale[c],
+                     base_kernel=_Attr(lengthscale=ls, variance=h.variance))
+
+    @property
+    def likelihood(self):
+        return _Attr(noise=self._h.noise[self._c:self._c + 1])
+
+    @property
+    def mean_module(self):
+        return _Attr(constant=self._h.mean_constant[self._c:self._c + 1])

@@ -1,0 +1,329 @@
+"""Torch-facing wrappers over the C ABI (include/dkt_abi.h): raw device pointers + the current HIP
+stream go down, nothing else.  PyTorch only owns the memory and the stream.
+
+Every function REQUIRES float32 CUDA (ROCm) tensors and raises otherwise -- there is no CPU path.
+
+Autograd surface
+  episode_loss_linear(z, y, sv, mean, noise, cls_weight) -> obj[B]   (fused: gram -> mll -> gram_bwd)
+  base_matrix(z, kind, lengthscale) -> E[B,N,N]                       (differentiable Gram / RBF)
+  mll_objective(e, y, sv, mean, noise, cls_weight) -> obj[B], aux     (differentiable in e, sv, mean, noise)
+which replace `-self.mll(self.model(*inputs), targets)` + `.backward()` of the reference
+(methods/DKT.py:161-163, methods/DKT_regression.py:53-56).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+KERNEL_LINEAR = 0
+KERNEL_RBF = 1
+MLL_WANT_GRAD = 1
+MLL_WANT_CHOL = 2
+
+LINEAR_KINDS = ("linear", "cossim", "bncossim")
+RBF_KINDS = ("rbf", "RBF")
+
+
+def kind_id(kernel: str) -> int:
+    if kernel in LINEAR_KINDS:
+        return KERNEL_LINEAR
+    if kernel in RBF_KINDS:
+        return KERNEL_RBF
+    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
+
+
+def _req(t: torch.Tensor, name: str, ndim: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("dkt_amd.ops: `%s` must be a CUDA/ROCm tensor -- the DKT hot path is HIP-only "
+                           "(no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("dkt_amd.ops: `%s` must be float32, got %s" % (name, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError("dkt_amd.ops: `%s` must have %d dims, got %s" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-kernel timing (bench.py): HIP events recorded on the stream the kernel is launched on
+# (torch's current stream), read back after the timed region -- no synchronisation while recording.
+_kernel_events = None
+
+
+def kernel_timing(enable: bool) -> None:
+    global _kernel_events
+    _kernel_events = {} if enable else None
+
+
+def kernel_timing_results() -> dict:
+    """name -> (launches, mean ms).  Call after torch.cuda.synchronize()."""
+    out = {}
+    for name, pairs in (_kernel_events or {}).items():
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _kernel_events is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _kernel_events is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _kernel_events.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
+# ------------------------------------------------------------------------------------------------
+# raw (non-differentiable) entry points
+# ------------------------------------------------------------------------------------------------
+def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_LINEAR,
+         lengthscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """E[b] = k(a[b], bm[b]); a:[B,M,D], bm:[B,N,D] or None (symmetric)."""
+    a = _req(a, "a", 3)
+    b_, m, d = a.shape
+    if bm is not None:
+        bm = _req(bm, "bm", 3)
+        if bm.shape[0] != b_ or bm.shape[2] != d:
+            raise RuntimeError("gram: shape mismatch %s vs %s" % (tuple(a.shape), tuple(bm.shape)))
+        n = bm.shape[1]
+    else:
+        n = m
+    if kind == KERNEL_RBF:
+        lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
+    e = torch.empty((b_, m, n), device=a.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_gram_f32"):
+        st = lib.dkt_gram_f32(_p(a), _p(bm), _p(e), b_, m, n, d, kind, _p(lengthscale), _stream())
+    _lib.check(st, "dkt_gram_f32")
+    return e
+
+
+def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
+        want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
+        jitter0: float = 1e-6, max_tries: int = 3) -> dict:
+    """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N]."""
+    e = _req(e, "e", 3)
+    b_, n, n2 = e.shape
+    if n != n2:
+        raise RuntimeError("mll: e must be [B,N,N]")
+    y = _req(y, "y")
+    if y.dim() == 2:
+        c_, y_bstride = y.shape[0], 0
+    elif y.dim() == 3 and y.shape[0] == b_:
+        c_, y_bstride = y.shape[1], y.shape[1] * n
+    else:
+        raise RuntimeError("mll: y must be [C,N] or [B,C,N]")
+    if y.shape[-1] != n:
+        raise RuntimeError("mll: y last dim %d != N %d" % (y.shape[-1], n))
+    sv = _req(sv.reshape(-1), "sv", 1)
+    mean = _req(mean.reshape(-1), "mean", 1)
+    noise = _req(noise.reshape(-1), "noise", 1)
+    if not (sv.numel() == mean.numel() == noise.numel() == c_):
+        raise RuntimeError("mll: sv/mean/noise must have C=%d elements" % c_)
+    dev = e.device
+    logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
+    jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
+    flags = 0
+    chol = w = dsv = dmean = dnoise = None
+    if want_chol:
+        flags |= MLL_WANT_CHOL
+        chol = torch.empty((b_, c_, n, n), device=dev, dtype=torch.float32)
+    if want_grad:
+        flags |= MLL_WANT_GRAD
+        w = torch.empty((b_, n, n), device=dev, dtype=torch.float32)
+        dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    if cls_weight is not None:
+        cls_weight = _req(cls_weight.reshape(-1), "cls_weight", 1)
+    lib = _lib.load()
+    ws_bytes = int(lib.dkt_mll_workspace_bytes(b_, c_, n))
+    ws = torch.empty((max(ws_bytes, 4) + 3) // 4, device=dev, dtype=torch.float32) if ws_bytes else None
+    with _timed("dkt_mll_f32"):
+        st = lib.dkt_mll_f32(_p(e), _p(y), y_bstride, _p(sv), _p(mean), _p(noise), b_, c_, n,
+                             float(jitter0), int(max_tries), flags, _p(cls_weight), _p(logp), _p(alpha),
+                             _p(chol), _p(w), _p(dsv), _p(dmean), _p(dnoise), _p(jit), _p(info), _p(ws),
+                             ws_bytes, _stream())
+    _lib.check(st, "dkt_mll_f32")
+    return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
+
+
+def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dZ[b] = ep_scale[b] * (W[b] + W[b]^T) Z[b]."""
+    w = _req(w, "w", 3)
+    z = _req(z, "z", 3)
+    b_, n, d = z.shape
+    if tuple(w.shape) != (b_, n, n):
+        raise RuntimeError("gram_bwd: w must be [B,N,N]")
+    if ep_scale is not None:
+        ep_scale = _req(ep_scale.reshape(-1), "ep_scale", 1)
+        if ep_scale.numel() != b_:
+            raise RuntimeError("gram_bwd: ep_scale must have B elements")
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    with _timed("dkt_gram_bwd_f32"):
+        st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale), _stream())
+    _lib.check(st, "dkt_gram_bwd_f32")
+    return dz
+
+
+def rbf_bwd(w: torch.Tensor, e: torch.Tensor, lengthscale: torch.Tensor):
+    w = _req(w, "w", 3)
+    e = _req(e, "e", 3)
+    lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
+    b_, n, _ = e.shape
+    wp = torch.empty_like(e)
+    dl = torch.empty((b_,), device=e.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dkt_rbf_bwd_f32(_p(w), _p(e), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream()), "dkt_rbf_bwd_f32")
+    return wp, dl
+
+
+def predict(ex: torch.Tensor, alpha: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, want_labels: bool = True):
+    """mu[b,c,q] = mean[c] + sv[c] sum_n ex[b,q,n] alpha[b,c,n]; labels[b,q] = argmax_c mu."""
+    ex = _req(ex, "ex", 3)
+    alpha = _req(alpha, "alpha", 3)
+    b_, m, n = ex.shape
+    c_ = alpha.shape[1]
+    if alpha.shape[0] != b_ or alpha.shape[2] != n:
+        raise RuntimeError("predict: alpha must be [B,C,N]")
+    sv = _req(sv.reshape(-1), "sv", 1)
+    mean = _req(mean.reshape(-1), "mean", 1)
+    mu = torch.empty((b_, c_, m), device=ex.device, dtype=torch.float32)
+    labels = torch.empty((b_, m), device=ex.device, dtype=torch.int32) if want_labels else None
+    lib = _lib.load()
+    _lib.check(lib.dkt_predict_f32(_p(ex), _p(alpha), _p(sv), _p(mean), _p(mu), _p(labels), b_, c_, m, n, _stream()),
+               "dkt_predict_f32")
+    return mu, labels
+
+
+def predict_var(ex: torch.Tensor, exx: torch.Tensor, chol: torch.Tensor, sv: torch.Tensor, noise: torch.Tensor):
+    ex = _req(ex, "ex", 3)
+    exx = _req(exx, "exx", 2)
+    chol = _req(chol, "chol", 4)
+    b_, m, n = ex.shape
+    c_ = chol.shape[1]
+    sv = _req(sv.reshape(-1), "sv", 1)
+    noise = _req(noise.reshape(-1), "noise", 1)
+    var = torch.empty((b_, c_, m), device=ex.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dkt_predict_var_f32(_p(ex), _p(exx), _p(chol), _p(sv), _p(noise), _p(var), b_, c_, m, n, _stream()),
+               "dkt_predict_var_f32")
+    return var
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd
+# ------------------------------------------------------------------------------------------------
+class _BaseMatrixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, lengthscale, kind):
+        e = gram(z, None, kind, lengthscale)
+        ctx.kind = kind
+        ctx.save_for_backward(z, e if kind == KERNEL_RBF else None, lengthscale)
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        z, e, lengthscale = ctx.saved_tensors
+        ge = ge.contiguous()
+        dl = None
+        if ctx.kind == KERNEL_RBF:
+            wp, dlb = rbf_bwd(ge, e, lengthscale)
+            dz = gram_bwd(wp, z)
+            if ctx.needs_input_grad[1]:
+                dl = dlb.sum().reshape(lengthscale.shape)
+        else:
+            dz = gram_bwd(ge, z)
+        return (dz if ctx.needs_input_grad[0] else None), dl, None
+
+
+def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable symmetric base kernel matrix E[B,N,N] of z[B,N,D]."""
+    kind = kind_id(kernel)
+    if kind == KERNEL_RBF and lengthscale is None:
+        raise RuntimeError("rbf needs a lengthscale tensor")
+    if lengthscale is None:
+        lengthscale = torch.zeros(1, device=z.device, dtype=torch.float32)
+    return _BaseMatrixFn.apply(z, lengthscale, kind)
+
+
+class _MllObjectiveFn(torch.autograd.Function):
+    """obj[b] = sum_c cls_weight[c] logp[b,c]; gradients were produced by the same kernel launch."""
+
+    @staticmethod
+    def forward(ctx, e, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+        out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
+        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        ctx.save_for_backward(out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
+        ctx.shapes = (sv.shape, mean.shape, noise.shape)
+        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"])
+        return obj, out["logp"], out["alpha"], out["info"], out["jitter"]
+
+    @staticmethod
+    def backward(ctx, gobj, *_unused):
+        w, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        gobj = gobj.contiguous()
+        ge = w * gobj.reshape(-1, 1, 1) if ctx.needs_input_grad[0] else None
+        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)          # [B,C]
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        return ge, None, gsv, gmean, gnoise, None, None, None
+
+
+def mll_objective(e, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):
+    """Returns (obj[B], logp[B,C], alpha[B,C,N], info[B,C], jitter[B,C])."""
+    return _MllObjectiveFn.apply(e, y, sv, mean, noise, cls_weight, jitter0, max_tries)
+
+
+class _EpisodeLossLinearFn(torch.autograd.Function):
+    """Fused training episode for the linear / cossim / bncossim kernel:
+       forward : E = Z Z^T (dkt_gram_f32) -> logp, W, hyper grads (dkt_mll_f32, one launch)
+       backward: dZ = g_b (W + W^T) Z (dkt_gram_bwd_f32, upstream grad folded in as ep_scale)."""
+
+    @staticmethod
+    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+        e = gram(z, None, KERNEL_LINEAR)
+        out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
+        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        ctx.save_for_backward(z, out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
+        ctx.shapes = (sv.shape, mean.shape, noise.shape)
+        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e)
+        return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e
+
+    @staticmethod
+    def backward(ctx, gobj, *_unused):
+        z, w, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        gobj = gobj.contiguous()
+        dz = gram_bwd(w, z, gobj) if ctx.needs_input_grad[0] else None
+        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        return dz, None, gsv, gmean, gnoise, None, None, None
+
+
+def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):
+    """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E)."""
+    return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries)

@@ -1,0 +1,139 @@
+/*
+ * dkt_abi.h -- C ABI of the MI355X-native DKT hot path (libdkt_hip.so, gfx950).
+ *
+ * The reference (BayesWatch/deep-kernel-transfer) is pure Python and has NO FFI of its own: the
+ * arithmetic below is what methods/DKT.py and methods/DKT_regression.py dispatch to GPyTorch /
+ * ATen (matmul, cholesky, cholesky_solve).  Each entry point cites the reference call site it
+ * replaces (file:line under /root/reference); INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - all matrices fp32, row-major, contiguous, batch-major [B,...], class-major [B,C,...];
+ *   - every pointer is a DEVICE pointer unless named *_host; the caller (PyTorch) owns every
+ *     buffer including workspace -- the library never allocates, frees or retains pointers;
+ *   - hyper-parameters are device pointers (they live in torch Parameters; no host sync);
+ *   - calls are asynchronous, ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream), re-entrant, no global state;
+ *   - return value: 0 = launched; <0 = argument error (DKT_ERR_*); failures of the numerical
+ *     kind (non-positive pivot after all jitter retries) are reported per matrix in `info`
+ *     on the device (LAPACK style: k+1 = index of the failing pivot), never as an exception.
+ */
+#ifndef DKT_ABI_H
+#define DKT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DKT_ABI_VERSION 1
+
+/* status codes */
+#define DKT_OK 0
+#define DKT_ERR_BAD_ARG (-1)
+#define DKT_ERR_TOO_LARGE (-2)
+#define DKT_ERR_WORKSPACE (-3)
+#define DKT_ERR_LAUNCH (-4)
+
+/* base-kernel kinds (configs.py:7 kernel_type; DKT.py:352-370) */
+#define DKT_KERNEL_LINEAR 0 /* linear / cossim / bncossim : E = A B^T                       */
+#define DKT_KERNEL_RBF 1    /* rbf : E = exp(-0.5 |a-b|^2 / l^2), centred norm expansion    */
+
+/* mll flags */
+#define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
+#define DKT_MLL_WANT_CHOL 2u /* also write the Cholesky factors L[B,C,N,N]                  */
+
+int dkt_abi_version(void);
+
+/* Device query used by the host side to fail loudly on a non-gfx950 box: returns the number of
+ * compute units of the current HIP device (>0) or <0 on error. */
+int dkt_device_cu_count(void);
+
+/*
+ * dkt_gram_f32 -- base kernel matrix of one or many episodes.
+ *   E[b] = k(A[b], Bm[b])  with A:[B,M,D], Bm:[B,N,D] -> E:[B,M,N].
+ *   Bm == NULL: symmetric Gram of A with itself (M == N, only lower tiles computed, mirrored).
+ *   kind = DKT_KERNEL_LINEAR | DKT_KERNEL_RBF; `lengthscale` (device, 1 float) used by RBF only.
+ * Replaces: ExactGPLayer.forward -> covar_module(x) (methods/DKT.py:375-378,
+ *   methods/DKT_regression.py:126-129), i.e. GPyTorch LinearKernel / RBFKernel evaluation,
+ *   evaluated once per episode instead of once per class model (DKT.py:148-149,161).
+ */
+int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, int M, int N, int D, int kind,
+                 const float* lengthscale, void* stream);
+
+/*
+ * dkt_mll_workspace_bytes -- bytes of scratch dkt_mll_f32 needs for (B,C,N) (0 when the
+ * factorisation is LDS/register resident).
+ */
+size_t dkt_mll_workspace_bytes(int B, int C, int N);
+
+/*
+ * dkt_mll_f32 -- exact-GP marginal log likelihood of C one-vs-rest models per episode that
+ * share the episode's base matrix E[b]:  K_c = sv[c] * E[b] + noise[c] * I.
+ *   jittered Cholesky (try 0, then total diagonal jitter jitter0 * 10^i, i < max_tries),
+ *   log-det, r = y_c - mean[c], alpha = K^-1 r,
+ *   logp[b,c] = -0.5 (r^T alpha + logdet K + N log 2 pi).
+ *   Y: [*,C,N] targets; episode b reads Y + b * y_bstride (y_bstride = 0: shared targets).
+ *   sv, mean, noise: [C] device (outputscale*variance, ConstantMean, likelihood noise).
+ * Outputs (device): logp[B,C], alpha[B,C,N], jitter_used[B,C], info[B,C] (0 = ok).
+ *   flags & DKT_MLL_WANT_CHOL : L[B,C,N,N] lower factors (upper part zero).
+ *   flags & DKT_MLL_WANT_GRAD : with M_c = 0.5 (alpha alpha^T - K_c^-1):
+ *        W[b]      = sum_c cls_weight[c] * sv[c] * M_c      (= d obj_b / d E[b], symmetric)
+ *        dsv[b,c]  = sum_ij M_c,ij E_ij   dmean[b,c] = sum_i alpha_i   dnoise[b,c] = tr M_c
+ *        (raw d logp[b,c] / d theta_c; the caller applies cls_weight / upstream grads)
+ *        cls_weight: [C] device or NULL (= 1).
+ * Replaces: `loss = -self.mll(output, self.model.train_targets)` and its autograd backward
+ *   (methods/DKT.py:161-163, 252-254; methods/DKT_regression.py:53-56): GPyTorch
+ *   GaussianLikelihood.marginal + MultivariateNormal.log_prob + psd_safe_cholesky +
+ *   cholesky_solve, and the mean cache of DefaultPredictionStrategy (DKT.py:177,187,265,330).
+ */
+int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv, const float* mean,
+                const float* noise, int B, int C, int N, float jitter0, int max_tries,
+                unsigned flags, const float* cls_weight, float* logp, float* alpha, float* L,
+                float* W, float* dsv, float* dmean, float* dnoise, float* jitter_used,
+                int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * dkt_gram_bwd_f32 -- backward of the linear Gram: dZ[b] = scale_b * (W[b] + W[b]^T) Z[b].
+ *   W:[B,N,N]  Z:[B,N,D]  dZ:[B,N,D];  ep_scale: [B] device per-episode factor (upstream
+ *   gradient of the episode objective) or NULL (= 1).
+ * Replaces: autograd through matmul(Z, Z^T) in loss.backward() (methods/DKT.py:163).
+ */
+int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
+                     const float* ep_scale, void* stream);
+
+/*
+ * dkt_rbf_bwd_f32 -- chain rule of the RBF base kernel.  With Ws = 0.5 (W + W^T) and
+ *   A = -(Ws o E) / l^2 :  Wp[b] = diag(A 1) - A  (so that dZ = 2 Wp Z = dkt_gram_bwd_f32(Wp, Z)),
+ *   dlengthscale[b] = sum_ij Ws_ij E_ij d2_ij / l^3,  d2_ij = -2 l^2 ln E_ij.
+ * Replaces: autograd through RBFKernel.forward in loss.backward() (methods/DKT_regression.py:56).
+ */
+int dkt_rbf_bwd_f32(const float* W, const float* E, const float* lengthscale, float* Wp,
+                    float* dlengthscale, int B, int N, void* stream);
+
+/*
+ * dkt_predict_f32 -- posterior mean of the C models at M test points and the arg-max label.
+ *   Ex:[B,M,N] base cross kernel k(x*, X_cond); alpha:[B,C,N]; sv, mean:[C] device.
+ *   mu[b,c,q] = mean[c] + sv[c] * sum_n Ex[b,q,n] alpha[b,c,n];   labels[b,q] = argmax_c mu
+ *   (first maximum wins, as np.argmax over sigmoid(mu) does -- sigmoid is monotone).
+ *   labels may be NULL.
+ * Replaces: `self.likelihood(*self.model(*z_query_list))` + sigmoid + vstack + argmax
+ *   (methods/DKT.py:176-181, 186-191, 264-270, 329-334; DKT_regression.py:92).
+ */
+int dkt_predict_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
+                    float* mu, int32_t* labels, int B, int C, int M, int N, void* stream);
+
+/*
+ * dkt_predict_var_f32 -- diagonal of the predictive covariance (what confidence_region() reads,
+ *   methods/DKT_regression.py:92-93):  var[b,c,q] = sv_c exx[b,q] - sv_c^2 |L_c^-1 Ex[b,q,:]|^2 + noise_c.
+ *   L:[B,C,N,N] from dkt_mll_f32(DKT_MLL_WANT_CHOL); exx:[B,M] = k(x*,x*) diagonal of the base kernel.
+ */
+int dkt_predict_var_f32(const float* Ex, const float* exx, const float* L, const float* sv,
+                        const float* noise, float* var, int B, int C, int M, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DKT_ABI_H */

@@ -1,0 +1,108 @@
+"""Generates tests/golden/*.npz -- small seeded input/expected-output vectors for the DKT hot path.
+
+PARITY UNPINNED: the reference's own implementation of this path cannot run here (GPyTorch is not
+installed / installable), so the expected values come from the float64 oracle
+(oracle/dkt_oracle.py), cross-checked at generation time against scikit-learn's
+GaussianProcessRegressor and scipy.stats.multivariate_normal.  Re-run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import dkt_oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# (name, n_way, n_support, n_query, D, kernel, correlated)
+TRAIN_CASES = [
+    ("cfg1_omniglot_5w5s_conv4s", 5, 5, 16, 64, "bncossim", 0),
+    ("cfg2_cub_5w5s_conv4", 5, 5, 16, 1600, "bncossim", 0),
+    ("cfg2_cub_5w5s_conv4_corr", 5, 5, 16, 1600, "bncossim", 5),
+    ("cfg3_mini_5w1s_resnet10", 5, 1, 16, 512, "bncossim", 0),
+    ("cfg4_mini_20w5s_resnet18", 20, 5, 16, 512, "bncossim", 0),
+    ("small_3w2s_rbf", 3, 2, 3, 20, "rbf", 0),
+]
+TEST_CASES = [
+    ("test_5w5s_d64", 5, 5, 15, 64),
+    ("test_5w1s_d512", 5, 1, 15, 512),
+    ("test_20w5s_d512", 20, 5, 15, 512),
+]
+
+
+def sklearn_logp(e_kernel, z, y, sv, noise, ls=None):
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import ConstantKernel as C, DotProduct, WhiteKernel, RBF
+    base = DotProduct(sigma_0=0.0, sigma_0_bounds="fixed") if e_kernel == "linear" else RBF(length_scale=ls)
+    k = C(sv, "fixed") * base + WhiteKernel(noise, "fixed")
+    gp = GaussianProcessRegressor(kernel=k, alpha=0.0, optimizer=None).fit(z, y)
+    return gp.log_marginal_likelihood_value_, gp
+
+
+def main():
+    for name, c, s, q, d, kernel, corr in TRAIN_CASES:
+        n = c * (s + q)
+        seed = abs(hash(name)) % 1000 + 11
+        seed = sum(ord(ch) for ch in name)           # stable across processes
+        z = O.synthetic_features(1, n, d, seed, corr)[0]
+        if kernel == "rbf":
+            z = z * 3.0 + 0.5
+        hyp = O.perturbed_hypers(c, seed + 1)
+        if kernel == "rbf":
+            hyp.lengthscale = 1.3
+        out = O.train_episode(z, c, hyp, kernel)
+        # cross-check class 0 against sklearn + scipy
+        from scipy.stats import multivariate_normal
+        kmat = hyp.outputscale[0] * out["e"] + hyp.noise[0] * np.eye(n)
+        ref_scipy = multivariate_normal.logpdf(out["y"][0], mean=np.full(n, hyp.mean[0]), cov=kmat)
+        ref_sk, _ = sklearn_logp("linear" if kernel != "rbf" else "rbf", z, out["y"][0] - hyp.mean[0],
+                                 hyp.outputscale[0], hyp.noise[0], hyp.lengthscale)
+        assert abs(ref_scipy - out["logp"][0]) < 1e-8 * abs(ref_scipy), (name, ref_scipy, out["logp"][0])
+        assert abs(ref_sk - out["logp"][0]) < 1e-8 * abs(ref_sk), (name, ref_sk, out["logp"][0])
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            seed=seed, n_way=c, n_support=s, n_query=q, d=d, kernel=kernel, correlated=corr,
+            z_scale=(3.0 if kernel == "rbf" else 1.0), z_shift=(0.5 if kernel == "rbf" else 0.0),
+            z=(z.astype(np.float64) if z.size <= 12000 else np.zeros(0)),   # big inputs are regenerated from the seed
+            z_checksum=float(z.sum()), z_row0=z[0, :8].copy(),
+            outputscale=hyp.outputscale, mean=hyp.mean, noise=hyp.noise, lengthscale=hyp.lengthscale,
+            loss=out["loss"], logp=out["logp"], logp0_sklearn=ref_sk, logp0_scipy=ref_scipy,
+            alpha=out["alpha"], chol_diag=np.stack([np.diag(l) for l in out["chol"]]),
+            dsv=out["dsv"], dmean=out["dmean"], dnoise=out["dnoise"],
+            dz_checksum=float(np.abs(out["dz"]).sum()), dz_rows=out["dz"][:3].copy(), dz_fro=float(np.linalg.norm(out["dz"])),
+            dlengthscale=out.get("dlengthscale", 0.0), w_e_fro=float(np.linalg.norm(out["w_e"])),
+        )
+        print("wrote", name, "loss", out["loss"])
+    for name, c, s, q, d in TEST_CASES:
+        seed = sum(ord(ch) for ch in name)
+        zall = O.synthetic_features(1, c * (s + q), d, seed, c)[0].reshape(c, s + q, d)
+        zs = zall[:, :s].reshape(c * s, d)
+        zq = zall[:, s:].reshape(c * q, d)
+        hyp = O.perturbed_hypers(c, seed + 1)
+        out = O.eval_episode(zs, zq, c, hyp)
+        _, gp = sklearn_logp("linear", zs, O.one_vs_rest_targets(c, s)[0] - hyp.mean[0], hyp.outputscale[0], hyp.noise[0])
+        mu0 = gp.predict(zq) + hyp.mean[0]
+        assert np.abs(mu0 - out["mu"][0]).max() < 1e-8
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), seed=seed, n_way=c, n_support=s, n_query=q, d=d,
+            z_checksum=float(zall.sum()), outputscale=hyp.outputscale, mean=hyp.mean, noise=hyp.noise,
+            mu=out["mu"], labels=out["labels"], correct=out["correct"], count=out["count"], alpha=out["alpha"], logp=out["logp"],
+        )
+        print("wrote", name, "acc", out["correct"] / out["count"])
+    # degenerate: duplicated rows (rank deficient, relies on noise) and near-singular needing jitter
+    rng = np.random.default_rng(5)
+    z = O.l2_normalize(rng.standard_normal((12, 16)))
+    z[6:] = z[:6]                                   # exact duplicates
+    e = O.gram_linear(z)
+    y = O.one_vs_rest_targets(2, 6)
+    res = O.mll_terms(e, y, np.array([0.7, 1.1]), np.array([0.05, -0.02]), np.array([0.1, 0.1]))
+    tiny = O.mll_terms(e, y, np.array([1.0, 1.0]), np.zeros(2), np.zeros(2), jitter0=1e-6)   # singular -> jitter
+    np.savez_compressed(os.path.join(OUT, "degenerate.npz"), z=z, logp_dup=res.logp, alpha_dup=res.alpha,
+                        jitter_dup=res.jitter, logp_sing=tiny.logp, jitter_sing=tiny.jitter)
+    print("wrote degenerate; jitter used for the singular case:", tiny.jitter)
+
+
+if __name__ == "__main__":
+    main()

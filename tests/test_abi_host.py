@@ -1,0 +1,114 @@
+"""CPU-side checks: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/dkt_abi.h declares; host logic (constraints, targets, module surface); and the product path
+fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dkt_amd
+from oracle import dkt_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_header_symbols(lib):
+    header = open(os.path.join(ROOT, "include", "dkt_abi.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(dkt_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(lib, name), "libdkt_hip.so lacks %s" % name
+        assert name in dkt_amd._lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert sorted(dkt_amd._lib.SIGNATURES) == declared
+    assert lib.dkt_abi_version() == 1
+    # pure host queries (no GPU needed)
+    assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # LDS resident
+    assert lib.dkt_mll_workspace_bytes(2, 20, 420) == 2 * 421 * 421 * 4  # global workspace
+    assert lib.dkt_mll_workspace_bytes(0, 5, 105) == 0
+
+
+def test_argument_errors_do_not_launch(lib):
+    # NULL pointers / bad sizes are rejected on the host before any launch
+    assert lib.dkt_gram_f32(None, None, None, 1, 4, 4, 4, 0, None, None) == -1
+    assert lib.dkt_gram_bwd_f32(None, None, None, 1, 4, 4, None, None) == -1
+    assert lib.dkt_predict_f32(None, None, None, None, None, None, 1, 1, 1, 1, None) == -1
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        dkt_amd.ops.gram(torch.zeros(1, 4, 8))
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        dkt_amd.ops.episode_loss_linear(torch.zeros(1, 4, 8), torch.zeros(2, 4), torch.ones(2), torch.zeros(2),
+                                        torch.ones(2), torch.ones(2))
+    # the product package never imports the oracle
+    import sys
+    for name, mod in list(sys.modules.items()):
+        if name.startswith("dkt_amd"):
+            src = getattr(mod, "__file__", None)
+            if src and src.endswith(".py"):
+                assert "oracle" not in open(src).read().replace("the oracle", ""), name
+
+
+def test_hyper_parameter_constraints_match_oracle():
+    h = dkt_amd.gp.ExactGPHypers(5, "bncossim", fixed_noise=0.1)
+    assert torch.allclose(h.outputscale, torch.full((5,), float(np.log(2.0))), atol=1e-7)
+    assert torch.allclose(h.noise, torch.full((5,), 0.1), atol=1e-7)
+    assert torch.allclose(h.variance, torch.ones(1), atol=1e-6)
+    assert not h.raw_noise.requires_grad and not h.raw_variance.requires_grad
+    assert [n for n, p in h.named_parameters() if p.requires_grad] == ["mean_constant", "raw_outputscale"]
+    r = dkt_amd.gp.ExactGPHypers(1, "rbf", fixed_noise=None)
+    assert abs(r.noise.item() - (np.log(2.0) + 1e-4)) < 1e-6      # GaussianLikelihood default
+    assert abs(r.lengthscale.item() - np.log(2.0)) < 1e-6
+    assert r.raw_noise.requires_grad and r.raw_lengthscale.requires_grad
+    with torch.no_grad():
+        h.raw_outputscale.copy_(torch.tensor([-1.0, 0.0, 0.5, 2.0, 40.0]))
+    np.testing.assert_allclose(h.outputscale.detach().numpy(), O.softplus([-1.0, 0.0, 0.5, 2.0, 40.0]), rtol=1e-6)
+    with pytest.raises(ValueError):
+        dkt_amd.gp.ExactGPHypers(5, "nope")
+    # model views expose the attribute paths the reference's logging reads (DKT.py:148-154)
+    mv = h.models[2]
+    assert mv.covar_module.base_kernel.lengthscale is None
+    assert abs(mv.likelihood.noise.item() - 0.1) < 1e-6
+
+
+def test_dkt_surface_and_state_dict_names():
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5)
+    for name in ("train_loop", "test_loop", "correct", "get_logits", "set_forward", "set_forward_loss",
+                 "init_summary", "get_model_likelihood_mll", "parse_feature"):
+        assert callable(getattr(m, name))
+    assert m.feature is m.feature_extractor and m.normalize and m.feat_dim == 64
+    assert isinstance(m.feature_extractor.trunk.bn_out, torch.nn.BatchNorm1d)
+    keys = set(m.state_dict().keys())
+    assert "feature.trunk.0.C.weight" in keys and "feature_extractor.trunk.0.trunk.0.weight" in keys
+    assert "feature.trunk.bn_out.running_mean" in keys and "model.raw_outputscale" in keys
+    assert m.set_forward(None) is None and m.set_forward_loss(None) is None
+    y = m._targets(3, 2, torch.device("cpu"))
+    np.testing.assert_array_equal(y.numpy(), O.one_vs_rest_targets(3, 2))
+    # optimizer groups exactly as DKT.py:114-115
+    n_gp = sum(p.numel() for p in m.model.parameters() if p.requires_grad)
+    assert n_gp == 10
+    reg = dkt_amd.DKTRegression(dkt_amd.backbone.Conv3(), "rbf")
+    assert sum(p.numel() for p in reg.model.parameters() if p.requires_grad) == 4   # mean, outputscale, lengthscale, noise
+    with pytest.raises(ValueError):
+        dkt_amd.DKTRegression(dkt_amd.backbone.Conv3(), "bncossim")
+
+
+def test_reference_checkpoint_key_loader():
+    h = dkt_amd.gp.ExactGPHypers(2, "bncossim")
+    state = {"model.models.0.mean_module.constant": torch.tensor([0.3]),
+             "model.models.1.covar_module.raw_outputscale": torch.tensor(-0.7),
+             "model.models.1.likelihood.noise_covar.raw_noise": torch.tensor([0.2])}
+    assert h.load_reference_state_dict(state) == 3
+    assert abs(h.mean_constant[0].item() - 0.3) < 1e-7 and abs(h.raw_outputscale[1].item() + 0.7) < 1e-7
+
+
+def test_backbone_shapes():
+    bb = dkt_amd.backbone
+    x = torch.randn(2, 3, 28, 28)
+    assert bb.Conv4S()(x).shape == (2, 64)
+    assert bb.Conv4()(torch.randn(2, 3, 84, 84)).shape == (2, 1600)
+    assert bb.Conv3()(torch.randn(2, 3, 100, 100)).shape == (2, 2916)
+    assert sum(p.numel() for p in bb.ResNet10().parameters()) == 4905792

@@ -1,0 +1,92 @@
+"""world_size-2 `gloo` tests of the episode-parallel path (CPU): the flat gradient bucket averages
+over ranks with one collective, the averaged gradient equals the mean of the single-episode oracle
+gradients (SURVEY.md 8e semantics caveat), episode sharding and accuracy gathering."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import dkt_amd
+    from oracle import dkt_oracle as O
+    from oracle import dkt_oracle_torch as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dkt_amd.distributed.init_from_env("gloo")
+    try:
+        torch.manual_seed(0)                                  # same init on every rank
+        lin = torch.nn.Linear(12, 8).double()
+        raw_s = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))
+        mean = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))
+        frozen = torch.nn.Parameter(torch.ones(2, dtype=torch.float64), requires_grad=False)
+        params = list(lin.parameters()) + [raw_s, mean, frozen, raw_s]   # alias + frozen must be handled
+        bucket = dkt_amd.distributed.GradBucket(params)
+        assert bucket.numel == 12 * 8 + 8 + 3 + 3
+
+        def episode_grads(seed):
+            for p in params:
+                p.grad = None
+            x = torch.tensor(np.random.default_rng(seed).standard_normal((12, 12)))
+            z = torch.nn.functional.normalize(lin(x), dim=1)
+            loss, _, _ = T.classification_loss(z, 3, torch.nn.functional.softplus(raw_s), mean,
+                                               torch.full((3,), 0.1, dtype=torch.float64))
+            loss.backward()
+            return [p.grad.clone() for p in bucket.params]
+
+        mine = episode_grads(100 + rank)                      # rank r draws its own episode
+        bucket.allreduce_mean()
+        got = [p.grad.clone() for p in bucket.params]
+        both = [episode_grads(100 + r) for r in range(world)]
+        for i, g in enumerate(got):
+            ref = sum(b[i] for b in both) / world
+            assert torch.allclose(g, ref, atol=1e-12), (rank, i)
+        # sharding + gather
+        sh = dkt_amd.distributed.shard_episodes(601)
+        accs = [float(e) for e in sh]
+        allacc = dkt_amd.distributed.gather_accuracies(accs, device=torch.device("cpu"))
+        assert allacc == [float(e) for e in range(601)]
+        t = dkt_amd.distributed.allreduce_sum_(torch.tensor([1.0 + rank]))
+        assert t.item() == sum(1.0 + r for r in range(world))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2_gradient_bucket_and_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_shard_episodes_partitions():
+    import dkt_amd
+    for n, w in [(600, 8), (601, 8), (5, 8), (0, 2)]:
+        parts = [list(dkt_amd.distributed.shard_episodes(n, r, w)) for r in range(w)]
+        assert sum(parts, []) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

@@ -1,0 +1,446 @@
+"""-m gpu: the HIP hot path (through the C ABI) against the float64 oracle on identical seeded
+inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Tolerances (north_star): marginal log likelihood 1e-4 relative,
+identical predicted labels; gradients rel-L2 1e-3."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dkt_amd
+from dkt_amd import ops
+from oracle import dkt_oracle as O
+from oracle import dkt_oracle_torch as T
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MLL_RTOL = 1e-4
+GRAD_RTOL = 1e-3
+
+
+def dev_t(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_loaded_native_library(cuda, lib):
+    assert lib.dkt_abi_version() == 1
+    assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ----------------------------------------------------------------------------------------------
+# Gram build
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,n,d", [(1, 1, 4), (2, 5, 7), (3, 19, 2916), (2, 25, 64), (2, 64, 32), (2, 65, 36),
+                                   (2, 85, 512), (3, 105, 64), (2, 105, 1600), (1, 130, 50), (1, 420, 512)])
+def test_gram_linear_symmetric(cuda, b, n, d):
+    rng = np.random.default_rng(n * 1000 + d)
+    z = rng.standard_normal((b, n, d)).astype(np.float32)
+    e = ops.gram(dev_t(z, cuda)).cpu().numpy()
+    ref = np.einsum("bnd,bmd->bnm", z.astype(np.float64), z.astype(np.float64))
+    assert np.abs(e - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-6
+    assert (e == e.transpose(0, 2, 1)).all(), "Gram must be exactly symmetric"
+
+
+@pytest.mark.parametrize("b,m,n,d", [(2, 75, 25, 64), (1, 75, 5, 512), (2, 300, 100, 512), (1, 19, 5, 2916), (1, 7, 3, 5)])
+def test_gram_linear_cross(cuda, b, m, n, d):
+    rng = np.random.default_rng(m * 100 + n)
+    a = rng.standard_normal((b, m, d)).astype(np.float32)
+    bm = rng.standard_normal((b, n, d)).astype(np.float32)
+    bm[0, 0, :] = np.arange(d)          # asymmetric content: a transposed write would be caught
+    e = ops.gram(dev_t(a, cuda), dev_t(bm, cuda)).cpu().numpy()
+    ref = np.einsum("bmd,bnd->bmn", a.astype(np.float64), bm.astype(np.float64))
+    assert np.abs(e - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-6
+
+
+@pytest.mark.parametrize("n,d,ls,shift", [(19, 2916, 30.0, 0.4), (5, 2916, 20.0, 0.4), (105, 64, 1.3, 0.0), (70, 33, 0.9, 5.0)])
+def test_gram_rbf(cuda, n, d, ls, shift):
+    rng = np.random.default_rng(n + d)
+    z = (np.abs(rng.standard_normal((2, n, d))) * 0.5 + shift).astype(np.float32)   # ReLU-like, common offset
+    lst = dev_t([ls], cuda)
+    e = ops.gram(dev_t(z, cuda), None, ops.KERNEL_RBF, lst).cpu().numpy()
+    for i in range(2):
+        ref = O.gram_rbf(z[i].astype(np.float64), None, ls)
+        assert np.abs(e[i] - ref).max() < 2e-5, np.abs(e[i] - ref).max()
+    assert (np.diagonal(e, axis1=1, axis2=2) == 1.0).all()
+    # cross
+    q = (np.abs(rng.standard_normal((2, 11, d))) * 0.5 + shift).astype(np.float32)
+    ex = ops.gram(dev_t(q, cuda), dev_t(z, cuda), ops.KERNEL_RBF, lst).cpu().numpy()
+    for i in range(2):
+        assert np.abs(ex[i] - O.gram_rbf(q[i].astype(np.float64), z[i].astype(np.float64), ls)).max() < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# marginal log likelihood: Cholesky, log-det, mean cache, gradients
+# ----------------------------------------------------------------------------------------------
+def _episode_case(c, per, d, seed, corr=0, b=2):
+    n = c * per
+    z = O.synthetic_features(b, n, d, seed, corr)
+    hyp = O.perturbed_hypers(c, seed + 1)
+    return z, hyp, n
+
+
+@pytest.mark.parametrize("c,per,d,corr", [(1, 1, 8, 0), (2, 1, 8, 0), (5, 1, 64, 0), (5, 5, 64, 0), (5, 17, 512, 0),
+                                          (5, 21, 64, 0), (5, 21, 1600, 5), (5, 26, 40, 0), (5, 38, 32, 0),
+                                          (4, 50, 64, 0), (20, 16, 512, 0), (20, 21, 512, 20)])
+def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr):
+    z, hyp, n = _episode_case(c, per, d, 17 + n_hash(c, per, d), corr)
+    y = O.one_vs_rest_targets(c, per)
+    sv = hyp.outputscale
+    cw = np.full(c, -1.0 / (c * n))
+    e_dev = ops.gram(dev_t(z, cuda))
+    out = ops.mll(e_dev, dev_t(y, cuda), dev_t(sv, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda),
+                  want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda))
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().max().item()) == 0
+    assert float(out["jitter"].abs().max().item()) == 0.0
+    for i in range(z.shape[0]):
+        e = O.gram_linear(z[i])
+        res = O.mll_terms(e, y, sv, hyp.mean, hyp.noise)
+        logp = out["logp"][i].cpu().numpy()
+        assert np.abs(logp - res.logp).max() / np.abs(res.logp).max() < MLL_RTOL
+        assert np.abs((logp - res.logp) / res.logp).max() < MLL_RTOL
+        assert rel_l2(out["alpha"][i].cpu().numpy(), res.alpha) < 5e-4
+        assert rel_l2(out["chol"][i].cpu().numpy(), res.chol) < 5e-5
+        w_e, dsv, dmean, dnoise = O.mll_grads(e, res, sv, hyp.noise, np.ones(c))
+        w_ref, _, _, _ = O.mll_grads(e, res, sv, hyp.noise, cw)
+        wk = out["w"][i].cpu().numpy()
+        assert rel_l2(wk, w_ref) < GRAD_RTOL
+        assert (wk == wk.T).all()
+        assert rel_l2(out["dsv"][i].cpu().numpy(), dsv) < GRAD_RTOL
+        assert rel_l2(out["dmean"][i].cpu().numpy(), dmean) < GRAD_RTOL
+        assert rel_l2(out["dnoise"][i].cpu().numpy(), dnoise) < GRAD_RTOL
+
+
+def n_hash(*a):
+    return int(sum((i + 1) * v for i, v in enumerate(a)))
+
+
+def test_mll_per_episode_targets_and_residual_property(cuda):
+    """Regression-style: y differs per episode ([B,C,N]); property check K alpha = r at full size."""
+    rng = np.random.default_rng(3)
+    b, n, d = 4, 19, 128
+    z = np.abs(rng.standard_normal((b, n, d))).astype(np.float32)
+    y = rng.standard_normal((b, 1, n)).astype(np.float32)
+    ls, sv, mean, noise = 9.0, 0.8, 0.1, 0.3
+    e = ops.gram(dev_t(z, cuda), None, ops.KERNEL_RBF, dev_t([ls], cuda))
+    out = ops.mll(e, dev_t(y, cuda), dev_t([sv], cuda), dev_t([mean], cuda), dev_t([noise], cuda), want_chol=True)
+    en = e.cpu().numpy().astype(np.float64)
+    for i in range(b):
+        res = O.mll_terms(O.gram_rbf(z[i].astype(np.float64), None, ls), y[i], sv, mean, noise)
+        assert abs(out["logp"][i, 0].item() - res.logp[0]) < MLL_RTOL * abs(res.logp[0])
+        k = sv * en[i] + noise * np.eye(n)
+        r = y[i, 0] - mean
+        assert np.abs(k @ out["alpha"][i, 0].cpu().numpy().astype(np.float64) - r).max() < 1e-4
+        l = out["chol"][i, 0].cpu().numpy().astype(np.float64)
+        assert np.abs(l @ l.T - k).max() < 1e-5 and np.abs(np.triu(l, 1)).max() == 0.0
+
+
+def test_jitter_retry_and_failure_info(cuda):
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.standard_normal((8, 8)))
+    y = np.ones((1, 8))
+
+    def run(min_eig):
+        e = q @ np.diag([min_eig, 0.3, 0.5, 0.7, 1.0, 1.2, 1.5, 2.0]) @ q.T
+        e = 0.5 * (e + e.T)
+        o = ops.mll(dev_t(e[None], cuda), dev_t(y, cuda), dev_t([1.0], cuda), dev_t([0.0], cuda), dev_t([0.1], cuda))
+        return e, o
+
+    # K = E + 0.1 I has smallest eigenvalue -5e-5: plain, 1e-6, 1e-5 fail; total jitter 1e-4 succeeds
+    e, o = run(-0.1 - 5e-5)
+    assert int(o["info"].item()) == 0 and o["jitter"].item() == pytest.approx(1e-4, rel=1e-5)
+    l, jit = O.psd_safe_cholesky(e + 0.1 * np.eye(8), 1e-6, 3)
+    assert jit == pytest.approx(1e-4)
+    # -5e-6: succeeds at 1e-5
+    _, o = run(-0.1 - 5e-6)
+    assert int(o["info"].item()) == 0 and o["jitter"].item() == pytest.approx(1e-5, rel=1e-5)
+    # hopeless: every retry fails -> info > 0 (LAPACK-style pivot index), outputs poisoned with NaN
+    _, o = run(-0.5)
+    assert int(o["info"].item()) > 0 and torch.isnan(o["logp"]).all() and torch.isnan(o["alpha"]).all()
+    # healthy matrix: no jitter
+    _, o = run(0.2)
+    assert int(o["info"].item()) == 0 and o["jitter"].item() == 0.0
+
+
+def test_duplicate_rows_rank_deficient_gram(cuda):
+    g = np.load(os.path.join(GOLD, "degenerate.npz"))
+    z = g["z"]
+    y = O.one_vs_rest_targets(2, 6)
+    o = ops.mll(ops.gram(dev_t(z[None], cuda)), dev_t(y, cuda), dev_t([0.7, 1.1], cuda), dev_t([0.05, -0.02], cuda),
+                dev_t([0.1, 0.1], cuda))
+    assert int(o["info"].abs().max().item()) == 0
+    np.testing.assert_allclose(o["logp"][0].cpu().numpy(), g["logp_dup"], rtol=MLL_RTOL)
+    assert rel_l2(o["alpha"][0].cpu().numpy(), g["alpha_dup"]) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------
+# golden vectors through the fused autograd entry point
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "cfg*.npz"))))
+def test_golden_training_episode_fused(cuda, path):
+    g = np.load(path)
+    c, s, q, d = int(g["n_way"]), int(g["n_support"]), int(g["n_query"]), int(g["d"])
+    n = c * (s + q)
+    z = O.synthetic_features(1, n, d, int(g["seed"]), int(g["correlated"]))[0]
+    assert abs(z.sum() - float(g["z_checksum"])) < 1e-9
+    zt = dev_t(z[None], cuda).requires_grad_(True)
+    raw_s = dev_t(O.inv_softplus(g["outputscale"]), cuda).requires_grad_(True)
+    mean = dev_t(g["mean"], cuda).requires_grad_(True)
+    noise = dev_t(g["noise"], cuda)
+    y = dev_t(O.one_vs_rest_targets(c, s + q), cuda)
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    sv = torch.nn.functional.softplus(raw_s)
+    obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zt, y, sv, mean, noise, cw)
+    loss = obj.mean()
+    loss.backward()
+    assert int(info.abs().max().item()) == 0
+    assert abs(loss.item() - float(g["loss"])) < MLL_RTOL * abs(float(g["loss"]))
+    assert np.abs((logp[0].cpu().numpy() - g["logp"]) / g["logp"]).max() < MLL_RTOL
+    assert rel_l2(alpha[0].cpu().numpy(), g["alpha"]) < 1e-4
+    dz = zt.grad[0].cpu().numpy().astype(np.float64)
+    assert abs(np.linalg.norm(dz) - float(g["dz_fro"])) < GRAD_RTOL * float(g["dz_fro"])
+    assert rel_l2(dz[:3], g["dz_rows"]) < GRAD_RTOL
+    # chain rule through softplus: d loss / d raw_s = dsv * sigmoid(raw)
+    ref_raw = g["dsv"] * O.sigmoid(O.inv_softplus(g["outputscale"]))
+    assert rel_l2(raw_s.grad.cpu().numpy(), ref_raw) < GRAD_RTOL
+    assert rel_l2(mean.grad.cpu().numpy(), g["dmean"]) < GRAD_RTOL
+
+
+def test_golden_rbf_episode_autograd(cuda):
+    g = np.load(os.path.join(GOLD, "small_3w2s_rbf.npz"))
+    c, per = int(g["n_way"]), int(g["n_support"]) + int(g["n_query"])
+    z = g["z"]
+    zt = dev_t(z[None], cuda).requires_grad_(True)
+    ls = dev_t([float(g["lengthscale"])], cuda).requires_grad_(True)
+    sv = dev_t(g["outputscale"], cuda).requires_grad_(True)
+    mean = dev_t(g["mean"], cuda).requires_grad_(True)
+    noise = dev_t(g["noise"], cuda).requires_grad_(True)
+    n = c * per
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    e = ops.base_matrix(zt, "rbf", ls)
+    obj, logp, alpha, info, jit = ops.mll_objective(e, dev_t(O.one_vs_rest_targets(c, per), cuda), sv, mean, noise, cw)
+    obj.mean().backward()
+    assert abs(obj.item() - float(g["loss"])) < MLL_RTOL * abs(float(g["loss"]))
+    hyp = O.GPHypers(g["outputscale"], g["mean"], g["noise"], float(g["lengthscale"]))
+    ref = O.train_episode(z, c, hyp, "rbf")
+    assert rel_l2(zt.grad[0].cpu().numpy(), ref["dz"]) < GRAD_RTOL
+    assert abs(ls.grad.item() - ref["dlengthscale"]) < GRAD_RTOL * abs(ref["dlengthscale"])
+    assert rel_l2(sv.grad.cpu().numpy(), ref["dsv"]) < GRAD_RTOL
+    assert rel_l2(noise.grad.cpu().numpy(), ref["dnoise"]) < GRAD_RTOL
+    assert rel_l2(mean.grad.cpu().numpy(), ref["dmean"]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("b,n,d", [(2, 5, 12), (2, 85, 512), (3, 105, 64), (2, 105, 1600), (1, 130, 36), (1, 420, 512)])
+def test_gram_bwd_vs_oracle(cuda, b, n, d):
+    rng = np.random.default_rng(n + d)
+    w = rng.standard_normal((b, n, n)).astype(np.float32)       # deliberately NOT symmetric
+    z = rng.standard_normal((b, n, d)).astype(np.float32)
+    sc = rng.standard_normal(b).astype(np.float32)
+    dz = ops.gram_bwd(dev_t(w, cuda), dev_t(z, cuda), dev_t(sc, cuda)).cpu().numpy()
+    for i in range(b):
+        ref = sc[i] * O.gram_linear_bwd(w[i].astype(np.float64), z[i].astype(np.float64))
+        assert rel_l2(dz[i], ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# prediction
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "test_*.npz"))))
+def test_golden_test_episode_prediction(cuda, path):
+    g = np.load(path)
+    c, s, q, d = int(g["n_way"]), int(g["n_support"]), int(g["n_query"]), int(g["d"])
+    zall = O.synthetic_features(1, c * (s + q), d, int(g["seed"]), c)[0].reshape(c, s + q, d)
+    zs, zq = zall[:, :s].reshape(1, c * s, d), zall[:, s:].reshape(1, c * q, d)
+    sv, mean, noise = dev_t(g["outputscale"], cuda), dev_t(g["mean"], cuda), dev_t(g["noise"], cuda)
+    zs_t, zq_t = dev_t(zs, cuda), dev_t(zq, cuda)
+    out = ops.mll(ops.gram(zs_t), dev_t(O.one_vs_rest_targets(c, s), cuda), sv, mean, noise)
+    mu, labels = ops.predict(ops.gram(zq_t, zs_t), out["alpha"], sv, mean)
+    assert np.abs(mu[0].cpu().numpy() - g["mu"]).max() < 1e-4
+    assert (labels[0].cpu().numpy() == g["labels"]).all(), "predicted labels must be identical"
+    assert float((labels[0].cpu().numpy() == np.repeat(np.arange(c), q)).sum()) == float(g["correct"])
+
+
+def test_predict_first_max_wins_on_ties(cuda):
+    ex = torch.ones(1, 3, 2, device=cuda)
+    alpha = torch.zeros(1, 4, 2, device=cuda)
+    mean = dev_t([0.5, 0.7, 0.7, 0.1], cuda)
+    mu, labels = ops.predict(ex, alpha, torch.ones(4, device=cuda), mean)
+    assert labels.cpu().tolist() == [[1, 1, 1]]
+
+
+def test_predict_variance_vs_oracle(cuda):
+    rng = np.random.default_rng(4)
+    z = np.abs(rng.standard_normal((19, 60)))
+    y = rng.standard_normal(19)
+    sup = [1, 3, 8, 12, 17]
+    hyp = O.GPHypers(np.array([0.8]), np.array([0.1]), np.array([0.3]), lengthscale=4.0)
+    ref = O.regression_predict(z[sup], y[sup], z, hyp)
+    ls = dev_t([4.0], cuda)
+    zs, za = dev_t(z[sup][None], cuda), dev_t(z[None], cuda)
+    sv, mean, noise = dev_t([0.8], cuda), dev_t([0.1], cuda), dev_t([0.3], cuda)
+    out = ops.mll(ops.gram(zs, None, ops.KERNEL_RBF, ls), dev_t(y[sup][None, None], cuda), sv, mean, noise, want_chol=True)
+    ex = ops.gram(za, zs, ops.KERNEL_RBF, ls)
+    mu, _ = ops.predict(ex, out["alpha"], sv, mean, want_labels=False)
+    var = ops.predict_var(ex, torch.ones(1, 19, device=cuda), out["chol"], sv, noise)
+    assert np.abs(mu[0, 0].cpu().numpy() - ref["mean"]).max() < 1e-4
+    assert np.abs(var[0, 0].cpu().numpy() - ref["var"]).max() < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json cfg2 at bench batch): no oracle pass over 1024 episodes needed
+# ----------------------------------------------------------------------------------------------
+def test_full_size_properties_cfg2(cuda):
+    b, n, d, c = 256, 105, 1600, 5
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    zr = torch.randn(b, n, d, generator=gen)
+    zr = (zr - zr.mean(1, keepdim=True)) / torch.sqrt(zr.var(1, unbiased=False, keepdim=True) + 1e-5)
+    z = torch.nn.functional.normalize(zr, dim=2).to(cuda).requires_grad_(True)
+    y = dev_t(O.one_vs_rest_targets(c, n // c), cuda)
+    hyp = O.perturbed_hypers(c, 7)
+    sv, mean, noise = dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda)
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw)
+    obj.sum().backward()
+    assert int(info.abs().max().item()) == 0 and torch.isfinite(logp).all()
+    assert torch.allclose(torch.diagonal(e, dim1=1, dim2=2), torch.ones(b, n, device=cuda), atol=2e-6)
+    assert torch.equal(e, e.transpose(1, 2))
+    # K alpha = y - m for every episode / class
+    k = sv.view(1, c, 1, 1) * e.unsqueeze(1) + noise.view(1, c, 1, 1) * torch.eye(n, device=cuda)
+    resid = torch.matmul(k.double(), alpha.double().unsqueeze(-1)).squeeze(-1) - (y.double().unsqueeze(0) - mean.double().view(1, c, 1))
+    assert resid.abs().max().item() < 2e-4
+    # determinism: a second launch is bitwise identical (no atomics anywhere)
+    z2 = z.detach().clone().requires_grad_(True)
+    obj2, logp2, *_ = ops.episode_loss_linear(z2, y, sv, mean, noise, cw)
+    obj2.sum().backward()
+    assert torch.equal(logp, logp2) and torch.equal(z.grad, z2.grad)
+    # spot-check three episodes against the oracle at full size
+    for i in (0, 100, 255):
+        ref = O.train_episode(z[i].detach().cpu().numpy().astype(np.float64), c, hyp)
+        assert np.abs((logp[i].cpu().numpy() - ref["logp"]) / ref["logp"]).max() < MLL_RTOL
+        assert rel_l2(z.grad[i].cpu().numpy(), ref["dz"]) < GRAD_RTOL
+    # linearity of the backward in the upstream gradient
+    z3 = z.detach().clone().requires_grad_(True)
+    obj3, *_ = ops.episode_loss_linear(z3, y, sv, mean, noise, cw)
+    (2.5 * obj3.sum()).backward()
+    assert torch.allclose(z3.grad, 2.5 * z.grad, rtol=1e-5, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------
+# the method surface end to end (DKT class on Conv4S / synthetic Omniglot-shaped images)
+# ----------------------------------------------------------------------------------------------
+class _Loader:
+    def __init__(self, n_ep, n_way, per, hw, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.x = [torch.rand(n_way, per, 3, hw, hw, generator=g) for _ in range(n_ep)]
+
+    def __len__(self):
+        return len(self.x)
+
+    def __iter__(self):
+        return iter((x, None) for x in self.x)
+
+
+def test_dkt_train_step_matches_float64_autograd(cuda):
+    """One optimizer-free training episode through DKT._episode_loss vs the torch float64 restatement
+    run on a CPU copy of the same backbone (gradients w.r.t. every backbone / bn_out / GP parameter)."""
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5).to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
+        m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+    import copy
+    ref = copy.deepcopy(m).cpu().double()
+    x = torch.rand(5, 21, 3, 28, 28, generator=torch.Generator().manual_seed(1))
+    x_all = x.view(105, 3, 28, 28)
+    m.train()
+    z = m._embed(x_all.to(cuda))
+    y = m._targets(5, 21, cuda)
+    loss, aux = m._episode_loss(z, y)
+    loss.backward()
+    ref.train()
+    zr = ref._embed(x_all.double())
+    loss_r, logp_r, _ = T.classification_loss(zr, 5, ref.model.outputscale, ref.model.mean, ref.model.noise)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    checked = 0
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None
+            continue
+        # conv biases in front of a train-mode BN have an exactly-zero gradient: absolute floor
+        diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+        assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+        checked += 1
+    assert checked >= 18
+
+
+def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5).to(cuda)
+    before = m.model.raw_outputscale.detach().clone()
+    m.train()
+    m.train_loop(0, _Loader(3, 5, 21, 28, 0), None)
+    assert "Epoch [0] [0/3]" in capsys.readouterr().out
+    assert not torch.equal(before, m.model.raw_outputscale.detach())
+    assert torch.isfinite(m._last["loss"]) and 0.0 <= m._last["acc_query"].item() <= 100.0
+    m.eval()
+    acc, std = m.test_loop(_Loader(4, 5, 20, 28, 1), return_std=True)
+    assert 0.0 <= acc <= 100.0 and std >= 0.0
+    # correct() / get_logits() against the oracle on the features the model itself produced
+    x = _Loader(1, 5, 20, 28, 2).x[0]
+    m.n_query = 15
+    top1, count, avg_loss = m.correct(x)
+    logits = m.get_logits(x)
+    assert count == 75 and logits.shape == (75, 5) and avg_loss == 0.0
+    with torch.no_grad():
+        xs, xq = m._split(x)
+        zs, zq = m._embed(xs).cpu().numpy().astype(np.float64), m._embed(xq).cpu().numpy().astype(np.float64)
+    hyp = O.GPHypers(m.model.outputscale.detach().cpu().numpy().astype(np.float64),
+                     m.model.mean.detach().cpu().numpy().astype(np.float64), np.full(5, 0.1))
+    ref = O.eval_episode(zs, zq, 5, hyp)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-3
+    margin = np.sort(ref["mu"], axis=0)
+    decided = (margin[-1] - margin[-2]) > 1e-3        # ignore numerically tied queries
+    assert (logits.argmax(1).cpu().numpy()[decided] == ref["labels"][decided]).all()
+    # test-time adaptation path (N > 0) runs and returns a finite loss
+    top1b, countb, avg = m.correct(x, N=2)
+    assert countb == 75 and np.isfinite(avg) and avg != 0.0
+
+
+def test_dkt_regression_surface(cuda):
+    torch.manual_seed(0)
+    bb = dkt_amd.backbone.Conv3()
+    m = dkt_amd.DKTRegression(bb, "rbf").to(cuda)
+    opt = torch.optim.Adam([{'params': m.model.parameters(), 'lr': 1e-3}, {'params': m.feature_extractor.parameters(), 'lr': 1e-3}])
+    g = torch.Generator().manual_seed(0)
+    batch = torch.rand(3, 19, 3, 100, 100, generator=g)
+    labels = torch.rand(3, 19, generator=g) * 2 - 1
+    # one task against the float64 restatement
+    z = m.feature_extractor(batch[0].to(cuda))
+    loss, aux = m._loss(z, labels[0].to(cuda))
+    loss.backward()
+    import copy
+    ref = copy.deepcopy(m).cpu().double()
+    for p in ref.parameters():
+        p.grad = None
+    zr = ref.feature_extractor(batch[0].double())
+    loss_r, _, _ = T.regression_loss(zr, labels[0].double(), ref.model.outputscale[0], ref.model.mean[0], ref.model.noise[0],
+                                     ref.model.lengthscale[0])
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is not None:
+            diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+            assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+    m.train_loop(0, opt, batch, labels)
+    mse = m.test_loop(5, inputs=batch, targets=labels)
+    assert mse.dim() == 0 and torch.isfinite(mse)
