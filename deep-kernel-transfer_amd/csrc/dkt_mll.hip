@@ -18,36 +18,10 @@
 // Replaces `-self.mll(output, targets)` + backward + the eval-mode mean cache
 // (reference methods/DKT.py:161-163, 177, 187, 252-254, 265, 330; methods/DKT_regression.py:53-56, 92),
 // i.e. GPyTorch psd_safe_cholesky / inv_quad_logdet / cholesky_solve.
-#include "dkt_common.h"
-#include "../../include/dkt_abi.h"
+#include "dkt_mll.h"
 
 namespace {
 
-struct MllArgs {
-    const float* E;
-    const float* Y;
-    long y_bstride;
-    const float* sv;
-    const float* mean;
-    const float* noise;
-    const float* cls_weight;
-    float* logp;
-    float* alpha;
-    float* L;
-    float* W;
-    float* dsv;
-    float* dmean;
-    float* dnoise;
-    float* jitter_used;
-    int32_t* info;
-    float* ws;
-    int B, C, N, LD;
-    float jitter0;
-    int max_tries;
-    unsigned flags;
-};
-
-constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 constexpr size_t MLL_LDS_LIMIT = 150 * 1024;
 
 __host__ __device__ inline int mll_ld(int N) { return N | 1; }
@@ -167,7 +141,7 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
         }
         const float asum = block_sum_256(apart, red);   // also orders al[] before the readers below
         if (tid == 0) {
-            a.logp[bc] = -0.5f * quad - logdet_half - (float)N * HALF_LOG_2PI;
+            a.logp[bc] = -0.5f * quad - logdet_half - (float)N * DKT_HALF_LOG_2PI;
             a.jitter_used[bc] = jit;
             a.info[bc] = 0;
         }
@@ -237,6 +211,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.ws = (float*)workspace; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (mll_fits_lds(N)) {
         const size_t lds = (mll_vec_floats(N) + mll_mat_floats(N)) * sizeof(float);
         if (lds > 48 * 1024) {

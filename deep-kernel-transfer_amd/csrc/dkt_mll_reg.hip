@@ -1,0 +1,442 @@
+// dkt_mll_reg.hip -- register-resident exact-GP marginal likelihood for N + 1 <= 128 (the few-shot
+// shapes: N = 105, 85, 25, 19, 5).
+//
+// One 256-thread workgroup per episode, classes in sequence.  The (N+1) x N working matrix of
+// dkt_mll.hip (L below the diagonal, U = L^-T above it, w = L^-1 r in row N) never touches LDS: it is
+// distributed 2-D cyclically over the 16 x 16 thread grid,
+//       thread (ty, tx) owns  Mw[ty + 16*pi][tx + 16*ji],  pi, ji in [0, NT),  NT = ceil((N+1)/16),
+// i.e. NT*NT registers per lane (49 for N = 105).  A sweep step costs ONE barrier: the 16 owners of
+// column k publish it (raw) to a double-buffered LDS vector, every thread reads the pivot, takes
+// v_rsq_f32, reads its NT row and NT column entries and does its (statically classified) share of the
+// rank-1 update.  The block column index KQ = k / 16 is a template parameter, so every register index is
+// static and blocks that are structurally untouched (ji < KQ, or KQ < pi < ji) cost nothing.
+//
+// Gradient: K^-1 = U U^T is a Gram matrix of the rows of U, so W = sum_c coef_c (alpha alpha^T - K_c^-1)
+// is accumulated over the classes IN MFMA ACCUMULATORS (v_mfma_f32_16x16x4_f32; U goes through LDS one
+// 16-column chunk at a time, alpha rides along as column N) and written once.  The per-class hyper
+// gradients need only scalars:  tr K^-1 = |U|_F^2,  alpha.alpha,  1.alpha,  r.alpha:
+//     dnoise = 0.5 (alpha.alpha - tr K^-1)
+//     dsv    = 0.5 ((r.alpha - N) - (noise + jitter) (alpha.alpha - tr K^-1)) / sv      [sv E = K - (noise+jitter) I]
+//
+// Replaces the same reference lines as dkt_mll.hip (methods/DKT.py:161-163,177,187,252-254,265,330;
+// methods/DKT_regression.py:53-56,92).
+#include "dkt_mll.h"
+
+namespace {
+
+struct Masks { bool row_ok, col_ok, is_acol; };
+
+constexpr int ULD = 24;   // LDS row stride (floats) of a 16-column chunk of U: 16 + 8 -> conflict-free b128 fragments
+
+template <int NT>
+struct RegCtx {
+    float* colbuf;   // [2][16*NT]
+    float* dv;       // [16*NT] pivots d_k
+    int N, tx, ty, tid;
+    bool col_ok;
+};
+
+// One block column KQ of the sweep: k = 16*KQ + kr, kr = 0 .. min(16, N - 16*KQ) - 1.
+// Returns 0 or (k+1) of the first non-positive pivot (block-uniform).
+template <int NT, int KQ>
+__device__ __forceinline__ int sweep_block(float (&A)[NT][NT], const RegCtx<NT>& c) {
+    constexpr int NP = 16 * NT;
+    const int kend = min(16, c.N - 16 * KQ);
+    const int tx = c.tx, ty = c.ty;
+    const bool lower_eq = ty >= tx;
+    // columns j >= N of the last block column are padding: never updated
+    const bool jpad_ok = c.col_ok;
+    for (int kr = 0; kr < kend; ++kr) {
+        const int k = 16 * KQ + kr;
+        float* cb = c.colbuf + (kr & 1) * NP;
+        if (tx == kr) {
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) cb[ty + 16 * pi] = A[pi][KQ];
+        }
+        __syncthreads();
+        const float d = cb[k];
+        if (!(d > 0.f)) return k + 1;
+        const float rinv = rsqrtf(d);
+        if (c.tid == (k & 255)) c.dv[k] = d;
+        float cp[NT], cj[NT];
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) cp[pi] = cb[ty + 16 * pi] * rinv;
+        if (ty == kr) cp[KQ] = rinv;                    // row k itself: U_kk = 1 / L_kk
+#pragma unroll
+        for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji] * rinv;
+        if (!(tx > kr)) cj[KQ] = 0.f;                   // only columns j > k are updated
+        if (!jpad_ok) cj[NT - 1] = 0.f;
+        const bool row_le_k = ty <= kr;                 // for pi == KQ: p <= k
+#pragma unroll
+        for (int ji = KQ; ji < NT; ++ji) {
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) {
+                if (pi < KQ) {                                        // U part, p <= k
+                    A[pi][ji] -= cp[pi] * cj[ji];
+                } else if (pi == KQ) {
+                    const bool ok = (ji == KQ) ? (row_le_k || lower_eq) : row_le_k;
+                    A[pi][ji] -= ok ? cp[pi] * cj[ji] : 0.f;
+                } else if (pi > ji) {                                 // L part strictly below the block diagonal
+                    A[pi][ji] -= cp[pi] * cj[ji];
+                } else if (pi == ji) {                                // L part on the block diagonal: p >= j
+                    A[pi][ji] -= lower_eq ? cp[pi] * cj[ji] : 0.f;
+                }                                                     // KQ < pi < ji : k < p < j, untouched
+            }
+        }
+        if (tx == kr) {                                               // finalise column k
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) A[pi][KQ] = cp[pi];
+        }
+    }
+    return 0;
+}
+
+template <int NT, int KQ>
+__device__ __forceinline__ int sweep_all(float (&A)[NT][NT], const RegCtx<NT>& c) {
+    if constexpr (KQ < NT) {
+        if (16 * KQ >= c.N) return 0;
+        const int f = sweep_block<NT, KQ>(A, c);
+        if (f) return f;
+        return sweep_all<NT, KQ + 1>(A, c);
+    } else {
+        return 0;
+    }
+}
+
+// Five block-wide sums at once (2 barriers).  red: >= 20 floats.
+__device__ __forceinline__ void block_sum5(float (&v)[5], float* red) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red[(threadIdx.x >> 6) * 5 + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = red[i] + red[5 + i] + red[10 + i] + red[15 + i];
+}
+
+// MFMA accumulation of one 16-column chunk for the tile rows RA (and RB >= 0) owned by this wave.
+// acc index: tiles of row RA first (tj = 0..RA), then tiles of row RB (tj = 0..RB).
+template <int NT, int RA, int RB, int CH>
+__device__ __forceinline__ void w_chunk_mfma(f32x4* acc, const float* ub, int r16, int q, float coef, int N) {
+    // row blocks > CH are all zero in chunk CH (U is upper triangular; alpha sits in the last chunk)
+    f32x4 sc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sc[t] = (16 * CH + 4 * q + t == N) ? coef : -coef;   // column N carries alpha
+    const float* base = ub + r16 * ULD + 4 * q;
+    if constexpr (RA <= CH) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RA * 16 * ULD) * sc;
+#pragma unroll
+        for (int tj = 0; tj <= RA; ++tj) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(base + tj * 16 * ULD);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], acc[tj], 0, 0, 0);
+        }
+    }
+    if constexpr (RB >= 0 && RB <= CH) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RB * 16 * ULD) * sc;
+#pragma unroll
+        for (int tj = 0; tj <= RB; ++tj) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(base + tj * 16 * ULD);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[RA + 1 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], acc[RA + 1 + tj], 0, 0, 0);
+        }
+    }
+}
+
+template <int NT, int RA, int RB>
+struct WaveTiles {
+    static constexpr int NACC = (RA >= 0 ? RA + 1 : 0) + (RB >= 0 ? RB + 1 : 0);
+};
+
+// tile-row assignment per wave: pairs (NT-1-w, w-1) style so every wave owns ~ (NT+1) tiles
+template <int NT, int W> struct RowsOf;
+#define DKT_ROWS(NT_, W_, RA_, RB_) \
+    template <> struct RowsOf<NT_, W_> { static constexpr int RA = RA_, RB = RB_; };
+DKT_ROWS(1, 0, 0, -1) DKT_ROWS(1, 1, -1, -1) DKT_ROWS(1, 2, -1, -1) DKT_ROWS(1, 3, -1, -1)
+DKT_ROWS(2, 0, 1, -1) DKT_ROWS(2, 1, 0, -1) DKT_ROWS(2, 2, -1, -1) DKT_ROWS(2, 3, -1, -1)
+DKT_ROWS(3, 0, 2, -1) DKT_ROWS(3, 1, 1, 0) DKT_ROWS(3, 2, -1, -1) DKT_ROWS(3, 3, -1, -1)
+DKT_ROWS(4, 0, 3, -1) DKT_ROWS(4, 1, 2, -1) DKT_ROWS(4, 2, 1, 0) DKT_ROWS(4, 3, -1, -1)
+DKT_ROWS(5, 0, 4, -1) DKT_ROWS(5, 1, 3, 0) DKT_ROWS(5, 2, 2, 1) DKT_ROWS(5, 3, -1, -1)
+DKT_ROWS(6, 0, 5, -1) DKT_ROWS(6, 1, 4, 0) DKT_ROWS(6, 2, 3, 1) DKT_ROWS(6, 3, 2, -1)
+DKT_ROWS(7, 0, 6, -1) DKT_ROWS(7, 1, 5, 0) DKT_ROWS(7, 2, 4, 1) DKT_ROWS(7, 3, 3, 2)
+DKT_ROWS(8, 0, 7, 0) DKT_ROWS(8, 1, 6, 1) DKT_ROWS(8, 2, 5, 2) DKT_ROWS(8, 3, 4, 3)
+#undef DKT_ROWS
+
+// All chunks of the product for one class: every thread writes its share of the 16-column chunk CH of
+// [U | alpha] to LDS (one barrier per chunk, double buffered), then each wave accumulates its own tile rows.
+template <int NT, int CH>
+__device__ __forceinline__ void w_product_all(f32x4* acc, float (&A)[NT][NT], float* ubuf, int N, int tx, int ty,
+                                              int wave, int r16, int q, float coef, const float (&alpha)[NT], const Masks& m) {
+    if constexpr (CH < NT) {
+        constexpr int NP = 16 * NT;
+        float* ub = ubuf + (CH & 1) * NP * ULD;
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) {
+            const int p = ty + 16 * pi;
+            float v = 0.f;
+            if (CH > pi) v = A[pi][CH];                               // U block
+            else if (CH == pi) v = (tx >= ty) ? A[pi][CH] : 0.f;      // diagonal block: upper incl. diagonal
+            if (CH == NT - 1) {
+                v = m.col_ok ? v : 0.f;                               // columns >= N are not U
+                v = m.is_acol ? alpha[pi] : v;                        // column N carries alpha
+            }
+            if (pi == NT - 1) v = m.row_ok ? v : 0.f;                 // rows >= N
+            ub[p * ULD + tx] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if constexpr (RowsOf<NT, 0>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, CH>(acc, ub, r16, q, coef, N);
+        } else if (wave == 1) {
+            if constexpr (RowsOf<NT, 1>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, CH>(acc, ub, r16, q, coef, N);
+        } else if (wave == 2) {
+            if constexpr (RowsOf<NT, 2>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, CH>(acc, ub, r16, q, coef, N);
+        } else {
+            if constexpr (RowsOf<NT, 3>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, CH>(acc, ub, r16, q, coef, N);
+        }
+        w_product_all<NT, CH + 1>(acc, A, ubuf, N, tx, ty, wave, r16, q, coef, alpha, m);
+    }
+}
+
+// store the accumulated tiles of one tile row (lower triangle + mirror)
+template <int ROW>
+__device__ __forceinline__ void w_store_row(const f32x4* acc, float* Wb, int N, int r16, int q) {
+#pragma unroll
+    for (int tj = 0; tj <= ROW; ++tj) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gi = ROW * 16 + 4 * q + reg, gj = tj * 16 + r16;
+            if (gi < N && gj < N && gj <= gi) {
+                const float v = acc[tj][reg];
+                Wb[(size_t)gi * N + gj] = v;
+                if (gi != gj) Wb[(size_t)gj * N + gi] = v;
+            }
+        }
+    }
+}
+
+template <int NT, bool WANT_GRAD, bool WANT_CHOL>
+__global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 2)) void mll_reg_kernel(MllArgs a) {
+    constexpr int NP = 16 * NT;
+    constexpr int MAXACC = NT + 1;                       // max tiles per wave
+    __shared__ float colbuf[2 * NP];
+    __shared__ float dv[NP];
+    __shared__ float wv[NP];
+    __shared__ float red[20];
+    __shared__ __attribute__((aligned(16))) float ubuf[2 * NP * ULD];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const int N = a.N, C = a.C;
+    const int tyN = N - 16 * (NT - 1);                  // row N lives at pi = NT-1, ty = tyN; column N at ji = NT-1, tx = tyN
+    const bool lower_eq = ty >= tx, upper_eq = tx >= ty;
+    const bool row_ok = ty < tyN, is_w = ty == tyN;      // last block row: p < N / p == N
+    const bool col_ok = tx < tyN, is_acol = tx == tyN;    // last block column: j < N / j == N
+    const float* Eb = a.E + (size_t)b * N * N;
+    constexpr bool want_grad = WANT_GRAD;
+    constexpr bool want_chol = WANT_CHOL;
+
+    Masks masks;
+    masks.row_ok = row_ok; masks.col_ok = col_ok; masks.is_acol = is_acol;
+    RegCtx<NT> ctx;
+    ctx.colbuf = colbuf; ctx.dv = dv; ctx.N = N; ctx.tx = tx; ctx.ty = ty; ctx.tid = tid; ctx.col_ok = col_ok;
+
+    f32x4 acc[MAXACC];
+#pragma unroll
+    for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool poisoned = false;
+
+    for (int c = 0; c < C; ++c) {
+        const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
+        const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
+        float A[NT][NT];
+        int fail_at = 0;
+        float jit = 0.f;
+        for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
+            jit = 0.f;
+            if (attempt > 0) {
+                jit = a.jitter0;
+                for (int i = 1; i < attempt; ++i) jit *= 10.f;
+            }
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) {
+#pragma unroll
+                for (int ji = 0; ji < NT; ++ji) {
+                    // static block structure; only the last block row / column need per-thread masks
+                    const int p = ty + 16 * pi, j = tx + 16 * ji;
+                    float v = 0.f;
+                    if (pi >= ji) {
+                        bool ld = true;                                    // lower-triangle element of K?
+                        if (pi == ji) ld = lower_eq;
+                        if (pi == NT - 1) ld = ld && row_ok;
+                        if (ji == NT - 1) ld = ld && col_ok;
+                        if (ld) {
+                            v = svc * Eb[p * N + j];
+                            if (pi == ji && tx == ty) v += nzc + jit;
+                        }
+                        if (pi == NT - 1) {
+                            bool lw = is_w;
+                            if (ji == NT - 1) lw = lw && col_ok;
+                            if (lw) v = yc[j] - mc;
+                        }
+                    }
+                    A[pi][ji] = v;
+                }
+            }
+            __syncthreads();          // previous users of colbuf / dv are done
+            fail_at = sweep_all<NT, 0>(A, ctx);
+            if (fail_at == 0) break;
+        }
+        const size_t bc = (size_t)b * C + c;
+        if (fail_at != 0) {
+            const float qnan = __int_as_float(0x7fc00000);
+            if (tid == 0) {
+                a.logp[bc] = qnan;
+                a.jitter_used[bc] = jit;
+                a.info[bc] = fail_at;
+                if (want_grad) { a.dsv[bc] = qnan; a.dmean[bc] = qnan; a.dnoise[bc] = qnan; }
+            }
+            for (int i = tid; i < N; i += 256) a.alpha[bc * N + i] = qnan;
+            if constexpr (want_chol)
+                for (int idx = tid; idx < N * N; idx += 256) a.L[bc * N * N + idx] = qnan;
+            poisoned = true;
+            __syncthreads();
+            continue;
+        }
+        // ---- w row -> LDS; scalars ----
+        if (ty == tyN) {
+#pragma unroll
+            for (int ji = 0; ji < NT; ++ji) wv[tx + 16 * ji] = A[NT - 1][ji];
+        }
+        __syncthreads();              // also orders dv[]
+        float wj[NT];
+#pragma unroll
+        for (int ji = 0; ji < NT; ++ji) wj[ji] = wv[tx + 16 * ji];
+        float alpha[NT];
+        float v5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // quad, sum log d, sum alpha, sum alpha^2, |U|_F^2
+        if (ty == tyN) {
+#pragma unroll
+            for (int ji = 0; ji < NT; ++ji) v5[0] += wj[ji] * wj[ji];
+        }
+        if (tid < N) v5[1] = logf(dv[tid]);
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) {
+            const int p = ty + 16 * pi;
+            float s = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int ji = pi; ji < NT; ++ji) {
+                float u = A[pi][ji];
+                if (ji == pi) u = upper_eq ? u : 0.f;              // strictly-lower entries of the diagonal block are L
+                if (ji == NT - 1) u = col_ok ? u : 0.f;            // padding / alpha slot
+                s += u * wj[ji];
+                u2 += u * u;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, DKT_WAVE);
+            if (pi == NT - 1) { s = row_ok ? s : 0.f; u2 = row_ok ? u2 : 0.f; }
+            alpha[pi] = s;                                          // alpha_p, replicated over the 16 tx lanes
+            v5[4] += u2;
+            if (tx == 0) {
+                v5[2] += s;
+                v5[3] += s * s;
+                if (pi < NT - 1 || row_ok) a.alpha[bc * N + p] = s;
+            }
+        }
+        block_sum5(v5, red);
+        const float quad = v5[0], logdet_half = 0.5f * v5[1], asum = v5[2], a2 = v5[3], trk = v5[4];
+        if (tid == 0) {
+            a.logp[bc] = -0.5f * quad - logdet_half - (float)N * DKT_HALF_LOG_2PI;
+            a.jitter_used[bc] = jit;
+            a.info[bc] = 0;
+            if (want_grad) {
+                const float nz_eff = nzc + jit;
+                a.dmean[bc] = asum;
+                a.dnoise[bc] = 0.5f * (a2 - trk);
+                a.dsv[bc] = 0.5f * ((quad - (float)N) - nz_eff * (a2 - trk)) / svc;
+            }
+        }
+        if constexpr (want_chol) {
+            float* Lb = a.L + bc * N * N;
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) {
+#pragma unroll
+                for (int ji = 0; ji < NT; ++ji) {
+                    const int p = ty + 16 * pi, j = tx + 16 * ji;
+                    bool ok = true;
+                    if (pi == NT - 1) ok = ok && row_ok;
+                    if (ji == NT - 1) ok = ok && col_ok;
+                    if (ok) {
+                        float v = 0.f;
+                        if (pi > ji) v = A[pi][ji];
+                        else if (pi == ji) v = (ty > tx) ? A[pi][ji] : ((ty == tx) ? sqrtf(dv[p]) : 0.f);
+                        Lb[p * N + j] = v;
+                    }
+                }
+            }
+        }
+        if constexpr (want_grad) {
+            const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
+            const float coef = 0.5f * cw * svc;
+            // W += coef (alpha alpha^T - U U^T): alpha rides as column N of the chunked U matrix
+            w_product_all<NT, 0>(acc, A, ubuf, N, tx, ty, wave, r16, q, coef, alpha, masks);
+        }
+        __syncthreads();
+    }
+
+    if constexpr (want_grad) {
+        float* Wb = a.W + (size_t)b * N * N;
+        if (poisoned) {
+            const float qnan = __int_as_float(0x7fc00000);
+            for (int idx = tid; idx < N * N; idx += 256) Wb[idx] = qnan;
+        } else {
+            switch (wave) {
+                case 0:
+                    if constexpr (RowsOf<NT, 0>::RA >= 0) w_store_row<RowsOf<NT, 0>::RA>(acc, Wb, N, r16, q);
+                    if constexpr (RowsOf<NT, 0>::RB >= 0) w_store_row<RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Wb, N, r16, q);
+                    break;
+                case 1:
+                    if constexpr (RowsOf<NT, 1>::RA >= 0) w_store_row<RowsOf<NT, 1>::RA>(acc, Wb, N, r16, q);
+                    if constexpr (RowsOf<NT, 1>::RB >= 0) w_store_row<RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Wb, N, r16, q);
+                    break;
+                case 2:
+                    if constexpr (RowsOf<NT, 2>::RA >= 0) w_store_row<RowsOf<NT, 2>::RA>(acc, Wb, N, r16, q);
+                    if constexpr (RowsOf<NT, 2>::RB >= 0) w_store_row<RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Wb, N, r16, q);
+                    break;
+                default:
+                    if constexpr (RowsOf<NT, 3>::RA >= 0) w_store_row<RowsOf<NT, 3>::RA>(acc, Wb, N, r16, q);
+                    if constexpr (RowsOf<NT, 3>::RB >= 0) w_store_row<RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Wb, N, r16, q);
+                    break;
+            }
+        }
+    }
+}
+
+template <int NT>
+void launch_reg(const MllArgs& a, hipStream_t st) {
+    const bool g = (a.flags & DKT_MLL_WANT_GRAD) != 0, c = (a.flags & DKT_MLL_WANT_CHOL) != 0;
+    if (g && c) hipLaunchKernelGGL((mll_reg_kernel<NT, true, true>), dim3(a.B), dim3(256), 0, st, a);
+    else if (g) hipLaunchKernelGGL((mll_reg_kernel<NT, true, false>), dim3(a.B), dim3(256), 0, st, a);
+    else if (c) hipLaunchKernelGGL((mll_reg_kernel<NT, false, true>), dim3(a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((mll_reg_kernel<NT, false, false>), dim3(a.B), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st) {
+    const int nt = (a.N + 1 + 15) / 16;
+    switch (nt) {
+        case 1: launch_reg<1>(a, st); return true;
+        case 2: launch_reg<2>(a, st); return true;
+        case 3: launch_reg<3>(a, st); return true;
+        case 4: launch_reg<4>(a, st); return true;
+        case 5: launch_reg<5>(a, st); return true;
+        case 6: launch_reg<6>(a, st); return true;
+        case 7: launch_reg<7>(a, st); return true;
+        case 8: launch_reg<8>(a, st); return true;
+        default: return false;
+    }
+}

@@ -23,6 +23,7 @@ KERNEL_LINEAR = 0
 KERNEL_RBF = 1
 MLL_WANT_GRAD = 1
 MLL_WANT_CHOL = 2
+MLL_FORCE_GENERIC = 4
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -118,7 +119,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
 
 def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
-        jitter0: float = 1e-6, max_tries: int = 3) -> dict:
+        jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False) -> dict:
     """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N]."""
     e = _req(e, "e", 3)
     b_, n, n2 = e.shape
@@ -143,7 +144,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
-    flags = 0
+    flags = MLL_FORCE_GENERIC if force_generic else 0
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL

@@ -89,16 +89,20 @@ def _episode_case(c, per, d, seed, corr=0, b=2):
 
 
 @pytest.mark.parametrize("c,per,d,corr", [(1, 1, 8, 0), (2, 1, 8, 0), (5, 1, 64, 0), (5, 5, 64, 0), (5, 17, 512, 0),
+                                          (3, 5, 16, 0), (4, 4, 16, 0), (1, 17, 16, 0), (3, 37, 24, 0), (4, 28, 24, 0), (7, 18, 24, 0), (1, 127, 24, 0),
                                           (5, 21, 64, 0), (5, 21, 1600, 5), (5, 26, 40, 0), (5, 38, 32, 0),
                                           (4, 50, 64, 0), (20, 16, 512, 0), (20, 21, 512, 20)])
-def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr):
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, force_generic):
+    """force_generic=False: register-resident kernel for N <= 126, generic LDS/global kernel above;
+    force_generic=True: the generic kernel for every N."""
     z, hyp, n = _episode_case(c, per, d, 17 + n_hash(c, per, d), corr)
     y = O.one_vs_rest_targets(c, per)
     sv = hyp.outputscale
     cw = np.full(c, -1.0 / (c * n))
     e_dev = ops.gram(dev_t(z, cuda))
     out = ops.mll(e_dev, dev_t(y, cuda), dev_t(sv, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda),
-                  want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda))
+                  want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda), force_generic=force_generic)
     torch.cuda.synchronize()
     assert int(out["info"].abs().max().item()) == 0
     assert float(out["jitter"].abs().max().item()) == 0.0
@@ -144,7 +148,8 @@ def test_mll_per_episode_targets_and_residual_property(cuda):
         assert np.abs(l @ l.T - k).max() < 1e-5 and np.abs(np.triu(l, 1)).max() == 0.0
 
 
-def test_jitter_retry_and_failure_info(cuda):
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_jitter_retry_and_failure_info(cuda, force_generic):
     rng = np.random.default_rng(0)
     q, _ = np.linalg.qr(rng.standard_normal((8, 8)))
     y = np.ones((1, 8))
@@ -152,7 +157,8 @@ def test_jitter_retry_and_failure_info(cuda):
     def run(min_eig):
         e = q @ np.diag([min_eig, 0.3, 0.5, 0.7, 1.0, 1.2, 1.5, 2.0]) @ q.T
         e = 0.5 * (e + e.T)
-        o = ops.mll(dev_t(e[None], cuda), dev_t(y, cuda), dev_t([1.0], cuda), dev_t([0.0], cuda), dev_t([0.1], cuda))
+        o = ops.mll(dev_t(e[None], cuda), dev_t(y, cuda), dev_t([1.0], cuda), dev_t([0.0], cuda), dev_t([0.1], cuda),
+                    want_grad=True, force_generic=force_generic)
         return e, o
 
     # K = E + 0.1 I has smallest eigenvalue -5e-5: plain, 1e-6, 1e-5 fail; total jitter 1e-4 succeeds
