@@ -15,6 +15,9 @@
 #include "dkt_common.h"
 #include "../../include/dkt_abi.h"
 
+bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipStream_t st);
+bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st);
+
 namespace {
 
 constexpr int GT = 64;         // output tile edge
@@ -316,8 +319,10 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     if (kind == DKT_KERNEL_RBF && !lengthscale) return DKT_ERR_BAD_ARG;
     const bool sym = (Bm == nullptr);
     if (sym && M != N) return DKT_ERR_BAD_ARG;
-    if (B > 65535) return DKT_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
+    if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, st))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, B), block(256);
     if (kind == DKT_KERNEL_LINEAR) {
         if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_LINEAR, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
@@ -332,6 +337,8 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
 extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
                                 const float* ep_scale, void* stream) {
     if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if (dkt_gram_bwd_ep_launch(W, Z, dZ, B, N, D, ep_scale, (hipStream_t)stream))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((D + GT - 1) / GT, (N + GT - 1) / GT, B), block(256);
     hipLaunchKernelGGL(gram_bwd_kernel, grid, block, 0, (hipStream_t)stream, W, Z, dZ, N, D, ep_scale);

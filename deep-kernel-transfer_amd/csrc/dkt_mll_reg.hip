@@ -21,6 +21,7 @@
 // Replaces the same reference lines as dkt_mll.hip (methods/DKT.py:161-163,177,187,252-254,265,330;
 // methods/DKT_regression.py:53-56,92).
 #include "dkt_mll.h"
+#include "dkt_tiles.h"
 
 namespace {
 
@@ -147,24 +148,6 @@ __device__ __forceinline__ void w_chunk_mfma(f32x4* acc, const float* ub, int r1
     }
 }
 
-template <int NT, int RA, int RB>
-struct WaveTiles {
-    static constexpr int NACC = (RA >= 0 ? RA + 1 : 0) + (RB >= 0 ? RB + 1 : 0);
-};
-
-// tile-row assignment per wave: pairs (NT-1-w, w-1) style so every wave owns ~ (NT+1) tiles
-template <int NT, int W> struct RowsOf;
-#define DKT_ROWS(NT_, W_, RA_, RB_) \
-    template <> struct RowsOf<NT_, W_> { static constexpr int RA = RA_, RB = RB_; };
-DKT_ROWS(1, 0, 0, -1) DKT_ROWS(1, 1, -1, -1) DKT_ROWS(1, 2, -1, -1) DKT_ROWS(1, 3, -1, -1)
-DKT_ROWS(2, 0, 1, -1) DKT_ROWS(2, 1, 0, -1) DKT_ROWS(2, 2, -1, -1) DKT_ROWS(2, 3, -1, -1)
-DKT_ROWS(3, 0, 2, -1) DKT_ROWS(3, 1, 1, 0) DKT_ROWS(3, 2, -1, -1) DKT_ROWS(3, 3, -1, -1)
-DKT_ROWS(4, 0, 3, -1) DKT_ROWS(4, 1, 2, -1) DKT_ROWS(4, 2, 1, 0) DKT_ROWS(4, 3, -1, -1)
-DKT_ROWS(5, 0, 4, -1) DKT_ROWS(5, 1, 3, 0) DKT_ROWS(5, 2, 2, 1) DKT_ROWS(5, 3, -1, -1)
-DKT_ROWS(6, 0, 5, -1) DKT_ROWS(6, 1, 4, 0) DKT_ROWS(6, 2, 3, 1) DKT_ROWS(6, 3, 2, -1)
-DKT_ROWS(7, 0, 6, -1) DKT_ROWS(7, 1, 5, 0) DKT_ROWS(7, 2, 4, 1) DKT_ROWS(7, 3, 3, 2)
-DKT_ROWS(8, 0, 7, 0) DKT_ROWS(8, 1, 6, 1) DKT_ROWS(8, 2, 5, 2) DKT_ROWS(8, 3, 4, 3)
-#undef DKT_ROWS
 
 // All chunks of the product for one class: every thread writes its share of the 16-column chunk CH of
 // [U | alpha] to LDS (one barrier per chunk, double buffered), then each wave accumulates its own tile rows.
