@@ -131,6 +131,34 @@ def timings():
     print("test episodes (25->75, D=1600): %.0f eps/s" % (600 * 10 / (time.perf_counter() - t0)))
 
 
+def ep_vs_v0():
+    b, n, d = 256, 105, 1600
+    g = torch.Generator(device=dev).manual_seed(3)
+    z = torch.nn.functional.normalize(torch.randn(b, n, d, device=dev, generator=g), dim=2)
+    w = torch.randn(b, n, n, device=dev, generator=g) * 0.01
+    sc = torch.full((b,), 2.5, device=dev)
+    for name, ww in (("asym", w), ("sym", 0.5 * (w + w.transpose(1, 2)))):
+        os.environ["DKT_GRAM_EP"] = "1"
+        a1 = ops.gram_bwd(ww, z)
+        a2 = ops.gram_bwd(ww, z, sc)
+        e1 = ops.gram(z)
+        os.environ["DKT_GRAM_EP"] = "0"
+        b1 = ops.gram_bwd(ww, z)
+        b2 = ops.gram_bwd(ww, z, sc)
+        e0 = ops.gram(z)
+        os.environ["DKT_GRAM_EP"] = "1"
+        ref = torch.matmul((ww + ww.transpose(1, 2)).double(), z.double())
+        def mx(x, y):
+            dd = (x.double() - y.double()).abs()
+            i = int(dd.argmax())
+            return "%.3e at %s (vals %.6e %.6e)" % (dd.max().item(), tuple(int(v) for v in np.unravel_index(i, dd.shape)),
+                                                   x.flatten()[i].item(), y.flatten()[i].item())
+        print(name, "ep vs f64:", mx(a1, ref), "| v0 vs f64:", mx(b1, ref))
+        print(name, "ep scaled vs 2.5*ep:", mx(a2, 2.5 * a1), "| v0 scaled vs 2.5*v0:", mx(b2, 2.5 * b1))
+        print(name, "gram ep vs v0:", mx(e1, e0))
+
+
+section("ep_vs_v0", ep_vs_v0)
 section("gram", gram_checks)
 section("mll", mll_checks)
 section("gram_bwd", bwd_checks)
