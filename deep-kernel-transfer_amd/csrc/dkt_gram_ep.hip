@@ -8,10 +8,10 @@
 //   NT b128 fragments per 16-wide K slice for its ~NT+1 tiles x 4 MFMAs and no cross-wave reduction is
 //   needed.  HBM traffic = the algorithmic 4 (N D + N^2) bytes per episode.
 //
-// gram_bwd_ep_kernel<NT, BD>: dZ = s_b (W + W^T) Z, one workgroup per episode.  Each wave keeps the
-//   A-operand fragments of ITS tile rows of (W + W^T) in registers for the whole episode (2 row blocks x
-//   NT K-slices x 4 VGPRs), Z is streamed through LDS in [16 NT] x BD column slabs (read once, coalesced),
-//   every wave multiplies its rows with the shared slab.  HBM traffic = 4 (2 N D + N^2) bytes per episode.
+// gram_bwd_ep_kernel<NT, BD>: dZ = s_b (W + W^T) Z, one workgroup of NT waves per episode.  Wave w keeps the
+//   A-operand fragments of row block w of (W + W^T) in registers for the whole episode (NT K-slices x 4
+//   VGPRs), Z is streamed through LDS in [16 NT] x BD column slabs (read once, coalesced), every wave
+//   multiplies its row block with the shared slab.  HBM traffic = 4 (2 N D + N^2) bytes per episode.
 //
 // Replaces (same lines as dkt_gram.hip): ExactGPLayer.forward -> covar_module(x) (methods/DKT.py:375-378)
 // and autograd through it (DKT.py:163).
@@ -135,18 +135,18 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// dZ = s (W + W^T) Z.  Wave w owns output row blocks w and w + 4 (when < NT).
+// dZ = s (W + W^T) Z.  The workgroup has NT waves; wave w owns output row block w (16 rows) for every
+// column of the slab, keeps its NT A-fragments of s (W + W^T) in registers for the whole episode, and all
+// waves share the Z slab in LDS -- perfectly balanced MFMA work, BD/16 float4 staging loads per thread.
 template <int NT, int BD>
-__global__ __launch_bounds__(256) void gram_bwd_ep_kernel(const float* __restrict__ W, const float* __restrict__ Z,
-                                                          float* __restrict__ dZ, int N, int D,
-                                                          const float* __restrict__ ep_scale) {
+__global__ __launch_bounds__(64 * NT) void gram_bwd_ep_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+                                                              float* __restrict__ dZ, int N, int D,
+                                                              const float* __restrict__ ep_scale) {
     constexpr int NP = 16 * NT;
+    constexpr int NTH = 64 * NT;
     constexpr int BLD = BD + 4;                        // b32 B-fragment reads: rows 4q+t, 16 consecutive columns
     constexpr int V4_PER_ROW = BD / 4;
-    constexpr int NV4 = NP * V4_PER_ROW;
-    constexpr int NLD = (NV4 + 255) / 256;
-    constexpr int NCT = BD / 16;                       // column tiles per slab
-    constexpr int NRB = (NT + 3) / 4;                  // row blocks per wave (max)
+    constexpr int NCT = BD / 16;                       // column tiles per slab == float4 loads per thread per slab
     __shared__ __attribute__((aligned(16))) float zs[2][NP * BLD];
 
     const int b = blockIdx.x;
@@ -156,11 +156,10 @@ __global__ __launch_bounds__(256) void gram_bwd_ep_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
     const float s = ep_scale ? ep_scale[b] : 1.0f;
 
-    // A fragments of (W + W^T), scaled by s, for this wave's row blocks: a[rb][kk][t] = Wsym[row][16 kk + 4 q + t]
-    f32x4 afr[NRB][NT];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        const int row = (wave + 4 * rb) * 16 + r16;
+    // A fragments: a[kk][t] = s * Wsym[wave*16 + r16][16 kk + 4 q + t]
+    f32x4 afr[NT];
+    {
+        const int row = wave * 16 + r16;
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
 #pragma unroll
@@ -168,29 +167,29 @@ __global__ __launch_bounds__(256) void gram_bwd_ep_kernel(const float* __restric
                 const int k = kk * 16 + 4 * q + t;
                 float v = 0.f;
                 if (row < N && k < N) v = s * (Wb[row * N + k] + Wb[k * N + row]);
-                afr[rb][kk][t] = v;
+                afr[kk][t] = v;
             }
         }
     }
 
-    float4 rg[NLD];
+    float4 rg[NCT];
     auto gload = [&](int d0) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NCT; ++i) {
+            const int idx = tid + NTH * i;
             const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
             const int d = d0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((NV4 % 256 == 0 || idx < NV4) && row < N && d < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)row * D + d);
+            if (row < N && d < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)row * D + d);
             rg[i] = v;
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NCT; ++i) {
+            const int idx = tid + NTH * i;
             const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
-            if (NV4 % 256 == 0 || idx < NV4) *reinterpret_cast<float4*>(&zs[buf][row * BLD + 4 * c4]) = rg[i];
+            *reinterpret_cast<float4*>(&zs[buf][row * BLD + 4 * c4]) = rg[i];
         }
     };
 
@@ -201,11 +200,9 @@ __global__ __launch_bounds__(256) void gram_bwd_ep_kernel(const float* __restric
     for (int sl = 0; sl < nslab; ++sl) {
         const int buf = sl & 1;
         if (sl + 1 < nslab) gload((sl + 1) * BD);
-        f32x4 acc[NRB][NCT];
+        f32x4 acc[NCT];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* bs = zs[buf];
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
@@ -217,28 +214,17 @@ __global__ __launch_bounds__(256) void gram_bwd_ep_kernel(const float* __restric
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-                    if (wave + 4 * rb < NT) {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct)
-                            acc[rb][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[rb][kk][t], bf[ct][t], acc[rb][ct], 0, 0, 0);
-                    }
-                }
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kk][t], bf[ct][t], acc[ct], 0, 0, 0);
         }
-        // store: row = blk*16 + 4q + reg, 16 consecutive columns per lane group
         const int d0 = sl * BD;
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            if (wave + 4 * rb < NT) {
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = wave * 16 + 4 * q + reg;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = (wave + 4 * rb) * 16 + 4 * q + reg;
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const int d = d0 + ct * 16 + r16;
-                        if (row < N && d < D) dZb[(size_t)row * D + d] = acc[rb][ct][reg];
-                    }
-                }
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int d = d0 + ct * 16 + r16;
+                if (row < N && d < D) dZb[(size_t)row * D + d] = acc[ct][reg];
             }
         }
         if (sl + 1 < nslab) lstore(buf ^ 1);
@@ -254,8 +240,8 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream
 
 template <int NT>
 void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, hipStream_t st) {
-    if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, W, Z, dZ, N, D, sc);
-    else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, W, Z, dZ, N, D, sc);
+    if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+    else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
 }
 
 int env_int(const char* name, int dflt) {

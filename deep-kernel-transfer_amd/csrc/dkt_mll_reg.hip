@@ -32,21 +32,21 @@ constexpr int ULD = 24;   // LDS row stride (floats) of a 16-column chunk of U: 
 template <int NT>
 struct RegCtx {
     float* colbuf;   // [2][16*NT]
-    float* dv;       // [16*NT] pivots d_k
     int N, tx, ty, tid;
     bool col_ok;
 };
 
 // One block column KQ of the sweep: k = 16*KQ + kr, kr = 0 .. min(16, N - 16*KQ) - 1.
 // Returns 0 or (k+1) of the first non-positive pivot (block-uniform).
+// Columns are scaled LAZILY: the registers keep the raw column and rinvcol[ji] remembers 1/L_kk of the
+// thread's column k = tx + 16 ji (applied once after the sweep) -- one v_cndmask per step instead of NT.
+// Structural masks are folded into copies of the row factor so every block update is a single v_fma.
 template <int NT, int KQ>
-__device__ __forceinline__ int sweep_block(float (&A)[NT][NT], const RegCtx<NT>& c) {
+__device__ __forceinline__ int sweep_block(float (&A)[NT][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
     constexpr int NP = 16 * NT;
     const int kend = min(16, c.N - 16 * KQ);
     const int tx = c.tx, ty = c.ty;
     const bool lower_eq = ty >= tx;
-    // columns j >= N of the last block column are padding: never updated
-    const bool jpad_ok = c.col_ok;
     for (int kr = 0; kr < kend; ++kr) {
         const int k = 16 * KQ + kr;
         float* cb = c.colbuf + (kr & 1) * NP;
@@ -57,48 +57,46 @@ __device__ __forceinline__ int sweep_block(float (&A)[NT][NT], const RegCtx<NT>&
         __syncthreads();
         const float d = cb[k];
         if (!(d > 0.f)) return k + 1;
-        const float rinv = rsqrtf(d);
-        if (c.tid == (k & 255)) c.dv[k] = d;
+        const float rinv = __builtin_amdgcn_rsqf(d);
+        log2sum += __builtin_amdgcn_logf(d);            // v_log_f32 = log2
         float cp[NT], cj[NT];
 #pragma unroll
         for (int pi = 0; pi < NT; ++pi) cp[pi] = cb[ty + 16 * pi] * rinv;
-        if (ty == kr) cp[KQ] = rinv;                    // row k itself: U_kk = 1 / L_kk
+        cp[KQ] = (ty == kr) ? rinv : cp[KQ];            // row k itself: U_kk = 1 / L_kk
 #pragma unroll
         for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji] * rinv;
-        if (!(tx > kr)) cj[KQ] = 0.f;                   // only columns j > k are updated
-        if (!jpad_ok) cj[NT - 1] = 0.f;
-        const bool row_le_k = ty <= kr;                 // for pi == KQ: p <= k
+        cj[KQ] = (tx > kr) ? cj[KQ] : 0.f;              // only columns j > k are updated
+        cj[NT - 1] = c.col_ok ? cj[NT - 1] : 0.f;       // padding columns j >= N
+        const bool row_le_k = ty <= kr;
+        const float cpk_le = row_le_k ? cp[KQ] : 0.f;                  // row block KQ, ji > KQ: p <= k only
+        const float cpk_dd = (row_le_k || lower_eq) ? cp[KQ] : 0.f;    // block (KQ, KQ): p <= k or p >= j
 #pragma unroll
         for (int ji = KQ; ji < NT; ++ji) {
 #pragma unroll
             for (int pi = 0; pi < NT; ++pi) {
-                if (pi < KQ) {                                        // U part, p <= k
-                    A[pi][ji] -= cp[pi] * cj[ji];
+                if (pi < KQ) {                                         // U part, p <= k
+                    A[pi][ji] = __builtin_fmaf(-cp[pi], cj[ji], A[pi][ji]);
                 } else if (pi == KQ) {
-                    const bool ok = (ji == KQ) ? (row_le_k || lower_eq) : row_le_k;
-                    A[pi][ji] -= ok ? cp[pi] * cj[ji] : 0.f;
-                } else if (pi > ji) {                                 // L part strictly below the block diagonal
-                    A[pi][ji] -= cp[pi] * cj[ji];
-                } else if (pi == ji) {                                // L part on the block diagonal: p >= j
-                    A[pi][ji] -= lower_eq ? cp[pi] * cj[ji] : 0.f;
-                }                                                     // KQ < pi < ji : k < p < j, untouched
+                    A[pi][ji] = __builtin_fmaf(-(ji == KQ ? cpk_dd : cpk_le), cj[ji], A[pi][ji]);
+                } else if (pi > ji) {                                  // L part strictly below the block diagonal
+                    A[pi][ji] = __builtin_fmaf(-cp[pi], cj[ji], A[pi][ji]);
+                } else if (pi == ji) {                                 // L part on the block diagonal: p >= j
+                    A[pi][ji] = __builtin_fmaf(-(lower_eq ? cp[pi] : 0.f), cj[ji], A[pi][ji]);
+                }                                                      // KQ < pi < ji : k < p < j, untouched
             }
         }
-        if (tx == kr) {                                               // finalise column k
-#pragma unroll
-            for (int pi = 0; pi < NT; ++pi) A[pi][KQ] = cp[pi];
-        }
+        rinvcol[KQ] = (tx == kr) ? rinv : rinvcol[KQ];
     }
     return 0;
 }
 
 template <int NT, int KQ>
-__device__ __forceinline__ int sweep_all(float (&A)[NT][NT], const RegCtx<NT>& c) {
+__device__ __forceinline__ int sweep_all(float (&A)[NT][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
     if constexpr (KQ < NT) {
         if (16 * KQ >= c.N) return 0;
-        const int f = sweep_block<NT, KQ>(A, c);
+        const int f = sweep_block<NT, KQ>(A, rinvcol, log2sum, c);
         if (f) return f;
-        return sweep_all<NT, KQ + 1>(A, c);
+        return sweep_all<NT, KQ + 1>(A, rinvcol, log2sum, c);
     } else {
         return 0;
     }
@@ -206,7 +204,6 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
     constexpr int NP = 16 * NT;
     constexpr int MAXACC = NT + 1;                       // max tiles per wave
     __shared__ float colbuf[2 * NP];
-    __shared__ float dv[NP];
     __shared__ float wv[NP];
     __shared__ float red[20];
     __shared__ __attribute__((aligned(16))) float ubuf[2 * NP * ULD];
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
     Masks masks;
     masks.row_ok = row_ok; masks.col_ok = col_ok; masks.is_acol = is_acol;
     RegCtx<NT> ctx;
-    ctx.colbuf = colbuf; ctx.dv = dv; ctx.N = N; ctx.tx = tx; ctx.ty = ty; ctx.tid = tid; ctx.col_ok = col_ok;
+    ctx.colbuf = colbuf; ctx.N = N; ctx.tx = tx; ctx.ty = ty; ctx.tid = tid; ctx.col_ok = col_ok;
 
     f32x4 acc[MAXACC];
 #pragma unroll
@@ -236,7 +233,8 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
     for (int c = 0; c < C; ++c) {
         const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
         const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
-        float A[NT][NT];
+        float A[NT][NT], rinvcol[NT];
+        float log2sum = 0.f;
         int fail_at = 0;
         float jit = 0.f;
         for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
@@ -270,8 +268,11 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
                     A[pi][ji] = v;
                 }
             }
-            __syncthreads();          // previous users of colbuf / dv are done
-            fail_at = sweep_all<NT, 0>(A, ctx);
+            __syncthreads();          // previous users of colbuf are done
+#pragma unroll
+            for (int ji = 0; ji < NT; ++ji) rinvcol[ji] = 1.0f;
+            log2sum = 0.f;
+            fail_at = sweep_all<NT, 0>(A, rinvcol, log2sum, ctx);
             if (fail_at == 0) break;
         }
         const size_t bc = (size_t)b * C + c;
@@ -290,12 +291,21 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
             __syncthreads();
             continue;
         }
+        // ---- apply the lazy column scaling: column k gets 1 / L_kk, the diagonal slot becomes U_kk = 1 / L_kk ----
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) {
+#pragma unroll
+            for (int ji = 0; ji < NT; ++ji) {
+                A[pi][ji] *= rinvcol[ji];
+                if (pi == ji) A[pi][ji] = (tx == ty) ? rinvcol[ji] : A[pi][ji];
+            }
+        }
         // ---- w row -> LDS; scalars ----
         if (ty == tyN) {
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) wv[tx + 16 * ji] = A[NT - 1][ji];
         }
-        __syncthreads();              // also orders dv[]
+        __syncthreads();
         float wj[NT];
 #pragma unroll
         for (int ji = 0; ji < NT; ++ji) wj[ji] = wv[tx + 16 * ji];
@@ -305,7 +315,6 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) v5[0] += wj[ji] * wj[ji];
         }
-        if (tid < N) v5[1] = logf(dv[tid]);
 #pragma unroll
         for (int pi = 0; pi < NT; ++pi) {
             const int p = ty + 16 * pi;
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
             }
         }
         block_sum5(v5, red);
-        const float quad = v5[0], logdet_half = 0.5f * v5[1], asum = v5[2], a2 = v5[3], trk = v5[4];
+        const float quad = v5[0], logdet_half = 0.34657359027997264f * log2sum, asum = v5[2], a2 = v5[3], trk = v5[4];
         if (tid == 0) {
             a.logp[bc] = -0.5f * quad - logdet_half - (float)N * DKT_HALF_LOG_2PI;
             a.jitter_used[bc] = jit;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
                     if (ok) {
                         float v = 0.f;
                         if (pi > ji) v = A[pi][ji];
-                        else if (pi == ji) v = (ty > tx) ? A[pi][ji] : ((ty == tx) ? sqrtf(dv[p]) : 0.f);
+                        else if (pi == ji) v = (ty > tx) ? A[pi][ji] : ((ty == tx) ? 1.0f / rinvcol[ji] : 0.f);
                         Lb[p * N + j] = v;
                     }
                 }
