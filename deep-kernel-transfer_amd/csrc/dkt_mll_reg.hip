@@ -297,7 +297,11 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) {
                 A[pi][ji] *= rinvcol[ji];
-                if (pi == ji) A[pi][ji] = (tx == ty) ? rinvcol[ji] : A[pi][ji];
+                if (pi == ji) {
+                    bool dg = tx == ty;
+                    if (pi == NT - 1) dg = dg && col_ok;           // the (N, N) corner and beyond are padding, not pivots
+                    A[pi][ji] = dg ? rinvcol[ji] : A[pi][ji];
+                }
             }
         }
         // ---- w row -> LDS; scalars ----
