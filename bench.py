@@ -159,11 +159,22 @@ def main():
             kernels[name] = dict(launches=cnt, ms=round(ms, 4), gbs=round(a["bytes"] * b / ms / 1e6, 1),
                                  tflops=round(a["flops"] * b / ms / 1e9, 2))
         dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot
+        # profile itself); linear in the episode count, so scaled when --episodes differs from the profiled run.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.config == "cfg2" and dom in tj["kernels"]:
+                traffic = round(tj["kernels"][dom]["hbm_bytes"] * b / tj["episodes_per_launch"])
+                traffic_src = tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = None
         if dom:
             k = kernels[dom]
             roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(k["gbs"] / HBM_PEAK_GBS, 4), traffic=None,
+                            frac=round(k["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit="bytes/launch (PMC)",
+                            traffic_source=traffic_src, algorithmic_bytes_per_launch=alg[dom]["bytes"] * b,
                             mfma_f32=dict(achieved=k["tflops"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                                           frac=round(k["tflops"] / MFMA_F32_PEAK_TFLOPS, 4)),
                             avg_launch_ms=k["ms"], episodes_per_launch=b)

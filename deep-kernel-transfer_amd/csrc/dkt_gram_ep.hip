@@ -268,7 +268,7 @@ bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipSt
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
     if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
     if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
-    const int bd = env_int("DKT_GRAM_EP_BD", 64);
+    const int bd = env_int("DKT_GRAM_EP_BD", 32);
     switch ((N + 15) / 16) {
         case 5: launch_bwd<5>(W, Z, dZ, B, N, D, sc, bd, st); return true;
         case 6: launch_bwd<6>(W, Z, dZ, B, N, D, sc, bd, st); return true;

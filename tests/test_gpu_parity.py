@@ -126,6 +126,28 @@ def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, force_generi
         assert rel_l2(out["dnoise"][i].cpu().numpy(), dnoise) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("c,per,d,corr", [(5, 21, 64, 0), (5, 21, 1600, 5), (1, 104, 32, 0), (3, 37, 24, 0)])
+def test_mll_wave_per_episode_kernel(cuda, c, per, d, corr, monkeypatch):
+    """The barrier-free wave-per-episode kernel (off by default) stays parity-green for its
+    N range (104 <= N <= 111): it must reproduce the register kernel's outputs to rounding."""
+    z, hyp, n = _episode_case(c, per, d, 5 + n_hash(c, per, d), corr, b=3)
+    y = dev_t(O.one_vs_rest_targets(c, per), cuda)
+    cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
+    e = ops.gram(dev_t(z, cuda))
+    args = (e, y, dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda))
+    monkeypatch.setenv("DKT_MLL_WAVE", "1")
+    a = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=cw)
+    monkeypatch.setenv("DKT_MLL_WAVE", "0")
+    r = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=cw)
+    torch.cuda.synchronize()
+    for i in range(3):
+        res = O.mll_terms(O.gram_linear(z[i]), O.one_vs_rest_targets(c, per), hyp.outputscale, hyp.mean, hyp.noise)
+        assert np.abs((a["logp"][i].cpu().numpy() - res.logp) / res.logp).max() < MLL_RTOL
+    for key in ("logp", "alpha", "chol", "w", "dsv", "dmean", "dnoise"):
+        assert rel_l2(a[key].cpu().numpy(), r[key].cpu().numpy()) < 1e-4, key
+    assert int(a["info"].abs().max().item()) == 0
+
+
 def n_hash(*a):
     return int(sum((i + 1) * v for i, v in enumerate(a)))
 
