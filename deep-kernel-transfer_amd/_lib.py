@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
-SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_wave.hip", "dkt_predict.hip"]
+SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_blk.hip", "dkt_mll_wave.hip", "dkt_predict.hip"]
 HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"), os.path.join(INCLUDE, "dkt_abi.h")]
 
 _c_p = ctypes.c_void_p
@@ -56,7 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split() + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

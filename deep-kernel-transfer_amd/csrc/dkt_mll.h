@@ -31,5 +31,7 @@ constexpr float DKT_HALF_LOG_2PI = 0.91893853320467274178f;
 
 // Register-resident path: handles N + 1 <= 128.  Returns false when N is out of range.
 bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st);
+// Blocked path (panel sweep + MFMA trailing updates): N + 1 <= 128.
+bool dkt_mll_blk_launch(const MllArgs& a, hipStream_t st);
 // Wave-per-episode path (no barriers): N + 1 in (104, 112].  Returns false when N is out of range / disabled.
 bool dkt_mll_wave_launch(const MllArgs& a, hipStream_t st);

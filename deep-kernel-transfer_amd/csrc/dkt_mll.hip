@@ -212,6 +212,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_wave_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_blk_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (mll_fits_lds(N)) {
         const size_t lds = (mll_vec_floats(N) + mll_mat_floats(N)) * sizeof(float);

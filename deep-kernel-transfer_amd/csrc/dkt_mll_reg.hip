@@ -27,6 +27,19 @@ namespace {
 
 struct Masks { bool row_ok, col_ok, is_acol; };
 
+// Buffer addressing = one per-lane VGPR offset + a wave-uniform SGPR offset (no 64-bit per-element address
+// registers for the compiler to hoist out of the class loop).
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(brsrc r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(brsrc r, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
 constexpr int ULD = 24;   // LDS row stride (floats) of a 16-column chunk of U: 16 + 8 -> conflict-free b128 fragments
 
 template <int NT>
@@ -182,25 +195,35 @@ __device__ __forceinline__ void w_product_all(f32x4* acc, float (&A)[NT][NT], fl
     }
 }
 
-// store the accumulated tiles of one tile row (lower triangle + mirror)
-template <int ROW>
-__device__ __forceinline__ void w_store_row(const f32x4* acc, float* Wb, int N, int r16, int q) {
+// add the class's tiles of one tile row into W (lower triangle + mirror); first class stores
+template <int NT, int ROW>
+__device__ __forceinline__ void w_accum_row(const f32x4* acc, brsrc Wr, int N, int tyN, int r16, int q, int vo_rc, int vo_cr,
+                                            bool first) {
 #pragma unroll
     for (int tj = 0; tj <= ROW; ++tj) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int gi = ROW * 16 + 4 * q + reg, gj = tj * 16 + r16;
-            if (gi < N && gj < N && gj <= gi) {
-                const float v = acc[tj][reg];
-                Wb[(size_t)gi * N + gj] = v;
-                if (gi != gj) Wb[(size_t)gj * N + gi] = v;
+            const int pl = 4 * q + reg;
+            bool ok = true;
+            if (ROW == NT - 1) ok = ok && (pl < tyN);                    // gi < N
+            if (tj == NT - 1) ok = ok && (r16 < tyN);                    // gj < N
+            if (tj == ROW) ok = ok && (r16 <= pl);                       // lower triangle of the diagonal tile
+            if (ok) {
+                const int so = ((16 * ROW + reg) * N + 16 * tj) * 4;
+                float v = acc[tj][reg];
+                if (!first) v += bload(Wr, vo_rc, so);
+                bstore(Wr, v, vo_rc, so);
+                if (!(tj == ROW && r16 == pl)) bstore(Wr, v, vo_cr, (16 * tj * N + 16 * ROW + reg) * 4);
             }
         }
     }
 }
 
 template <int NT, bool WANT_GRAD, bool WANT_CHOL>
-__global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 2)) void mll_reg_kernel(MllArgs a) {
+#ifndef DKT_REG_MINW
+#define DKT_REG_MINW 4
+#endif
+__global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_REG_MINW : 2)) void mll_reg_kernel(MllArgs a) {
     constexpr int NP = 16 * NT;
     constexpr int MAXACC = NT + 1;                       // max tiles per wave
     __shared__ float colbuf[2 * NP];
@@ -216,7 +239,9 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
     const bool lower_eq = ty >= tx, upper_eq = tx >= ty;
     const bool row_ok = ty < tyN, is_w = ty == tyN;      // last block row: p < N / p == N
     const bool col_ok = tx < tyN, is_acol = tx == tyN;    // last block column: j < N / j == N
-    const float* Eb = a.E + (size_t)b * N * N;
+    const brsrc Er = make_rsrc(a.E + (size_t)b * N * N, N * N * 4);
+    const int vo_form = (ty * N + tx) * 4;               // per-lane part of element (ty + 16 pi, tx + 16 ji)
+    const int vo_rc = (4 * q * N + r16) * 4, vo_cr = (r16 * N + 4 * q) * 4;   // MFMA-layout (row 4q, col r16) and its mirror
     constexpr bool want_grad = WANT_GRAD;
     constexpr bool want_chol = WANT_CHOL;
 
@@ -225,14 +250,11 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
     RegCtx<NT> ctx;
     ctx.colbuf = colbuf; ctx.N = N; ctx.tx = tx; ctx.ty = ty; ctx.tid = tid; ctx.col_ok = col_ok;
 
-    f32x4 acc[MAXACC];
-#pragma unroll
-    for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bool poisoned = false;
 
     for (int c = 0; c < C; ++c) {
         const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
-        const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
+        const brsrc yr = make_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, N * 4);
         float A[NT][NT], rinvcol[NT];
         float log2sum = 0.f;
         int fail_at = 0;
@@ -248,21 +270,22 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
 #pragma unroll
                 for (int ji = 0; ji < NT; ++ji) {
                     // static block structure; only the last block row / column need per-thread masks
-                    const int p = ty + 16 * pi, j = tx + 16 * ji;
                     float v = 0.f;
                     if (pi >= ji) {
                         bool ld = true;                                    // lower-triangle element of K?
                         if (pi == ji) ld = lower_eq;
                         if (pi == NT - 1) ld = ld && row_ok;
                         if (ji == NT - 1) ld = ld && col_ok;
-                        if (ld) {
-                            v = svc * Eb[p * N + j];
-                            if (pi == ji && tx == ty) v += nzc + jit;
+                        {
+                            float x = svc * bload(Er, vo_form, (16 * pi * N + 16 * ji) * 4);   // out-of-range reads return 0
+                            if (pi == ji && tx == ty) x += nzc + jit;
+                            v = ld ? x : 0.f;
                         }
                         if (pi == NT - 1) {
                             bool lw = is_w;
                             if (ji == NT - 1) lw = lw && col_ok;
-                            if (lw) v = yc[j] - mc;
+                            const float yv = bload(yr, tx * 4, 16 * ji * 4) - mc;
+                            v = lw ? yv : v;
                         }
                     }
                     A[pi][ji] = v;
@@ -378,35 +401,42 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? 3 : 
             const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
             const float coef = 0.5f * cw * svc;
             // W += coef (alpha alpha^T - U U^T): alpha rides as column N of the chunked U matrix
+            // The class's contribution is accumulated into W[b] in memory (same lanes, same words, class after class:
+            // deterministic, no atomics) so that no accumulator registers stay live across the next class's sweep.
+            f32x4 acc[MAXACC];
+#pragma unroll
+            for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             w_product_all<NT, 0>(acc, A, ubuf, N, tx, ty, wave, r16, q, coef, alpha, masks);
+            const brsrc Wr = make_rsrc(a.W + (size_t)b * N * N, N * N * 4);
+            const bool first = (c == 0);
+            const int tyN16 = tyN;
+            switch (wave) {
+                case 0:
+                    if constexpr (RowsOf<NT, 0>::RA >= 0) w_accum_row<NT, RowsOf<NT, 0>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    if constexpr (RowsOf<NT, 0>::RB >= 0) w_accum_row<NT, RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    break;
+                case 1:
+                    if constexpr (RowsOf<NT, 1>::RA >= 0) w_accum_row<NT, RowsOf<NT, 1>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    if constexpr (RowsOf<NT, 1>::RB >= 0) w_accum_row<NT, RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    break;
+                case 2:
+                    if constexpr (RowsOf<NT, 2>::RA >= 0) w_accum_row<NT, RowsOf<NT, 2>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    if constexpr (RowsOf<NT, 2>::RB >= 0) w_accum_row<NT, RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    break;
+                default:
+                    if constexpr (RowsOf<NT, 3>::RA >= 0) w_accum_row<NT, RowsOf<NT, 3>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    if constexpr (RowsOf<NT, 3>::RB >= 0) w_accum_row<NT, RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
+                    break;
+            }
         }
         __syncthreads();
     }
 
     if constexpr (want_grad) {
-        float* Wb = a.W + (size_t)b * N * N;
         if (poisoned) {
+            float* Wb = a.W + (size_t)b * N * N;
             const float qnan = __int_as_float(0x7fc00000);
             for (int idx = tid; idx < N * N; idx += 256) Wb[idx] = qnan;
-        } else {
-            switch (wave) {
-                case 0:
-                    if constexpr (RowsOf<NT, 0>::RA >= 0) w_store_row<RowsOf<NT, 0>::RA>(acc, Wb, N, r16, q);
-                    if constexpr (RowsOf<NT, 0>::RB >= 0) w_store_row<RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Wb, N, r16, q);
-                    break;
-                case 1:
-                    if constexpr (RowsOf<NT, 1>::RA >= 0) w_store_row<RowsOf<NT, 1>::RA>(acc, Wb, N, r16, q);
-                    if constexpr (RowsOf<NT, 1>::RB >= 0) w_store_row<RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Wb, N, r16, q);
-                    break;
-                case 2:
-                    if constexpr (RowsOf<NT, 2>::RA >= 0) w_store_row<RowsOf<NT, 2>::RA>(acc, Wb, N, r16, q);
-                    if constexpr (RowsOf<NT, 2>::RB >= 0) w_store_row<RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Wb, N, r16, q);
-                    break;
-                default:
-                    if constexpr (RowsOf<NT, 3>::RA >= 0) w_store_row<RowsOf<NT, 3>::RA>(acc, Wb, N, r16, q);
-                    if constexpr (RowsOf<NT, 3>::RB >= 0) w_store_row<RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Wb, N, r16, q);
-                    break;
-            }
         }
     }
 }
