@@ -68,13 +68,13 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(const float* __restrict__ 
     auto gload = [&](int k0) {
         const int k = k0 + lc;
         float4 ref = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KIND == DKT_KERNEL_RBF) ref = load4_guard(Ab, k, D, true, vec_ok);
+        if (KIND != DKT_KERNEL_LINEAR) ref = load4_guard(Ab, k, D, true, vec_ok);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int rowa = m0 + lr + 32 * h;
             const bool oka = rowa < M;
             ra[h] = load4_guard(Ab + (size_t)rowa * D, k, D, oka, vec_ok);
-            if (KIND == DKT_KERNEL_RBF && oka) {
+            if (KIND != DKT_KERNEL_LINEAR && oka) {
                 if (k + 0 < D) ra[h].x -= ref.x;
                 if (k + 1 < D) ra[h].y -= ref.y;
                 if (k + 2 < D) ra[h].z -= ref.z;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(const float* __restrict__ 
                 const int rowb = n0 + lr + 32 * h;
                 const bool okb = rowb < N;
                 rb[h] = load4_guard(Bb + (size_t)rowb * D, k, D, okb, vec_ok);
-                if (KIND == DKT_KERNEL_RBF && okb) {
+                if (KIND != DKT_KERNEL_LINEAR && okb) {
                     if (k + 0 < D) rb[h].x -= ref.x;
                     if (k + 1 < D) rb[h].y -= ref.y;
                     if (k + 2 < D) rb[h].z -= ref.z;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(const float* __restrict__ 
     }
 
     float inv_l2 = 0.f;
-    if (KIND == DKT_KERNEL_RBF) {
+    if (KIND != DKT_KERNEL_LINEAR) {
         // reduce the per-thread partial norms over the 8 threads sharing a staging row
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(256) void gram_nt_kernel(const float* __restrict__ 
                 const int gm = m0 + lm, gn = n0 + ln;
                 if (gm >= M || gn >= N) continue;
                 float v = acc[fi][fj][reg];
-                if (KIND == DKT_KERNEL_RBF) {
+                if (KIND != DKT_KERNEL_LINEAR) {
                     float d2 = nrmA[lm] + nrmB[ln] - 2.0f * v;
                     d2 = d2 > 0.f ? d2 : 0.f;
                     if (SYM && gm == gn) d2 = 0.f;
-                    v = expf(-0.5f * d2 * inv_l2);
+                    v = (KIND == DKT_KERNEL_RBF) ? expf(-0.5f * d2 * inv_l2) : d2 * inv_l2;
                 }
                 if (SYM) {
                     if (diag && gn > gm) continue;  // keep the matrix exactly symmetric
@@ -310,13 +310,49 @@ __global__ __launch_bounds__(256) void rbf_bwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) dl[b] = tot / l;
 }
 
+// scaled squared distance U = d2 / l^2: chain rule.  A = Ws / l^2, Wp = diag(A 1) - A (dZ = 2 Wp Z),
+// dl = sum Ws U (-2 / l).
+__global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict__ W, const float* __restrict__ U,
+                                                         const float* __restrict__ lengthscale, float* __restrict__ Wp,
+                                                         float* __restrict__ dl, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Ub = U + (size_t)b * N * N;
+    float* Wpb = Wp + (size_t)b * N * N;
+    const float l = lengthscale[0];
+    const float inv_l2 = 1.0f / (l * l);
+    float dl_part = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float rowsum = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float ws = 0.5f * (Wb[(size_t)i * N + j] + Wb[(size_t)j * N + i]);
+            const float a = ws * inv_l2;
+            rowsum += a;
+            if (j != i) Wpb[(size_t)i * N + j] = -a;
+            dl_part += ws * Ub[(size_t)i * N + j];
+        }
+        Wpb[(size_t)i * N + i] = rowsum - Wb[(size_t)i * N + i] * inv_l2;
+    }
+    const float tot = block_sum_256(dl_part, red);
+    if (threadIdx.x == 0) dl[b] = -2.0f * tot / l;
+}
+
 }  // namespace
+
+extern "C" int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* lengthscale, float* Wp,
+                                  float* dlengthscale, int B, int N, void* stream) {
+    if (!W || !U || !lengthscale || !Wp || !dlengthscale || B <= 0 || N <= 0) return DKT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sqdist_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, W, U, lengthscale, Wp,
+                       dlengthscale, N);
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
 
 extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, int M, int N, int D, int kind,
                             const float* lengthscale, void* stream) {
     if (!A || !E || B <= 0 || M <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
-    if (kind != DKT_KERNEL_LINEAR && kind != DKT_KERNEL_RBF) return DKT_ERR_BAD_ARG;
-    if (kind == DKT_KERNEL_RBF && !lengthscale) return DKT_ERR_BAD_ARG;
+    if (kind != DKT_KERNEL_LINEAR && kind != DKT_KERNEL_RBF && kind != DKT_KERNEL_SQDIST) return DKT_ERR_BAD_ARG;
+    if (kind != DKT_KERNEL_LINEAR && !lengthscale) return DKT_ERR_BAD_ARG;
     const bool sym = (Bm == nullptr);
     if (sym && M != N) return DKT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -327,9 +363,12 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     if (kind == DKT_KERNEL_LINEAR) {
         if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_LINEAR, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
         else hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_LINEAR, false>), grid, block, 0, st, A, Bm, E, M, N, D, lengthscale);
-    } else {
+    } else if (kind == DKT_KERNEL_RBF) {
         if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_RBF, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
         else hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_RBF, false>), grid, block, 0, st, A, Bm, E, M, N, D, lengthscale);
+    } else {
+        if (sym) hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_SQDIST, true>), grid, block, 0, st, A, A, E, M, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_nt_kernel<DKT_KERNEL_SQDIST, false>), grid, block, 0, st, A, Bm, E, M, N, D, lengthscale);
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }

@@ -1,0 +1,59 @@
+"""Episodic loaders.  The reference's SetDataManager (data/datamgr.py:68-84) reads JSON file lists of image
+datasets through torchvision; neither the datasets nor torchvision exist here (data/ is
+out of scope), so the drivers run on a SYNTHETIC episodic source with the same output contract:
+an iterable of length n_episode yielding (x, y) with x: float32 [n_way, n_support + n_query, 3, H, W] on the CPU
+and y: [n_way, n_support + n_query] global class ids, classes drawn by torch.randperm(n_classes)[:n_way]
+(EpisodicBatchSampler, data/dataset.py:76-87)."""
+from __future__ import annotations
+
+import torch
+
+
+class SyntheticEpisodeLoader:
+    """Class-structured random images: every class owns a fixed low-frequency prototype; a sample is the
+    prototype under a random gain plus pixel noise, so a backbone can actually learn to separate classes.
+    `class_offset` shifts the class pool so base / val / novel splits are disjoint."""
+
+    def __init__(self, n_way, n_support, n_query, n_episode=100, image_size=84, n_classes=64, class_offset=0,
+                 seed=0, noise=0.6):
+        self.n_way, self.per = n_way, n_support + n_query
+        self.n_episode, self.hw = n_episode, image_size
+        self.n_classes, self.class_offset, self.noise = n_classes, class_offset, noise
+        self.gen = torch.Generator().manual_seed(1000 + seed)
+        self._proto_cache = {}
+
+    def __len__(self):
+        return self.n_episode
+
+    def _prototype(self, cls):
+        p = self._proto_cache.get(cls)
+        if p is None:
+            g = torch.Generator().manual_seed(7919 * (cls + self.class_offset) + 13)
+            low = torch.rand(3, 7, 7, generator=g)
+            p = torch.nn.functional.interpolate(low[None], size=(self.hw, self.hw), mode='bilinear', align_corners=False)[0]
+            self._proto_cache[cls] = p
+        return p
+
+    def __iter__(self):
+        for _ in range(self.n_episode):
+            classes = torch.randperm(self.n_classes, generator=self.gen)[:self.n_way]
+            xs, ys = [], []
+            for c in classes.tolist():
+                proto = self._prototype(c)
+                gain = 0.7 + 0.6 * torch.rand(self.per, 1, 1, 1, generator=self.gen)
+                x = gain * proto[None] + self.noise * torch.randn(self.per, 3, self.hw, self.hw, generator=self.gen)
+                xs.append(x.clamp(0.0, 1.5))
+                ys.append(torch.full((self.per,), c + self.class_offset, dtype=torch.long))
+            yield torch.stack(xs), torch.stack(ys)
+
+
+def get_episode_loader(params, split, n_way, n_support, n_query, n_episode, image_size, seed=0):
+    """split in {'base', 'val', 'novel'}.  Real datasets need the reference's filelists + torchvision."""
+    if params.dataset != 'synthetic':
+        raise NotImplementedError(
+            "dataset '%s': the image datasets of the reference (filelists/, torchvision transforms) are not part of "
+            "this build; use --dataset synthetic" % params.dataset)
+    offsets = {'base': 0, 'val': 64, 'novel': 96}
+    sizes = {'base': 64, 'val': 32, 'novel': 40}
+    return SyntheticEpisodeLoader(n_way, n_support, n_query, n_episode, image_size, n_classes=max(sizes[split], n_way),
+                                  class_offset=offsets[split], seed=seed + {'base': 0, 'val': 1, 'novel': 2}[split])

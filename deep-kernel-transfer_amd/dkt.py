@@ -144,7 +144,7 @@ class DKT(MetaTemplate):
         if self.kernel_type in LINEAR_KINDS:
             obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zb, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
         else:
-            e = ops.base_matrix(zb, self.kernel_type, self.model.lengthscale)
+            e = ops.base_matrix(zb, self.kernel_type, self.model.lengthscale, self.model.offset)
             obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
         aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
         return obj.mean(), aux
@@ -152,13 +152,14 @@ class DKT(MetaTemplate):
     def _posterior(self, z_cond, y, z_star, e_cond=None):
         """Mean cache on the conditioning set, posterior means [C,M] and labels [M] at z_star."""
         sv, mean, noise = self._hypers()
-        kind = ops.kind_id(self.kernel_type)
-        ls = self.model.lengthscale
+        ls, off = self.model.lengthscale, self.model.offset
+        ls = None if ls is None else ls.detach()
+        off = None if off is None else off.detach()
         zc = z_cond.detach().unsqueeze(0)
-        if e_cond is None or kind == ops.KERNEL_RBF:
-            e_cond = ops.gram(zc, None, kind, ls)
+        if e_cond is None or self.kernel_type not in LINEAR_KINDS:      # E depends on post-step hyper-parameters
+            e_cond = ops.kernel_matrix(zc, None, self.kernel_type, ls, off)
         out = ops.mll(e_cond, y, sv.detach(), mean.detach(), noise.detach(), jitter0=self.jitter0, max_tries=self.max_tries)
-        ex = ops.gram(z_star.detach().unsqueeze(0), zc, kind, ls)
+        ex = ops.kernel_matrix(z_star.detach().unsqueeze(0), zc, self.kernel_type, ls, off)
         mu, labels = ops.predict(ex, out["alpha"], sv.detach(), mean.detach())
         return mu[0], labels[0], out
 

@@ -6,7 +6,8 @@ methods/DKT_regression.py:25-37, 112-129):
   * ConstantMean            -> `mean_constant` [C], init 0, learned
   * ScaleKernel             -> `raw_outputscale` [C], outputscale = softplus(raw), init raw 0 -> ln 2
   * LinearKernel.variance   -> `raw_variance` [1]; cossim/bncossim: variance = 1.0 and frozen (DKT.py:366-370)
-  * RBFKernel.lengthscale   -> `raw_lengthscale` [1], lengthscale = softplus(raw), init ln 2
+  * RBFKernel / MaternKernel(nu=2.5).lengthscale -> `raw_lengthscale` [1], lengthscale = softplus(raw), init ln 2
+  * PolynomialKernel.offset -> `raw_offset` [1] (poli1, poli2), offset = softplus(raw), init ln 2
   * GaussianLikelihood      -> `raw_noise` [C], noise = softplus(raw) + 1e-4 (GreaterThan(1e-4));
                                classification: noise forced to 0.1 and frozen (DKT.py:346-347);
                                regression: learned, init softplus(0) + 1e-4.
@@ -26,7 +27,9 @@ import torch.nn.functional as F
 NOISE_LOWER_BOUND = 1e-4
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
-SUPPORTED_CLASSIFICATION = LINEAR_KINDS + RBF_KINDS
+MATERN_KINDS = ("matern",)
+POLY_KINDS = ("poli1", "poli2")
+SUPPORTED_CLASSIFICATION = LINEAR_KINDS + RBF_KINDS + MATERN_KINDS + POLY_KINDS
 
 
 def inv_softplus(y: float) -> float:
@@ -49,10 +52,14 @@ class ExactGPHypers(nn.Module):
             self.raw_variance = nn.Parameter(torch.zeros(1))
         else:
             self.register_parameter("raw_variance", None)
-        if kernel in RBF_KINDS:
+        if kernel in RBF_KINDS + MATERN_KINDS:
             self.raw_lengthscale = nn.Parameter(torch.zeros(1))
         else:
             self.register_parameter("raw_lengthscale", None)
+        if kernel in POLY_KINDS:          # PolynomialKernel.offset = softplus(raw_offset), init raw 0
+            self.raw_offset = nn.Parameter(torch.zeros(1))
+        else:
+            self.register_parameter("raw_offset", None)
         if fixed_noise is not None:
             raw = inv_softplus(fixed_noise - NOISE_LOWER_BOUND)
             self.raw_noise = nn.Parameter(torch.full((n_models,), raw), requires_grad=False)
@@ -71,6 +78,10 @@ class ExactGPHypers(nn.Module):
     @property
     def lengthscale(self) -> Optional[torch.Tensor]:
         return None if self.raw_lengthscale is None else F.softplus(self.raw_lengthscale)
+
+    @property
+    def offset(self) -> Optional[torch.Tensor]:
+        return None if self.raw_offset is None else F.softplus(self.raw_offset)
 
     @property
     def noise(self) -> torch.Tensor:

@@ -21,12 +21,15 @@ from . import _lib
 
 KERNEL_LINEAR = 0
 KERNEL_RBF = 1
+KERNEL_SQDIST = 2
 MLL_WANT_GRAD = 1
 MLL_WANT_CHOL = 2
 MLL_FORCE_GENERIC = 4
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
+MATERN_KINDS = ("matern",)
+POLY_KINDS = {"poli1": 1, "poli2": 2}
 
 
 def kind_id(kernel: str) -> int:
@@ -107,7 +110,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
         n = bm.shape[1]
     else:
         n = m
-    if kind == KERNEL_RBF:
+    if kind != KERNEL_LINEAR:
         lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
     e = torch.empty((b_, m, n), device=a.device, dtype=torch.float32)
     lib = _lib.load()
@@ -200,6 +203,38 @@ def rbf_bwd(w: torch.Tensor, e: torch.Tensor, lengthscale: torch.Tensor):
     return wp, dl
 
 
+def sqdist_bwd(w: torch.Tensor, u: torch.Tensor, lengthscale: torch.Tensor):
+    w = _req(w, "w", 3)
+    u = _req(u, "u", 3)
+    lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
+    b_, n, _ = u.shape
+    wp = torch.empty_like(u)
+    dl = torch.empty((b_,), device=u.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dkt_sqdist_bwd_f32(_p(w), _p(u), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream()), "dkt_sqdist_bwd_f32")
+    return wp, dl
+
+
+def _matern25(u: torch.Tensor) -> torch.Tensor:
+    """MaternKernel(nu=2.5) from the scaled squared distance (gpytorch clamps d2 >= 1e-30 before the sqrt)."""
+    r = torch.sqrt(5.0 * u.clamp_min(1e-30))
+    return (1.0 + r + r * r / 3.0) * torch.exp(-r)
+
+
+def kernel_matrix(a: torch.Tensor, bm: Optional[torch.Tensor], kernel: str, lengthscale: Optional[torch.Tensor] = None,
+                  offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Base kernel matrix k(a, bm) (no autograd): all kernel types of ExactGPLayer (reference DKT.py:352-370)."""
+    if kernel in LINEAR_KINDS:
+        return gram(a, bm, KERNEL_LINEAR)
+    if kernel in RBF_KINDS:
+        return gram(a, bm, KERNEL_RBF, lengthscale)
+    if kernel in MATERN_KINDS:
+        return _matern25(gram(a, bm, KERNEL_SQDIST, lengthscale))
+    if kernel in POLY_KINDS:
+        return (gram(a, bm, KERNEL_LINEAR) + offset.reshape(())) ** POLY_KINDS[kernel]
+    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
+
+
 def predict(ex: torch.Tensor, alpha: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, want_labels: bool = True):
     """mu[b,c,q] = mean[c] + sv[c] sum_n ex[b,q,n] alpha[b,c,n]; labels[b,q] = argmax_c mu."""
     ex = _req(ex, "ex", 3)
@@ -259,8 +294,33 @@ class _BaseMatrixFn(torch.autograd.Function):
         return (dz if ctx.needs_input_grad[0] else None), dl, None
 
 
-def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable symmetric base kernel matrix E[B,N,N] of z[B,N,D]."""
+class _SqDistFn(torch.autograd.Function):
+    """U[b] = |z_i - z_j|^2 / l^2 (differentiable in z and l): the building block of the Matern kernel."""
+
+    @staticmethod
+    def forward(ctx, z, lengthscale):
+        u = gram(z, None, KERNEL_SQDIST, lengthscale)
+        ctx.save_for_backward(z, u, lengthscale)
+        return u
+
+    @staticmethod
+    def backward(ctx, gu):
+        z, u, lengthscale = ctx.saved_tensors
+        wp, dlb = sqdist_bwd(gu.contiguous(), u, lengthscale)
+        dz = gram_bwd(wp, z) if ctx.needs_input_grad[0] else None
+        dl = dlb.sum().reshape(lengthscale.shape) if ctx.needs_input_grad[1] else None
+        return dz, dl
+
+
+def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None,
+                offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable symmetric base kernel matrix E[B,N,N] of z[B,N,D] for every kernel type of the reference's
+    ExactGPLayer (DKT.py:352-370): linear / cossim / bncossim, rbf, matern (nu = 2.5), poli1, poli2."""
+    if kernel in MATERN_KINDS:
+        return _matern25(_SqDistFn.apply(z, lengthscale))
+    if kernel in POLY_KINDS:
+        g = _BaseMatrixFn.apply(z, torch.zeros(1, device=z.device, dtype=torch.float32), KERNEL_LINEAR)
+        return (g + offset.reshape(())) ** POLY_KINDS[kernel]
     kind = kind_id(kernel)
     if kind == KERNEL_RBF and lengthscale is None:
         raise RuntimeError("rbf needs a lengthscale tensor")

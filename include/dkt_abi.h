@@ -40,6 +40,7 @@ extern "C" {
 /* base-kernel kinds (configs.py:7 kernel_type; DKT.py:352-370) */
 #define DKT_KERNEL_LINEAR 0 /* linear / cossim / bncossim : E = A B^T                       */
 #define DKT_KERNEL_RBF 1    /* rbf : E = exp(-0.5 |a-b|^2 / l^2), centred norm expansion    */
+#define DKT_KERNEL_SQDIST 2 /* U = |a-b|^2 / l^2 (clamped >= 0): building block of matern   */
 
 /* mll flags */
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
@@ -56,7 +57,7 @@ int dkt_device_cu_count(void);
  * dkt_gram_f32 -- base kernel matrix of one or many episodes.
  *   E[b] = k(A[b], Bm[b])  with A:[B,M,D], Bm:[B,N,D] -> E:[B,M,N].
  *   Bm == NULL: symmetric Gram of A with itself (M == N, only lower tiles computed, mirrored).
- *   kind = DKT_KERNEL_LINEAR | DKT_KERNEL_RBF; `lengthscale` (device, 1 float) used by RBF only.
+ *   kind = DKT_KERNEL_LINEAR | DKT_KERNEL_RBF | DKT_KERNEL_SQDIST; `lengthscale` (device, 1 float) unused by LINEAR.
  * Replaces: ExactGPLayer.forward -> covar_module(x) (methods/DKT.py:375-378,
  *   methods/DKT_regression.py:126-129), i.e. GPyTorch LinearKernel / RBFKernel evaluation,
  *   evaluated once per episode instead of once per class model (DKT.py:148-149,161).
@@ -113,6 +114,14 @@ int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, in
  */
 int dkt_rbf_bwd_f32(const float* W, const float* E, const float* lengthscale, float* Wp,
                     float* dlengthscale, int B, int N, void* stream);
+
+/*
+ * dkt_sqdist_bwd_f32 -- chain rule of U = |z_i - z_j|^2 / l^2 (DKT_KERNEL_SQDIST; MaternKernel, DKT.py:358-359):
+ *   with Ws = 0.5 (W + W^T) (W = d obj / d U):  Wp = diag(A 1) - A, A = Ws / l^2  (dZ = dkt_gram_bwd_f32(Wp, Z)),
+ *   dlengthscale[b] = -(2 / l) sum_ij Ws_ij U_ij.
+ */
+int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* lengthscale, float* Wp,
+                       float* dlengthscale, int B, int N, void* stream);
 
 /*
  * dkt_predict_f32 -- posterior mean of the C models at M test points and the arg-max label.

@@ -37,6 +37,17 @@ def base_matrix(za, zb, kernel, lengthscale=None):
         b = (zb_ - adj) / lengthscale
         d2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
         return torch.exp(-0.5 * d2.clamp_min(0.0))
+    if kernel == "matern":       # MaternKernel(nu=2.5): sqrt(clamp(d2, 1e-30)) as gpytorch does
+        zb_ = za if zb is None else zb
+        adj = za.mean(0, keepdim=True)
+        a = (za - adj) / lengthscale
+        b = (zb_ - adj) / lengthscale
+        d2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        r = math.sqrt(5.0) * torch.sqrt(d2.clamp_min(1e-30))
+        return (1.0 + r + r * r / 3.0) * torch.exp(-r)
+    if kernel in ("poli1", "poli2"):     # PolynomialKernel: the offset rides in the `lengthscale` argument
+        g = za @ (za if zb is None else zb).T
+        return (g + lengthscale) ** (1 if kernel == "poli1" else 2)
     raise ValueError(kernel)
 
 

@@ -1,0 +1,74 @@
+"""CPU checks of the driver-side pieces that mirror the reference's io_utils / data contracts."""
+import os
+
+import numpy as np
+import torch
+
+import dkt_amd
+from dkt_amd.data import SyntheticEpisodeLoader, get_episode_loader
+from dkt_amd.io_utils import (checkpoint_dir_for, default_image_size, get_assigned_file, get_best_file,
+                              get_resume_file, parse_args)
+
+
+def test_parse_args_defaults_match_reference_flags():
+    p = parse_args('train', [])
+    assert (p.seed, p.method, p.train_n_way, p.test_n_way, p.n_shot, p.save_freq, p.start_epoch, p.stop_epoch) == \
+        (0, 'DKT', 5, 5, 5, 50, 0, -1)
+    assert not p.resume and not p.warmup and not p.train_aug
+    t = parse_args('test', ['--repeat', '2', '--split', 'val'])
+    assert (t.repeat, t.split, t.save_iter, t.adaptation) == (2, 'val', -1, False)
+    assert default_image_size('Conv4', 'CUB') == 84 and default_image_size('Conv4S', 'omniglot') == 28
+    assert default_image_size('ResNet10', 'miniImagenet') == 224
+
+
+def test_checkpoint_path_helpers(tmp_path):
+    p = parse_args('train', ['--model', 'Conv4', '--train_aug'])
+    d = checkpoint_dir_for(p, str(tmp_path))
+    assert d.endswith('checkpoints/synthetic/Conv4_DKT_aug_5way_5shot')
+    os.makedirs(d)
+    assert get_resume_file(d) is None and get_best_file(d) is None
+    for e in (0, 50, 7):
+        torch.save({'epoch': e, 'state': {}}, get_assigned_file(d, e))
+    assert get_resume_file(d).endswith('50.tar')
+    assert get_best_file(d).endswith('50.tar')             # falls back to the latest epoch
+    torch.save({'epoch': 3, 'state': {}}, os.path.join(d, 'best_model.tar'))
+    assert get_best_file(d).endswith('best_model.tar') and get_resume_file(d).endswith('50.tar')
+
+
+def test_synthetic_episode_loader_contract():
+    ld = SyntheticEpisodeLoader(5, 5, 16, n_episode=3, image_size=28, n_classes=20, seed=1)
+    assert len(ld) == 3
+    eps = list(ld)
+    assert len(eps) == 3
+    x, y = eps[0]
+    assert x.shape == (5, 21, 3, 28, 28) and x.dtype == torch.float32 and y.shape == (5, 21)
+    assert len(set(y[:, 0].tolist())) == 5 and (y == y[:, :1]).all()       # class-major rows, distinct classes
+    # same class -> same prototype: within-class distance < between-class distance
+    m = x.mean(1)
+    within = (x[0] - m[0]).pow(2).mean()
+    between = (m[0] - m[1]).pow(2).mean() + within
+    assert between > within
+    # deterministic per seed, disjoint class pools per split
+    x2, y2 = next(iter(SyntheticEpisodeLoader(5, 5, 16, n_episode=3, image_size=28, n_classes=20, seed=1)))
+    assert torch.equal(x, x2) and torch.equal(y, y2)
+    p = parse_args('train', [])
+    yb = next(iter(get_episode_loader(p, 'base', 5, 1, 1, 1, 28)))[1]
+    yn = next(iter(get_episode_loader(p, 'novel', 5, 1, 1, 1, 28)))[1]
+    assert yb.max() < 64 <= 96 <= yn.min()
+
+
+def test_ece_loss_on_known_distribution():
+    import test_uncertainty as tu
+    ece = tu.ECELoss(n_bins=10)
+    # perfectly confident and always right -> ECE 0; perfectly confident and always wrong -> ECE 1
+    logits = torch.tensor([[50.0, 0.0], [0.0, 50.0]]).repeat(10, 1)
+    labels = torch.tensor([0, 1]).repeat(10)
+    assert ece(logits, labels).item() < 1e-6
+    assert abs(ece(logits, 1 - labels).item() - 1.0) < 1e-6
+    # temperature calibration lowers the NLL of over-confident logits
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(400, 5, generator=g) * 8.0
+    y = torch.where(torch.rand(400, generator=g) < 0.6, z.argmax(1), torch.randint(0, 5, (400,), generator=g))
+    t = ece.calibrate(z, y)
+    nll = torch.nn.CrossEntropyLoss()
+    assert nll(z * t, y) < nll(z, y) and 0.0 < t.item() < 1.0

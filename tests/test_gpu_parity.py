@@ -415,6 +415,51 @@ def test_dkt_train_step_matches_float64_autograd(cuda):
     assert checked >= 18
 
 
+@pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2", "linear", "cossim"])
+def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
+    """configs.kernel_type values of the reference's ExactGPLayer (DKT.py:352-370): loss, gradients w.r.t. every
+    parameter (backbone, outputscale, mean, lengthscale / offset / variance) and predictions vs the float64 restatement."""
+    import copy
+    torch.manual_seed(1)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type=kernel).to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
+        m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+        if m.model.raw_lengthscale is not None:
+            m.model.raw_lengthscale.fill_(8.0)      # un-normalised Conv4S features: distances ~ 8
+        if m.model.raw_offset is not None:
+            m.model.raw_offset.fill_(0.3)
+        if kernel == "linear":
+            m.model.raw_variance.fill_(-0.4)
+    ref = copy.deepcopy(m).cpu().double()
+    x = torch.rand(5, 12, 3, 28, 28, generator=torch.Generator().manual_seed(2))
+    x_all = x.view(60, 3, 28, 28)
+    m.train()
+    z = m._embed(x_all.to(cuda))
+    loss, aux = m._episode_loss(z, m._targets(5, 12, cuda))
+    loss.backward()
+    assert int(aux["info"].abs().max().item()) == 0
+    ref.train()
+    zr = ref._embed(x_all.double())
+    extra = ref.model.lengthscale if ref.model.raw_lengthscale is not None else ref.model.offset
+    var = ref.model.variance if ref.model.raw_variance is not None else 1.0
+    loss_r, _, alpha_r = T.classification_loss(zr, 5, ref.model.outputscale, ref.model.mean, ref.model.noise,
+                                               kernel if kernel != "cossim" else "linear", extra, variance=var)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None, name
+            continue
+        diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+        assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+    # prediction through the same kernel (cross matrix)
+    m.eval()
+    m.n_query = 7
+    logits = m.get_logits(x)
+    assert logits.shape == (35, 5) and torch.isfinite(logits).all()
+
+
 def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
     torch.manual_seed(0)
     m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5).to(cuda)
@@ -476,3 +521,28 @@ def test_dkt_regression_surface(cuda):
     m.train_loop(0, opt, batch, labels)
     mse = m.test_loop(5, inputs=batch, targets=labels)
     assert mse.dim() == 0 and torch.isfinite(mse)
+
+
+def test_drivers_end_to_end(cuda, tmp_path, monkeypatch, capsys):
+    """train.py -> checkpoint -> test.py (results line) -> test_uncertainty.py on synthetic episodes."""
+    import importlib
+    monkeypatch.chdir(tmp_path)
+    train = importlib.import_module("train")
+    test = importlib.import_module("test")
+    tu = importlib.import_module("test_uncertainty")
+    common = ["--model", "Conv4S", "--image_size", "28", "--n_episode", "6", "--seed", "3"]
+    train.main(common + ["--stop_epoch", "2", "--save_freq", "1"])
+    ckpt = tmp_path / "save" / "checkpoints" / "synthetic" / "Conv4S_DKT_5way_5shot"
+    assert (ckpt / "best_model.tar").exists() and (ckpt / "1.tar").exists()
+    state = torch.load(ckpt / "1.tar", map_location="cpu")
+    assert state["epoch"] == 1 and "feature.trunk.0.C.weight" in state["state"] and "model.raw_outputscale" in state["state"]
+    train.main(common + ["--stop_epoch", "3", "--save_freq", "1", "--resume"])       # resumes at epoch 2
+    assert (ckpt / "2.tar").exists()
+    accs = test.main(common + ["--repeat", "2"])
+    assert len(accs) == 2 and all(0.0 <= a <= 100.0 for a in accs)
+    line = (tmp_path / "record" / "results.txt").read_text().strip().splitlines()[-1]
+    assert "Setting: synthetic-novel-Conv4S-DKT 5shot 5way_train 5way_test" in line and "Test Acc" in line
+    eces = tu.main(common + ["--repeat", "1"])
+    assert len(eces) == 1 and 0.0 <= eces[0] <= 1.0
+    out = capsys.readouterr().out
+    assert "Epoch [0] [0/6]" in out and "Overall Test Acc" in out and "Overall ECE" in out
