@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void rbf_bwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) dl[b] = tot / l;
 }
 
-// scaled squared distance U = d2 / l^2: chain rule.  A = Ws / l^2, Wp = diag(A 1) - A (dZ = 2 Wp Z),
-// dl = sum Ws U (-2 / l).
+// scaled squared distance U = d2 / l^2: chain rule.  dU_ij = (2 / l^2)(z_i - z_j).(dz_i - dz_j), so with
+// A = 2 Ws / l^2 and Wp = diag(A 1) - A the gradient is dZ = 2 Wp Z (= dkt_gram_bwd_f32(Wp, Z));  dl = sum Ws U (-2 / l).
 __global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict__ W, const float* __restrict__ U,
                                                          const float* __restrict__ lengthscale, float* __restrict__ Wp,
                                                          float* __restrict__ dl, int N) {
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict
         float rowsum = 0.f;
         for (int j = 0; j < N; ++j) {
             const float ws = 0.5f * (Wb[(size_t)i * N + j] + Wb[(size_t)j * N + i]);
-            const float a = ws * inv_l2;
+            const float a = 2.0f * ws * inv_l2;
             rowsum += a;
             if (j != i) Wpb[(size_t)i * N + j] = -a;
             dl_part += ws * Ub[(size_t)i * N + j];
         }
-        Wpb[(size_t)i * N + i] = rowsum - Wb[(size_t)i * N + i] * inv_l2;
+        Wpb[(size_t)i * N + i] = rowsum - 2.0f * Wb[(size_t)i * N + i] * inv_l2;
     }
     const float tot = block_sum_256(dl_part, red);
     if (threadIdx.x == 0) dl[b] = -2.0f * tot / l;

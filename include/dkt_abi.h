@@ -117,7 +117,7 @@ int dkt_rbf_bwd_f32(const float* W, const float* E, const float* lengthscale, fl
 
 /*
  * dkt_sqdist_bwd_f32 -- chain rule of U = |z_i - z_j|^2 / l^2 (DKT_KERNEL_SQDIST; MaternKernel, DKT.py:358-359):
- *   with Ws = 0.5 (W + W^T) (W = d obj / d U):  Wp = diag(A 1) - A, A = Ws / l^2  (dZ = dkt_gram_bwd_f32(Wp, Z)),
+ *   with Ws = 0.5 (W + W^T) (W = d obj / d U):  Wp = diag(A 1) - A, A = 2 Ws / l^2  (dZ = dkt_gram_bwd_f32(Wp, Z)),
  *   dlengthscale[b] = -(2 / l) sum_ij Ws_ij U_ij.
  */
 int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* lengthscale, float* Wp,
