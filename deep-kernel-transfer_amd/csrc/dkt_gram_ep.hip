@@ -135,6 +135,162 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// gram_sym_ep_bf16x3_kernel<NT>: the same episode-resident symmetric Gram on the bf16 MFMA pipe.
+// Every fp32 feature is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 significand bits) while it is
+// staged into LDS (v_cvt_pk_bf16_f32 + subtract, three bf16 planes), and each fp32 product is rebuilt from the six
+// leading cross terms  hh + hm + mh + hl + lh + mm  with v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The dropped
+// terms (ml, lm, ll) are <= 2^-23 relative per product -- the size of one fp32 rounding -- so the result is
+// fp32-faithful, while the MFMA time per 32-wide K slice drops from 8 x 32 to 6 x ~17 cycles per tile: the kernel
+// leaves the fp32-MFMA roof (157 TF) and becomes HBM-bound.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hi = (__bf16)x[i];
+        const float r1 = x[i] - (float)hi;
+        const __bf16 mi = (__bf16)r1;
+        const float r2 = r1 - (float)mi;
+        h[i] = hi;
+        m[i] = mi;
+        l[i] = (__bf16)r2;
+    }
+}
+
+constexpr int SPLD = 48;   // bf16 per LDS row of a plane: 32 data + 16 pad (96 B; (96/16) mod 16 = 6: conflict-free b128 fragments)
+
+template <int NT, int RA, int RB>
+__device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* zp, int r16, int q) {
+    constexpr int PLANE = 16 * NT * SPLD;
+    const __bf16* base = zp + r16 * SPLD + 8 * q;
+    auto frag = [&](int plane, int blk) { return *reinterpret_cast<const bf16x8*>(base + plane * PLANE + blk * 16 * SPLD); };
+    auto tile = [&](f32x4& c, const bf16x8& ah, const bf16x8& am, const bf16x8& al, int tj) {
+        const bf16x8 bh = frag(0, tj), bm = frag(1, tj), bl = frag(2, tj);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);     // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    };
+    {
+        const bf16x8 ah = frag(0, RA), am = frag(1, RA), al = frag(2, RA);
+#pragma unroll
+        for (int tj = 0; tj <= RA; ++tj) tile(acc[tj], ah, am, al, tj);
+    }
+    if constexpr (RB >= 0) {
+        const bf16x8 ah = frag(0, RB), am = frag(1, RB), al = frag(2, RB);
+#pragma unroll
+        for (int tj = 0; tj <= RB; ++tj) tile(acc[RA + 1 + tj], ah, am, al, tj);
+    }
+}
+
+// NBUF = LDS stage buffers (2: one barrier per stage, 2 workgroups/CU; 1: two barriers, 4 workgroups/CU);
+// PF   = global-load run-ahead in stages (register sets): PF stages x 14 KB per workgroup stay in flight.
+template <int NT, int NBUF, int PF>
+__global__ __launch_bounds__(256) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
+    constexpr int NP = 16 * NT;
+    constexpr int BK = 32;
+    constexpr int V4_PER_ROW = BK / 4;
+    constexpr int NV4 = NP * V4_PER_ROW;
+    constexpr int NLD = (NV4 + 255) / 256;
+    constexpr int PLANE = NP * SPLD;
+    __shared__ __attribute__((aligned(16))) __bf16 zp[NBUF][3 * PLANE];
+
+    const int b = blockIdx.x;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* Eb = E + (size_t)b * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+
+    auto gload = [&](float4 (&rg)[NLD], int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
+            const int k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((NV4 % 256 == 0 || idx < NV4) && row < N && k < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)row * D + k);
+            rg[i] = v;
+        }
+    };
+    auto lstore = [&](const float4 (&rg)[NLD], int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
+            if (NV4 % 256 == 0 || idx < NV4) {
+                bf16x4 h, m, l;
+                split3(rg[i], h, m, l);
+                __bf16* dst = &zp[buf][row * SPLD + 4 * c4];
+                *reinterpret_cast<bf16x4*>(dst) = h;
+                *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+            }
+        }
+    };
+
+    f32x4 acc[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        if (wave == 0) {
+            if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB>(acc, zp[buf], r16, q);
+        } else if (wave == 1) {
+            if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB>(acc, zp[buf], r16, q);
+        } else if (wave == 2) {
+            if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB>(acc, zp[buf], r16, q);
+        } else {
+            if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB>(acc, zp[buf], r16, q);
+        }
+    };
+
+    const int nk = (D + BK - 1) / BK;
+    float4 r0[NLD], r1[NLD];
+    // stage kt: LDS holds slice kt, `rnear` holds slice kt+1 (PF = 2) or is loaded now (PF = 1), `rfar` is issued for kt+2
+    auto stage = [&](float4 (&rnear)[NLD], float4 (&rfar)[NLD], int kt) {
+        const int buf = (NBUF == 2) ? (kt & 1) : 0;
+        if constexpr (PF == 2) {
+            if (kt + 2 < nk) gload(rfar, (kt + 2) * BK);
+        } else {
+            if (kt + 1 < nk) gload(rnear, (kt + 1) * BK);
+        }
+        compute(buf);
+        if constexpr (NBUF == 1) __syncthreads();
+        if (kt + 1 < nk) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        __syncthreads();
+    };
+    gload(r0, 0);
+    if constexpr (PF == 2) {
+        if (nk > 1) gload(r1, BK);
+    }
+    lstore(r0, 0);
+    __syncthreads();
+    if constexpr (PF == 2) {
+        for (int kt = 0; kt < nk; kt += 2) {
+            stage(r1, r0, kt);
+            if (kt + 1 < nk) stage(r0, r1, kt + 1);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) stage(r0, r1, kt);
+    }
+    if (wave == 0) {
+        if constexpr (RowsOf<NT, 0>::RA >= 0) sym_store_row<RowsOf<NT, 0>::RA>(acc, Eb, N, r16, q);
+        if constexpr (RowsOf<NT, 0>::RB >= 0) sym_store_row<RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Eb, N, r16, q);
+    } else if (wave == 1) {
+        if constexpr (RowsOf<NT, 1>::RA >= 0) sym_store_row<RowsOf<NT, 1>::RA>(acc, Eb, N, r16, q);
+        if constexpr (RowsOf<NT, 1>::RB >= 0) sym_store_row<RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Eb, N, r16, q);
+    } else if (wave == 2) {
+        if constexpr (RowsOf<NT, 2>::RA >= 0) sym_store_row<RowsOf<NT, 2>::RA>(acc, Eb, N, r16, q);
+        if constexpr (RowsOf<NT, 2>::RB >= 0) sym_store_row<RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Eb, N, r16, q);
+    } else {
+        if constexpr (RowsOf<NT, 3>::RA >= 0) sym_store_row<RowsOf<NT, 3>::RA>(acc, Eb, N, r16, q);
+        if constexpr (RowsOf<NT, 3>::RB >= 0) sym_store_row<RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Eb, N, r16, q);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dZ = s (W + W^T) Z.  The workgroup has NT waves; wave w owns output row block w (16 rows) for every
 // column of the slab, keeps its NT A-fragments of s (W + W^T) in registers for the whole episode, and all
 // waves share the Z slab in LDS -- perfectly balanced MFMA work, BD/16 float4 staging loads per thread.
@@ -232,21 +388,172 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_kernel(const float* __res
     }
 }
 
-template <int NT>
-void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream_t st) {
-    if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-    else hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+// ---------------------------------------------------------------------------------------------
+// gram_bwd_ep_bf16x3_kernel<NT>: dZ = s (W + W^T) Z on the bf16 MFMA pipe with the same exact 3-way split.
+// The contraction index j is the SLOW index of Z in memory, so the Z slab is transposed while it is staged:
+// a thread loads a 4(j) x 4(d) fp32 block (4 float4, 256-B coalesced rows), splits it, and writes, per d and per
+// plane, the 4 consecutive-j bf16 as one 8-byte LDS store into a [d][j] image -- one ds_read_b128 then yields a
+// lane's 8 consecutive-j B-operand values.  LDS row of feature d = 4 r + t is 16 t + r: tile t of the slab holds
+// the 16 features {4 r + t}, which makes (i) the 8-byte stores of a wave cover 2 full bank rows (the minimum),
+// (ii) the fragment reads conflict-free (row stride == 2 mod 4 sixteen-byte units) and (iii) the epilogue a
+// float4 store per accumulator register (tiles t = 0..3 of one lane are 4 consecutive d).
+// Wave w owns output rows [16 w, 16 w + 16) and keeps its A fragments (3 planes of s (W + W^T), K padded to a
+// multiple of 32) in registers for the whole episode.
+__device__ __forceinline__ void split3s(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
 }
 
 template <int NT>
-void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, hipStream_t st) {
-    if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
-    else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+__global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+                                                                     float* __restrict__ dZ, int N, int D,
+                                                                     const float* __restrict__ ep_scale) {
+    constexpr int NP = 16 * NT;
+    constexpr int NTH = 64 * NT;
+    constexpr int BD = 64;                               // features per slab: one 4x4 staging block per thread
+    constexpr int KS = (NP + 31) / 32;                   // k32 slices
+    constexpr int KP = 32 * KS;
+    constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);   // 16-B units per LDS row, == 2 mod 4
+    constexpr int RS = 8 * SU;                           // bf16 per LDS row
+    constexpr int PLANE = BD * RS;
+    static_assert(SU % 4 == 2 && RS >= KP, "LDS row stride");
+    __shared__ __attribute__((aligned(16))) __bf16 zt[2][3 * PLANE];
+
+    const int b = blockIdx.x;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* dZb = dZ + (size_t)b * N * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const float s = ep_scale ? ep_scale[b] : 1.0f;
+
+    // zero the whole image once: columns j in [NP, KP) are never staged and must not hold NaN bit patterns
+    for (int i = tid; i < 2 * 3 * PLANE / 8; i += NTH) reinterpret_cast<float4*>(&zt[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // A fragments: slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e
+    bf16x8 ah[KS], am[KS], al[KS];
+    {
+        const int row = wave * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * q + e;
+                float v = 0.f;
+                if (row < N && k < N) v = s * (Wb[row * N + k] + Wb[k * N + row]);
+                __bf16 h, m, l;
+                split3s(v, h, m, l);
+                ah[ks][e] = h;
+                am[ks][e] = m;
+                al[ks][e] = l;
+            }
+        }
+    }
+
+    const int d4 = tid & 15, jg = tid >> 4;              // staging block: rows 4 jg .. 4 jg + 3, features 4 d4 .. 4 d4 + 3
+    auto gload = [&](float4 (&rg)[4], int d0) {
+        const int d = d0 + 4 * d4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int j = 4 * jg + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < N && d < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)j * D + d);
+            rg[rr] = v;
+        }
+    };
+    auto lstore = [&](const float4 (&rg)[4], int buf) {
+        const float x[4][4] = {{rg[0].x, rg[1].x, rg[2].x, rg[3].x}, {rg[0].y, rg[1].y, rg[2].y, rg[3].y},
+                               {rg[0].z, rg[1].z, rg[2].z, rg[3].z}, {rg[0].w, rg[1].w, rg[2].w, rg[3].w}};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                __bf16 hh, mm, ll;
+                split3s(x[t][rr], hh, mm, ll);
+                h[rr] = hh;
+                m[rr] = mm;
+                l[rr] = ll;
+            }
+            __bf16* dst = &zt[buf][(16 * t + d4) * RS + 4 * jg];
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+        }
+    };
+    auto compute_store = [&](int buf, int d0) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const __bf16* base = &zt[buf][r16 * RS + 8 * q];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const __bf16* p = base + 16 * t * RS + 32 * ks;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(p);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(p + PLANE);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(p + 2 * PLANE);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[t], 0, 0, 0);
+            }
+        }
+        const int d = d0 + 4 * r16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = wave * 16 + 4 * q + reg;
+            if (row < N && d < D)
+                *reinterpret_cast<float4*>(dZb + (size_t)row * D + d) = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+        }
+    };
+
+    const int nslab = (D + BD - 1) / BD;
+    float4 r0[4], r1[4];
+    auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
+        const int buf = sl & 1;
+        if (sl + 2 < nslab) gload(rfar, (sl + 2) * BD);
+        compute_store(buf, sl * BD);
+        if (sl + 1 < nslab) lstore(rnear, buf ^ 1);
+        __syncthreads();
+    };
+    gload(r0, 0);
+    if (nslab > 1) gload(r1, BD);
+    __syncthreads();                                     // zero fill done
+    lstore(r0, 0);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; sl += 2) {
+        stage(r1, r0, sl);
+        if (sl + 1 < nslab) stage(r0, r1, sl + 1);
+    }
 }
 
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
+}
+
+template <int NT>
+void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream_t st) {
+    if (bk == 3) {
+        const int v = env_int("DKT_GRAM_SPLIT_VAR", 12);      // <LDS buffers><prefetch depth>
+        if (v == 21) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 11) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+    } else if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+    else hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+}
+
+template <int NT>
+void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, hipStream_t st) {
+    if (bd == 3) hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+    else if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+    else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
 }
 
 }  // namespace
@@ -255,7 +562,8 @@ int env_int(const char* name, int dflt) {
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipStream_t st) {
     if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
     if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
-    const int bk = env_int("DKT_GRAM_EP_BK", 64);
+    // DKT_GRAM_SPLIT=1 (default): 3-way bf16 split on the bf16 MFMA pipe; 0: exact-fp32 MFMA (BK from DKT_GRAM_EP_BK)
+    const int bk = env_int("DKT_GRAM_SPLIT", 1) ? 3 : env_int("DKT_GRAM_EP_BK", 64);
     switch ((N + 15) / 16) {
         case 5: launch_sym<5>(Z, E, B, N, D, bk, st); return true;
         case 6: launch_sym<6>(Z, E, B, N, D, bk, st); return true;
@@ -268,7 +576,8 @@ bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipSt
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
     if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
     if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
-    const int bd = env_int("DKT_GRAM_EP_BD", 32);
+    // the split kernel pays a per-episode setup (A-fragment split, LDS zero fill): it wins from ~16 slabs of 64 features
+    const int bd = (env_int("DKT_GRAM_SPLIT", 1) && D >= env_int("DKT_GRAM_BWD_SPLIT_MIND", 1024)) ? 3 : env_int("DKT_GRAM_EP_BD", 32);
     switch ((N + 15) / 16) {
         case 5: launch_bwd<5>(W, Z, dZ, B, N, D, sc, bd, st); return true;
         case 6: launch_bwd<6>(W, Z, dZ, B, N, D, sc, bd, st); return true;

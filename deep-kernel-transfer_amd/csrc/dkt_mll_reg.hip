@@ -29,6 +29,7 @@ struct Masks { bool row_ok, col_ok, is_acol; };
 
 // Buffer addressing = one per-lane VGPR offset + a wave-uniform SGPR offset (no 64-bit per-element address
 // registers for the compiler to hoist out of the class loop).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t brsrc;
 __device__ __forceinline__ brsrc make_rsrc(const void* p, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -54,62 +55,99 @@ struct RegCtx {
 // Columns are scaled LAZILY: the registers keep the raw column and rinvcol[ji] remembers 1/L_kk of the
 // thread's column k = tx + 16 ji (applied once after the sweep) -- one v_cndmask per step instead of NT.
 // Structural masks are folded into copies of the row factor so every block update is a single v_fma.
+// Element (pi, ji) of the register matrix.  Rows are held in PAIRS (pi = 2m, 2m + 1) so that the rank-1 update runs
+// on v_pk_fma_f32: the row-factor pair comes straight out of one ds_read2_b32, the column factor is broadcast.
+#define AE(pi, ji) A2[(pi) >> 1][ji][(pi) & 1]
+
 template <int NT, int KQ>
-__device__ __forceinline__ int sweep_block(float (&A)[NT][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
+__device__ __forceinline__ int sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
     constexpr int NP = 16 * NT;
+    constexpr int NP2 = (NT + 1) / 2;
     const int kend = min(16, c.N - 16 * KQ);
     const int tx = c.tx, ty = c.ty;
     const bool lower_eq = ty >= tx;
+    int fail = 0;
+    // Diagonal blocks below the pivot block are updated in BOTH triangles (no per-step mask); the strictly-upper
+    // half then holds Schur-complement values nobody reads, and is cleared here, when the block becomes the pivot
+    // block and its upper half starts to collect U.
+    if constexpr (KQ > 0) AE(KQ, KQ) = lower_eq ? AE(KQ, KQ) : 0.f;
+    // Software pipeline: a step's critical path is  barrier -> one LDS round trip -> rsq -> the updates of block
+    // column KQ -> publish of the next pivot column;  the other (NT - KQ - 1) block columns are updated after the
+    // publish, off the path.  The pivot-sign test is deferred to the end of the block column (uniform).
+    if (tx == 0) {
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) c.colbuf[ty + 16 * pi] = AE(pi, KQ);
+    }
     for (int kr = 0; kr < kend; ++kr) {
         const int k = 16 * KQ + kr;
-        float* cb = c.colbuf + (kr & 1) * NP;
-        if (tx == kr) {
-#pragma unroll
-            for (int pi = 0; pi < NT; ++pi) cb[ty + 16 * pi] = A[pi][KQ];
-        }
+        const float* cb = c.colbuf + (kr & 1) * NP;
         __syncthreads();
         const float d = cb[k];
-        if (!(d > 0.f)) return k + 1;
+        f32x2 cp2[NP2];
+        float cj[NT];
+#pragma unroll
+        for (int m = 0; m < NP2; ++m) {
+            cp2[m][0] = cb[ty + 32 * m];
+            cp2[m][1] = (2 * m + 1 < NT) ? cb[ty + 32 * m + 16] : 0.f;
+        }
+#pragma unroll
+        for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji];
         const float rinv = __builtin_amdgcn_rsqf(d);
-        log2sum += __builtin_amdgcn_logf(d);            // v_log_f32 = log2
-        float cp[NT], cj[NT];
+        const float nrd = -rinv * rinv;                  // -1 / d
+        // row factor -(column / d); the column factor stays raw (product = L_pk L_jk)
 #pragma unroll
-        for (int pi = 0; pi < NT; ++pi) cp[pi] = cb[ty + 16 * pi] * rinv;
-        cp[KQ] = (ty == kr) ? rinv : cp[KQ];            // row k itself: U_kk = 1 / L_kk
-#pragma unroll
-        for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji] * rinv;
+        for (int m = 0; m < NP2; ++m) cp2[m] *= nrd;
+        const float cpK = (ty == kr) ? nrd : cp2[KQ >> 1][KQ & 1];   // row k itself seeds U_kj = -L_jk / d
         cj[KQ] = (tx > kr) ? cj[KQ] : 0.f;              // only columns j > k are updated
         cj[NT - 1] = c.col_ok ? cj[NT - 1] : 0.f;       // padding columns j >= N
         const bool row_le_k = ty <= kr;
-        const float cpk_le = row_le_k ? cp[KQ] : 0.f;                  // row block KQ, ji > KQ: p <= k only
-        const float cpk_dd = (row_le_k || lower_eq) ? cp[KQ] : 0.f;    // block (KQ, KQ): p <= k or p >= j
+        const float cpk_le = row_le_k ? cpK : 0.f;                     // row block KQ, ji > KQ: p <= k only
+        const float cpk_dd = (row_le_k || lower_eq) ? cpK : 0.f;       // block (KQ, KQ): p <= k or p >= j
+        // update of block column ji: rows pi < KQ (U part) and pi >= ji (L part) plain, row block KQ masked,
+        // KQ < pi < ji (k < p < j) untouched
+        auto column = [&](const int ji) {                              // ji is an unrolled constant
+            const f32x2 cjv = {cj[ji], cj[ji]};
+            const float sK = (ji == KQ) ? cpk_dd : cpk_le;
 #pragma unroll
-        for (int ji = KQ; ji < NT; ++ji) {
-#pragma unroll
-            for (int pi = 0; pi < NT; ++pi) {
-                if (pi < KQ) {                                         // U part, p <= k
-                    A[pi][ji] = __builtin_fmaf(-cp[pi], cj[ji], A[pi][ji]);
-                } else if (pi == KQ) {
-                    A[pi][ji] = __builtin_fmaf(-(ji == KQ ? cpk_dd : cpk_le), cj[ji], A[pi][ji]);
-                } else if (pi > ji) {                                  // L part strictly below the block diagonal
-                    A[pi][ji] = __builtin_fmaf(-cp[pi], cj[ji], A[pi][ji]);
-                } else if (pi == ji) {                                 // L part on the block diagonal: p >= j
-                    A[pi][ji] = __builtin_fmaf(-(lower_eq ? cp[pi] : 0.f), cj[ji], A[pi][ji]);
-                }                                                      // KQ < pi < ji : k < p < j, untouched
+            for (int m = 0; m < NP2; ++m) {
+                const int p0 = 2 * m, p1 = 2 * m + 1;
+                // 0 none, 1 plain, 2 row block KQ
+                const int k0 = (p0 < KQ) ? 1 : (p0 == KQ) ? 2 : (p0 < ji) ? 0 : 1;
+                const int k1 = (p1 >= NT) ? 0 : (p1 < KQ) ? 1 : (p1 == KQ) ? 2 : (p1 < ji) ? 0 : 1;
+                if (k0 == 1 && k1 == 1) {
+                    A2[m][ji] = __builtin_elementwise_fma(cp2[m], cjv, A2[m][ji]);
+                } else if (k0 != 0 && k1 != 0) {
+                    const f32x2 v = {k0 == 2 ? sK : cp2[m][0], k1 == 2 ? sK : cp2[m][1]};
+                    A2[m][ji] = __builtin_elementwise_fma(v, cjv, A2[m][ji]);
+                } else if (k0 != 0) {
+                    A2[m][ji][0] = __builtin_fmaf(k0 == 2 ? sK : cp2[m][0], cj[ji], A2[m][ji][0]);
+                } else if (k1 != 0) {
+                    A2[m][ji][1] = __builtin_fmaf(k1 == 2 ? sK : cp2[m][1], cj[ji], A2[m][ji][1]);
+                }
             }
+        };
+        column(KQ);
+        if (kr + 1 < kend && tx == kr + 1) {
+            float* nb = c.colbuf + ((kr + 1) & 1) * NP;
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
         }
+#pragma unroll
+        for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
+        log2sum += __builtin_amdgcn_logf(d);            // v_log_f32 = log2
         rinvcol[KQ] = (tx == kr) ? rinv : rinvcol[KQ];
+        fail = (fail == 0 && !(d > 0.f)) ? k + 1 : fail;
     }
-    return 0;
+    return fail;
 }
 
 template <int NT, int KQ>
-__device__ __forceinline__ int sweep_all(float (&A)[NT][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
+__device__ __forceinline__ int sweep_all(f32x2 (&A2)[(NT + 1) / 2][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
     if constexpr (KQ < NT) {
         if (16 * KQ >= c.N) return 0;
-        const int f = sweep_block<NT, KQ>(A, rinvcol, log2sum, c);
+        const int f = sweep_block<NT, KQ>(A2, rinvcol, log2sum, c);
         if (f) return f;
-        return sweep_all<NT, KQ + 1>(A, rinvcol, log2sum, c);
+        return sweep_all<NT, KQ + 1>(A2, rinvcol, log2sum, c);
     } else {
         return 0;
     }
@@ -163,7 +201,7 @@ __device__ __forceinline__ void w_chunk_mfma(f32x4* acc, const float* ub, int r1
 // All chunks of the product for one class: every thread writes its share of the 16-column chunk CH of
 // [U | alpha] to LDS (one barrier per chunk, double buffered), then each wave accumulates its own tile rows.
 template <int NT, int CH>
-__device__ __forceinline__ void w_product_all(f32x4* acc, float (&A)[NT][NT], float* ubuf, int N, int tx, int ty,
+__device__ __forceinline__ void w_product_all(f32x4* acc, f32x2 (&A2)[(NT + 1) / 2][NT], float* ubuf, int N, int tx, int ty,
                                               int wave, int r16, int q, float coef, const float (&alpha)[NT], const Masks& m) {
     if constexpr (CH < NT) {
         constexpr int NP = 16 * NT;
@@ -172,8 +210,8 @@ __device__ __forceinline__ void w_product_all(f32x4* acc, float (&A)[NT][NT], fl
         for (int pi = 0; pi < NT; ++pi) {
             const int p = ty + 16 * pi;
             float v = 0.f;
-            if (CH > pi) v = A[pi][CH];                               // U block
-            else if (CH == pi) v = (tx >= ty) ? A[pi][CH] : 0.f;      // diagonal block: upper incl. diagonal
+            if (CH > pi) v = AE(pi, CH);                               // U block
+            else if (CH == pi) v = (tx >= ty) ? AE(pi, CH) : 0.f;      // diagonal block: upper incl. diagonal
             if (CH == NT - 1) {
                 v = m.col_ok ? v : 0.f;                               // columns >= N are not U
                 v = m.is_acol ? alpha[pi] : v;                        // column N carries alpha
@@ -191,7 +229,7 @@ __device__ __forceinline__ void w_product_all(f32x4* acc, float (&A)[NT][NT], fl
         } else {
             if constexpr (RowsOf<NT, 3>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, CH>(acc, ub, r16, q, coef, N);
         }
-        w_product_all<NT, CH + 1>(acc, A, ubuf, N, tx, ty, wave, r16, q, coef, alpha, m);
+        w_product_all<NT, CH + 1>(acc, A2, ubuf, N, tx, ty, wave, r16, q, coef, alpha, m);
     }
 }
 
@@ -255,7 +293,8 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
     for (int c = 0; c < C; ++c) {
         const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
         const brsrc yr = make_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, N * 4);
-        float A[NT][NT], rinvcol[NT];
+        f32x2 A2[(NT + 1) / 2][NT];
+        float rinvcol[NT];
         float log2sum = 0.f;
         int fail_at = 0;
         float jit = 0.f;
@@ -288,14 +327,14 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
                             v = lw ? yv : v;
                         }
                     }
-                    A[pi][ji] = v;
+                    AE(pi, ji) = v;
                 }
             }
             __syncthreads();          // previous users of colbuf are done
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) rinvcol[ji] = 1.0f;
             log2sum = 0.f;
-            fail_at = sweep_all<NT, 0>(A, rinvcol, log2sum, ctx);
+            fail_at = sweep_all<NT, 0>(A2, rinvcol, log2sum, ctx);
             if (fail_at == 0) break;
         }
         const size_t bc = (size_t)b * C + c;
@@ -319,18 +358,18 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
         for (int pi = 0; pi < NT; ++pi) {
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) {
-                A[pi][ji] *= rinvcol[ji];
+                AE(pi, ji) *= rinvcol[ji];
                 if (pi == ji) {
                     bool dg = tx == ty;
                     if (pi == NT - 1) dg = dg && col_ok;           // the (N, N) corner and beyond are padding, not pivots
-                    A[pi][ji] = dg ? rinvcol[ji] : A[pi][ji];
+                    AE(pi, ji) = dg ? rinvcol[ji] : AE(pi, ji);
                 }
             }
         }
         // ---- w row -> LDS; scalars ----
         if (ty == tyN) {
 #pragma unroll
-            for (int ji = 0; ji < NT; ++ji) wv[tx + 16 * ji] = A[NT - 1][ji];
+            for (int ji = 0; ji < NT; ++ji) wv[tx + 16 * ji] = AE(NT - 1, ji);
         }
         __syncthreads();
         float wj[NT];
@@ -348,7 +387,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
             float s = 0.f, u2 = 0.f;
 #pragma unroll
             for (int ji = pi; ji < NT; ++ji) {
-                float u = A[pi][ji];
+                float u = AE(pi, ji);
                 if (ji == pi) u = upper_eq ? u : 0.f;              // strictly-lower entries of the diagonal block are L
                 if (ji == NT - 1) u = col_ok ? u : 0.f;            // padding / alpha slot
                 s += u * wj[ji];
@@ -390,8 +429,8 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
                     if (ji == NT - 1) ok = ok && col_ok;
                     if (ok) {
                         float v = 0.f;
-                        if (pi > ji) v = A[pi][ji];
-                        else if (pi == ji) v = (ty > tx) ? A[pi][ji] : ((ty == tx) ? 1.0f / rinvcol[ji] : 0.f);
+                        if (pi > ji) v = AE(pi, ji);
+                        else if (pi == ji) v = (ty > tx) ? AE(pi, ji) : ((ty == tx) ? 1.0f / rinvcol[ji] : 0.f);
                         Lb[p * N + j] = v;
                     }
                 }
@@ -406,7 +445,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
             f32x4 acc[MAXACC];
 #pragma unroll
             for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            w_product_all<NT, 0>(acc, A, ubuf, N, tx, ty, wave, r16, q, coef, alpha, masks);
+            w_product_all<NT, 0>(acc, A2, ubuf, N, tx, ty, wave, r16, q, coef, alpha, masks);
             const brsrc Wr = make_rsrc(a.W + (size_t)b * N * N, N * N * 4);
             const bool first = (c == 0);
             const int tyN16 = tyN;
