@@ -42,7 +42,14 @@ _lock = threading.Lock()
 _lib = None
 
 
+def _lib_path() -> str:
+    """DKT_AMD_LIB points the loader at an alternative build of the same ABI (A/B measurements of kernel variants)."""
+    return os.environ.get("DKT_AMD_LIB") or LIB_PATH
+
+
 def needs_build() -> bool:
+    if os.environ.get("DKT_AMD_LIB"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
@@ -50,22 +57,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = None, replace: dict = None) -> str:
     """hipcc --offload-arch=gfx950 -> deep-kernel-transfer_amd/libdkt_hip.so (in-tree).
-    Cross-compiles without a GPU."""
-    if not force and not needs_build():
+    Cross-compiles without a GPU.  `out` / `replace` ({source name: other path}) build a variant library for A/B runs."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
+    target = out or LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [(replace or {}).get(s, os.path.join(CSRC, s)) for s in SOURCES]
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           "-I", INCLUDE] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE, "-I", CSRC] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split() + srcs + ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 def load() -> ctypes.CDLL:
@@ -74,11 +82,12 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
+        path = _lib_path()
+        if not os.path.exists(path):
             raise RuntimeError(
                 "libdkt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "-- the DKT hot path has no CPU fallback." % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
+                "-- the DKT hot path has no CPU fallback." % path)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(lib, name)

@@ -190,7 +190,7 @@ __device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* 
 // NBUF = LDS stage buffers (2: one barrier per stage, 2 workgroups/CU; 1: two barriers, 4 workgroups/CU);
 // PF   = global-load run-ahead in stages (register sets): PF stages x 14 KB per workgroup stay in flight.
 template <int NT, int NBUF, int PF>
-__global__ __launch_bounds__(256) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
+__global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
     constexpr int NP = 16 * NT;
     constexpr int BK = 32;
     constexpr int V4_PER_ROW = BK / 4;
@@ -204,15 +204,25 @@ __global__ __launch_bounds__(256) void gram_sym_ep_bf16x3_kernel(const float* __
     float* Eb = E + (size_t)b * N * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
 
+    // Buffer loads: one 32-bit per-lane byte offset per staged float4 (rows >= N get an out-of-range offset and read
+    // as 0 through the descriptor's bounds check), the slice offset k0 rides in the SGPR operand -- no 64-bit address
+    // arithmetic and no exec-mask juggling in the steady state; only a ragged last slice (D % 32 != 0) tests k < D.
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    int voff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
+        voff[i] = ((NV4 % 256 == 0 || idx < NV4) && row < N) ? (row * D + 4 * c4) * 4 : 0x7ffffff0;
+    }
     auto gload = [&](float4 (&rg)[NLD], int k0) {
+        const bool ragged = k0 + BK > D;                 // uniform
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
-            const int k = k0 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((NV4 % 256 == 0 || idx < NV4) && row < N && k < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)row * D + k);
-            rg[i] = v;
+            int vo = voff[i];
+            if (ragged) vo = (k0 + 4 * ((tid + 256 * i) % V4_PER_ROW) < D) ? vo : 0x7ffffff0;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, vo, k0 * 4, 0);
+            rg[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
     auto lstore = [&](const float4 (&rg)[NLD], int buf) {
@@ -428,29 +438,6 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
     const float s = ep_scale ? ep_scale[b] : 1.0f;
 
-    // zero the whole image once: columns j in [NP, KP) are never staged and must not hold NaN bit patterns
-    for (int i = tid; i < 2 * 3 * PLANE / 8; i += NTH) reinterpret_cast<float4*>(&zt[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // A fragments: slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e
-    bf16x8 ah[KS], am[KS], al[KS];
-    {
-        const int row = wave * 16 + r16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 32 * ks + 8 * q + e;
-                float v = 0.f;
-                if (row < N && k < N) v = s * (Wb[row * N + k] + Wb[k * N + row]);
-                __bf16 h, m, l;
-                split3s(v, h, m, l);
-                ah[ks][e] = h;
-                am[ks][e] = m;
-                al[ks][e] = l;
-            }
-        }
-    }
-
     const int d4 = tid & 15, jg = tid >> 4;              // staging block: rows 4 jg .. 4 jg + 3, features 4 d4 .. 4 d4 + 3
     auto gload = [&](float4 (&rg)[4], int d0) {
         const int d = d0 + 4 * d4;
@@ -462,6 +449,48 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
             rg[rr] = v;
         }
     };
+    const int nslab = (D + BD - 1) / BD;
+    float4 r0[4], r1[4];
+    gload(r0, 0);                                        // the first two slabs fly while W is staged and split
+    if (nslab > 1) gload(r1, BD);
+
+    // A fragments: slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e.  W[b] (N x N fp32, 44 KB) is first
+    // copied into the (still unused) staging LDS with coalesced loads, so the row AND the column access of
+    // s (W + W^T) are LDS reads instead of 2 x 8 KS scattered global loads per lane.
+    bf16x8 ah[KS], am[KS], al[KS];
+    {
+        float* wl = reinterpret_cast<float*>(&zt[0][0]);
+        static_assert(sizeof(zt) >= NP * NP * 4, "W does not fit the staging buffers");
+        const int nn = N * N;
+        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        __syncthreads();
+        const int row = wave * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * q + e;
+                float v = 0.f;
+                if (row < N && k < N) v = s * (wl[row * N + k] + wl[k * N + row]);
+                __bf16 h, m, l;
+                split3s(v, h, m, l);
+                ah[ks][e] = h;
+                am[ks][e] = m;
+                al[ks][e] = l;
+            }
+        }
+        __syncthreads();
+    }
+    // columns j in [NP, KP) of the [d][j] image are never staged: zero them once (NaN bit patterns would poison 0 * x)
+    if constexpr (KP > NP) {
+        constexpr int PADV = (KP - NP) / 8;              // 16-byte pieces per row
+        for (int i = tid; i < 2 * 3 * BD * PADV; i += NTH) {
+            const int rowi = i / PADV, pc = i % PADV;    // rowi enumerates (buffer, plane, d)
+            __bf16* dst = &zt[0][0] + (size_t)rowi * RS + NP + 8 * pc;
+            *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     auto lstore = [&](const float4 (&rg)[4], int buf) {
         const float x[4][4] = {{rg[0].x, rg[1].x, rg[2].x, rg[3].x}, {rg[0].y, rg[1].y, rg[2].y, rg[3].y},
                                {rg[0].z, rg[1].z, rg[2].z, rg[3].z}, {rg[0].w, rg[1].w, rg[2].w, rg[3].w}};
@@ -512,8 +541,6 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
         }
     };
 
-    const int nslab = (D + BD - 1) / BD;
-    float4 r0[4], r1[4];
     auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
         const int buf = sl & 1;
         if (sl + 2 < nslab) gload(rfar, (sl + 2) * BD);
@@ -521,9 +548,7 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
         if (sl + 1 < nslab) lstore(rnear, buf ^ 1);
         __syncthreads();
     };
-    gload(r0, 0);
-    if (nslab > 1) gload(r1, BD);
-    __syncthreads();                                     // zero fill done
+    __syncthreads();                                     // pad columns zeroed
     lstore(r0, 0);
     __syncthreads();
     for (int sl = 0; sl < nslab; sl += 2) {
@@ -540,11 +565,11 @@ int env_int(const char* name, int dflt) {
 template <int NT>
 void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream_t st) {
     if (bk == 3) {
-        const int v = env_int("DKT_GRAM_SPLIT_VAR", 12);      // <LDS buffers><prefetch depth>
+        const int v = env_int("DKT_GRAM_SPLIT_VAR", 11);      // <LDS buffers><prefetch depth>
         if (v == 21) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 11) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 12) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
     } else if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
     else hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
 }

@@ -5,16 +5,19 @@
 // dkt_mll.hip (L below the diagonal, U = L^-T above it, w = L^-1 r in row N) never touches LDS: it is
 // distributed 2-D cyclically over the 16 x 16 thread grid,
 //       thread (ty, tx) owns  Mw[ty + 16*pi][tx + 16*ji],  pi, ji in [0, NT),  NT = ceil((N+1)/16),
-// i.e. NT*NT registers per lane (49 for N = 105).  A sweep step costs ONE barrier: the 16 owners of
-// column k publish it (raw) to a double-buffered LDS vector, every thread reads the pivot, takes
-// v_rsq_f32, reads its NT row and NT column entries and does its (statically classified) share of the
-// rank-1 update.  The block column index KQ = k / 16 is a template parameter, so every register index is
-// static and blocks that are structurally untouched (ji < KQ, or KQ < pi < ji) cost nothing.
+// i.e. NT*NT registers per lane (49 for N = 105), rows held in pairs (pi = 2m, 2m+1) so the rank-1 update runs on
+// v_pk_fma_f32.  A sweep step costs ONE barrier and ONE LDS round trip: the 16 owners of column k publish it (raw) to a
+// double-buffered LDS vector; every thread reads the pivot and its NT row / NT column entries, takes v_rcp_f32, updates
+// block column KQ first, the owners of column k+1 publish it at once, and the remaining block columns are updated off
+// the critical path.  KQ = k / 16 is a template parameter, so every register index is static and blocks that are
+// structurally untouched (ji < KQ, or KQ < pi < ji) cost nothing.  Columns stay unscaled during the sweep; pivots,
+// column scales 1 / L_kk, log det and the first non-positive pivot are all read off the diagonal slots afterwards.
 //
-// Gradient: K^-1 = U U^T is a Gram matrix of the rows of U, so W = sum_c coef_c (alpha alpha^T - K_c^-1)
-// is accumulated over the classes IN MFMA ACCUMULATORS (v_mfma_f32_16x16x4_f32; U goes through LDS one
-// 16-column chunk at a time, alpha rides along as column N) and written once.  The per-class hyper
-// gradients need only scalars:  tr K^-1 = |U|_F^2,  alpha.alpha,  1.alpha,  r.alpha:
+// Gradient: K^-1 = U U^T is a Gram matrix of the rows of U.  Per class, U goes through LDS one 16-column chunk at a
+// time and each wave accumulates its tile rows of U U^T on v_mfma_f32_16x16x4_f32 (four per-wave instantiations, each
+// accumulator first touched when its row block becomes non-zero); the epilogue forms coef_c (alpha alpha^T - U U^T)
+// with alpha from LDS and adds it into W[b] in memory, class after class (same lane, same word: deterministic).
+// The per-class hyper gradients need only scalars:  tr K^-1 = |U|_F^2,  alpha.alpha,  1.alpha,  r.alpha:
 //     dnoise = 0.5 (alpha.alpha - tr K^-1)
 //     dsv    = 0.5 ((r.alpha - N) - (noise + jitter) (alpha.alpha - tr K^-1)) / sv      [sv E = K - (noise+jitter) I]
 //
@@ -50,106 +53,104 @@ struct RegCtx {
     bool col_ok;
 };
 
-// One block column KQ of the sweep: k = 16*KQ + kr, kr = 0 .. min(16, N - 16*KQ) - 1.
-// Returns 0 or (k+1) of the first non-positive pivot (block-uniform).
-// Columns are scaled LAZILY: the registers keep the raw column and rinvcol[ji] remembers 1/L_kk of the
-// thread's column k = tx + 16 ji (applied once after the sweep) -- one v_cndmask per step instead of NT.
-// Structural masks are folded into copies of the row factor so every block update is a single v_fma.
 // Element (pi, ji) of the register matrix.  Rows are held in PAIRS (pi = 2m, 2m + 1) so that the rank-1 update runs
 // on v_pk_fma_f32: the row-factor pair comes straight out of one ds_read2_b32, the column factor is broadcast.
 #define AE(pi, ji) A2[(pi) >> 1][ji][(pi) & 1]
 
-template <int NT, int KQ>
-__device__ __forceinline__ int sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
+// One pivot step; PAR = kr & 1 is static so both LDS buffers have compile-time addresses.
+template <int NT, int KQ, int PAR>
+__device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c, const int kr, const int kend,
+                                           const bool lower_eq) {
     constexpr int NP = 16 * NT;
     constexpr int NP2 = (NT + 1) / 2;
+    const int tx = c.tx, ty = c.ty;
+    const float* cb = c.colbuf + PAR * NP;
+    __syncthreads();
+    const float d = cb[16 * KQ + kr];
+    f32x2 cp2[NP2];
+    float cj[NT];
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) {
+        cp2[m][0] = cb[ty + 32 * m];
+        cp2[m][1] = (2 * m + 1 < NT) ? cb[ty + 32 * m + 16] : 0.f;
+    }
+#pragma unroll
+    for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji];
+    const float nrd = -__builtin_amdgcn_rcpf(d);                      // -1 / d
+    // row factor -(column / d); the column factor stays raw (product = L_pk L_jk)
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) cp2[m] *= nrd;
+    const float cpK = (ty == kr) ? nrd : cp2[KQ >> 1][KQ & 1];        // row k itself seeds U_kj = -L_jk / d
+    cj[KQ] = (tx > kr) ? cj[KQ] : 0.f;                                // only columns j > k are updated
+    cj[NT - 1] = c.col_ok ? cj[NT - 1] : 0.f;                         // padding columns j >= N
+    const bool row_le_k = ty <= kr;
+    const float cpk_le = row_le_k ? cpK : 0.f;                        // row block KQ, ji > KQ: p <= k only
+    const float cpk_dd = (row_le_k || lower_eq) ? cpK : 0.f;          // block (KQ, KQ): p <= k or p >= j
+    // update of block column ji: rows pi < KQ (U part) and pi >= ji (L part) plain, row block KQ masked,
+    // KQ < pi < ji (k < p < j) untouched
+    auto column = [&](const int ji) {                                 // ji is an unrolled constant
+        const f32x2 cjv = {cj[ji], cj[ji]};
+        const float sK = (ji == KQ) ? cpk_dd : cpk_le;
+#pragma unroll
+        for (int m = 0; m < NP2; ++m) {
+            const int p0 = 2 * m, p1 = 2 * m + 1;
+            // 0 none, 1 plain, 2 row block KQ
+            const int k0 = (p0 < KQ) ? 1 : (p0 == KQ) ? 2 : (p0 < ji) ? 0 : 1;
+            const int k1 = (p1 >= NT) ? 0 : (p1 < KQ) ? 1 : (p1 == KQ) ? 2 : (p1 < ji) ? 0 : 1;
+            if (k0 == 1 && k1 == 1) {
+                A2[m][ji] = __builtin_elementwise_fma(cp2[m], cjv, A2[m][ji]);
+            } else if (k0 != 0 && k1 != 0) {
+                const f32x2 v = {k0 == 2 ? sK : cp2[m][0], k1 == 2 ? sK : cp2[m][1]};
+                A2[m][ji] = __builtin_elementwise_fma(v, cjv, A2[m][ji]);
+            } else if (k0 != 0) {
+                A2[m][ji][0] = __builtin_fmaf(k0 == 2 ? sK : cp2[m][0], cj[ji], A2[m][ji][0]);
+            } else if (k1 != 0) {
+                A2[m][ji][1] = __builtin_fmaf(k1 == 2 ? sK : cp2[m][1], cj[ji], A2[m][ji][1]);
+            }
+        }
+    };
+    column(KQ);
+    if (kr + 1 < kend && tx == kr + 1) {
+        float* nb = c.colbuf + (PAR ^ 1) * NP;
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
+    }
+#pragma unroll
+    for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
+}
+
+// One block column KQ of the sweep: k = 16*KQ + kr, kr = 0 .. min(16, N - 16*KQ) - 1.
+// Columns are scaled LAZILY (the registers keep the raw columns; 1 / L_kk is applied once after the sweep), and the
+// pivots themselves are not inspected here: d_k stays in the diagonal slot (k, k), from which the caller takes
+// log det, the column scales and the first non-positive pivot after the sweep.
+template <int NT, int KQ>
+__device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c) {
     const int kend = min(16, c.N - 16 * KQ);
     const int tx = c.tx, ty = c.ty;
     const bool lower_eq = ty >= tx;
-    int fail = 0;
     // Diagonal blocks below the pivot block are updated in BOTH triangles (no per-step mask); the strictly-upper
     // half then holds Schur-complement values nobody reads, and is cleared here, when the block becomes the pivot
     // block and its upper half starts to collect U.
     if constexpr (KQ > 0) AE(KQ, KQ) = lower_eq ? AE(KQ, KQ) : 0.f;
-    // Software pipeline: a step's critical path is  barrier -> one LDS round trip -> rsq -> the updates of block
+    // Software pipeline: a step's critical path is  barrier -> one LDS round trip -> rcp -> the updates of block
     // column KQ -> publish of the next pivot column;  the other (NT - KQ - 1) block columns are updated after the
-    // publish, off the path.  The pivot-sign test is deferred to the end of the block column (uniform).
+    // publish, off the path.
     if (tx == 0) {
 #pragma unroll
         for (int pi = 0; pi < NT; ++pi) c.colbuf[ty + 16 * pi] = AE(pi, KQ);
     }
-    for (int kr = 0; kr < kend; ++kr) {
-        const int k = 16 * KQ + kr;
-        const float* cb = c.colbuf + (kr & 1) * NP;
-        __syncthreads();
-        const float d = cb[k];
-        f32x2 cp2[NP2];
-        float cj[NT];
-#pragma unroll
-        for (int m = 0; m < NP2; ++m) {
-            cp2[m][0] = cb[ty + 32 * m];
-            cp2[m][1] = (2 * m + 1 < NT) ? cb[ty + 32 * m + 16] : 0.f;
-        }
-#pragma unroll
-        for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji];
-        const float rinv = __builtin_amdgcn_rsqf(d);
-        const float nrd = -rinv * rinv;                  // -1 / d
-        // row factor -(column / d); the column factor stays raw (product = L_pk L_jk)
-#pragma unroll
-        for (int m = 0; m < NP2; ++m) cp2[m] *= nrd;
-        const float cpK = (ty == kr) ? nrd : cp2[KQ >> 1][KQ & 1];   // row k itself seeds U_kj = -L_jk / d
-        cj[KQ] = (tx > kr) ? cj[KQ] : 0.f;              // only columns j > k are updated
-        cj[NT - 1] = c.col_ok ? cj[NT - 1] : 0.f;       // padding columns j >= N
-        const bool row_le_k = ty <= kr;
-        const float cpk_le = row_le_k ? cpK : 0.f;                     // row block KQ, ji > KQ: p <= k only
-        const float cpk_dd = (row_le_k || lower_eq) ? cpK : 0.f;       // block (KQ, KQ): p <= k or p >= j
-        // update of block column ji: rows pi < KQ (U part) and pi >= ji (L part) plain, row block KQ masked,
-        // KQ < pi < ji (k < p < j) untouched
-        auto column = [&](const int ji) {                              // ji is an unrolled constant
-            const f32x2 cjv = {cj[ji], cj[ji]};
-            const float sK = (ji == KQ) ? cpk_dd : cpk_le;
-#pragma unroll
-            for (int m = 0; m < NP2; ++m) {
-                const int p0 = 2 * m, p1 = 2 * m + 1;
-                // 0 none, 1 plain, 2 row block KQ
-                const int k0 = (p0 < KQ) ? 1 : (p0 == KQ) ? 2 : (p0 < ji) ? 0 : 1;
-                const int k1 = (p1 >= NT) ? 0 : (p1 < KQ) ? 1 : (p1 == KQ) ? 2 : (p1 < ji) ? 0 : 1;
-                if (k0 == 1 && k1 == 1) {
-                    A2[m][ji] = __builtin_elementwise_fma(cp2[m], cjv, A2[m][ji]);
-                } else if (k0 != 0 && k1 != 0) {
-                    const f32x2 v = {k0 == 2 ? sK : cp2[m][0], k1 == 2 ? sK : cp2[m][1]};
-                    A2[m][ji] = __builtin_elementwise_fma(v, cjv, A2[m][ji]);
-                } else if (k0 != 0) {
-                    A2[m][ji][0] = __builtin_fmaf(k0 == 2 ? sK : cp2[m][0], cj[ji], A2[m][ji][0]);
-                } else if (k1 != 0) {
-                    A2[m][ji][1] = __builtin_fmaf(k1 == 2 ? sK : cp2[m][1], cj[ji], A2[m][ji][1]);
-                }
-            }
-        };
-        column(KQ);
-        if (kr + 1 < kend && tx == kr + 1) {
-            float* nb = c.colbuf + ((kr + 1) & 1) * NP;
-#pragma unroll
-            for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
-        }
-#pragma unroll
-        for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
-        log2sum += __builtin_amdgcn_logf(d);            // v_log_f32 = log2
-        rinvcol[KQ] = (tx == kr) ? rinv : rinvcol[KQ];
-        fail = (fail == 0 && !(d > 0.f)) ? k + 1 : fail;
+    for (int kr = 0; kr < kend; kr += 2) {
+        sweep_step<NT, KQ, 0>(A2, c, kr, kend, lower_eq);
+        if (kr + 1 < kend) sweep_step<NT, KQ, 1>(A2, c, kr + 1, kend, lower_eq);
     }
-    return fail;
 }
 
 template <int NT, int KQ>
-__device__ __forceinline__ int sweep_all(f32x2 (&A2)[(NT + 1) / 2][NT], float (&rinvcol)[NT], float& log2sum, const RegCtx<NT>& c) {
+__device__ __forceinline__ void sweep_all(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c) {
     if constexpr (KQ < NT) {
-        if (16 * KQ >= c.N) return 0;
-        const int f = sweep_block<NT, KQ>(A2, rinvcol, log2sum, c);
-        if (f) return f;
-        return sweep_all<NT, KQ + 1>(A2, rinvcol, log2sum, c);
-    } else {
-        return 0;
+        if (16 * KQ >= c.N) return;
+        sweep_block<NT, KQ>(A2, c);
+        sweep_all<NT, KQ + 1>(A2, c);
     }
 }
 
@@ -167,78 +168,46 @@ __device__ __forceinline__ void block_sum5(float (&v)[5], float* red) {
     for (int i = 0; i < 5; ++i) v[i] = red[i] + red[5 + i] + red[10 + i] + red[15 + i];
 }
 
-// MFMA accumulation of one 16-column chunk for the tile rows RA (and RB >= 0) owned by this wave.
-// acc index: tiles of row RA first (tj = 0..RA), then tiles of row RB (tj = 0..RB).
+// MFMA accumulation of one 16-column chunk of U U^T for the tile rows RA (and RB >= 0) owned by this wave.
+// acc index: tiles of the SHORT row RB first (tj = 0..RB), then the tiles of row RA (tj = 0..RA).  Row block R of U is
+// zero left of column chunk R, so its tiles are first touched -- with a zero C operand -- at chunk R: no accumulator
+// is live before it is needed (the long rows start late, when most of the matrix registers are already dead).
 template <int NT, int RA, int RB, int CH>
-__device__ __forceinline__ void w_chunk_mfma(f32x4* acc, const float* ub, int r16, int q, float coef, int N) {
-    // row blocks > CH are all zero in chunk CH (U is upper triangular; alpha sits in the last chunk)
-    f32x4 sc;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) sc[t] = (16 * CH + 4 * q + t == N) ? coef : -coef;   // column N carries alpha
+__device__ __forceinline__ void w_chunk_mfma(f32x4* acc, const float* ub, int r16, int q) {
+    constexpr int OA = (RB >= 0) ? RB + 1 : 0;
     const float* base = ub + r16 * ULD + 4 * q;
-    if constexpr (RA <= CH) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RA * 16 * ULD) * sc;
-#pragma unroll
-        for (int tj = 0; tj <= RA; ++tj) {
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(base + tj * 16 * ULD);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], acc[tj], 0, 0, 0);
-        }
-    }
     if constexpr (RB >= 0 && RB <= CH) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RB * 16 * ULD) * sc;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RB * 16 * ULD);
 #pragma unroll
         for (int tj = 0; tj <= RB; ++tj) {
             const f32x4 bf = *reinterpret_cast<const f32x4*>(base + tj * 16 * ULD);
+            f32x4 cacc = (CH == RB) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[tj];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[RA + 1 + tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], acc[RA + 1 + tj], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], cacc, 0, 0, 0);
+            acc[tj] = cacc;
+        }
+    }
+    if constexpr (RA <= CH) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + RA * 16 * ULD);
+#pragma unroll
+        for (int tj = 0; tj <= RA; ++tj) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(base + tj * 16 * ULD);
+            f32x4 cacc = (CH == RA) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[OA + tj];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bf[t], cacc, 0, 0, 0);
+            acc[OA + tj] = cacc;
         }
     }
 }
 
-
-// All chunks of the product for one class: every thread writes its share of the 16-column chunk CH of
-// [U | alpha] to LDS (one barrier per chunk, double buffered), then each wave accumulates its own tile rows.
-template <int NT, int CH>
-__device__ __forceinline__ void w_product_all(f32x4* acc, f32x2 (&A2)[(NT + 1) / 2][NT], float* ubuf, int N, int tx, int ty,
-                                              int wave, int r16, int q, float coef, const float (&alpha)[NT], const Masks& m) {
-    if constexpr (CH < NT) {
-        constexpr int NP = 16 * NT;
-        float* ub = ubuf + (CH & 1) * NP * ULD;
-#pragma unroll
-        for (int pi = 0; pi < NT; ++pi) {
-            const int p = ty + 16 * pi;
-            float v = 0.f;
-            if (CH > pi) v = AE(pi, CH);                               // U block
-            else if (CH == pi) v = (tx >= ty) ? AE(pi, CH) : 0.f;      // diagonal block: upper incl. diagonal
-            if (CH == NT - 1) {
-                v = m.col_ok ? v : 0.f;                               // columns >= N are not U
-                v = m.is_acol ? alpha[pi] : v;                        // column N carries alpha
-            }
-            if (pi == NT - 1) v = m.row_ok ? v : 0.f;                 // rows >= N
-            ub[p * ULD + tx] = v;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if constexpr (RowsOf<NT, 0>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, CH>(acc, ub, r16, q, coef, N);
-        } else if (wave == 1) {
-            if constexpr (RowsOf<NT, 1>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, CH>(acc, ub, r16, q, coef, N);
-        } else if (wave == 2) {
-            if constexpr (RowsOf<NT, 2>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, CH>(acc, ub, r16, q, coef, N);
-        } else {
-            if constexpr (RowsOf<NT, 3>::RA >= 0) w_chunk_mfma<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, CH>(acc, ub, r16, q, coef, N);
-        }
-        w_product_all<NT, CH + 1>(acc, A2, ubuf, N, tx, ty, wave, r16, q, coef, alpha, m);
-    }
-}
-
-// add the class's tiles of one tile row into W (lower triangle + mirror); first class stores
+// W tile = coef (alpha_i alpha_j - (U U^T)_ij), added into W (lower triangle + mirror); the first class stores
 template <int NT, int ROW>
 __device__ __forceinline__ void w_accum_row(const f32x4* acc, brsrc Wr, int N, int tyN, int r16, int q, int vo_rc, int vo_cr,
-                                            bool first) {
+                                            bool first, bool last, float coef, const float* alv) {
+    const f32x4 ai = *reinterpret_cast<const f32x4*>(alv + 16 * ROW + 4 * q) * coef;
 #pragma unroll
     for (int tj = 0; tj <= ROW; ++tj) {
+        const float aj = alv[16 * tj + r16];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int pl = 4 * q + reg;
@@ -248,13 +217,50 @@ __device__ __forceinline__ void w_accum_row(const f32x4* acc, brsrc Wr, int N, i
             if (tj == ROW) ok = ok && (r16 <= pl);                       // lower triangle of the diagonal tile
             if (ok) {
                 const int so = ((16 * ROW + reg) * N + 16 * tj) * 4;
-                float v = acc[tj][reg];
+                float v = __builtin_fmaf(ai[reg], aj, -coef * acc[tj][reg]);
                 if (!first) v += bload(Wr, vo_rc, so);
                 bstore(Wr, v, vo_rc, so);
-                if (!(tj == ROW && r16 == pl)) bstore(Wr, v, vo_cr, (16 * tj * N + 16 * ROW + reg) * 4);
+                // the strided mirror write happens once, when the sum over the classes is complete
+                if (last && !(tj == ROW && r16 == pl)) bstore(Wr, v, vo_cr, (16 * tj * N + 16 * ROW + reg) * 4);
             }
         }
     }
+}
+
+// All chunks of the product for one class, for the wave that owns tile rows RA / RB: every thread writes its share of
+// the 16-column chunk CH of U to LDS (one barrier per chunk, double buffered), then the wave accumulates its tile rows.
+// The four waves run four different instantiations (the caller switches on the wave id); each executes exactly NT
+// barriers, so the workgroup barrier still pairs up chunk by chunk.
+template <int NT, int RA, int RB, int CH>
+__device__ __forceinline__ void w_product_all(f32x4* acc, f32x2 (&A2)[(NT + 1) / 2][NT], float* ubuf, int tx, int ty,
+                                              int r16, int q, const Masks& m) {
+    if constexpr (CH < NT) {
+        constexpr int NP = 16 * NT;
+        float* ub = ubuf + (CH & 1) * NP * ULD;
+#pragma unroll
+        for (int pi = 0; pi < NT; ++pi) {
+            const int p = ty + 16 * pi;
+            float v = 0.f;
+            if (CH > pi) v = AE(pi, CH);                               // U block
+            else if (CH == pi) v = (tx >= ty) ? AE(pi, CH) : 0.f;      // diagonal block: upper incl. diagonal
+            if (CH == NT - 1) v = m.col_ok ? v : 0.f;                  // columns >= N are not U
+            if (pi == NT - 1) v = m.row_ok ? v : 0.f;                  // rows >= N
+            ub[p * ULD + tx] = v;
+        }
+        __syncthreads();
+        if constexpr (RA >= 0) w_chunk_mfma<NT, RA, RB, CH>(acc, ub, r16, q);
+        w_product_all<NT, RA, RB, CH + 1>(acc, A2, ubuf, tx, ty, r16, q, m);
+    }
+}
+
+template <int NT, int W>
+__device__ __forceinline__ void w_product_wave(f32x2 (&A2)[(NT + 1) / 2][NT], float* ubuf, int tx, int ty, int r16, int q, const Masks& m,
+                                               brsrc Wr, int N, int tyN, int vo_rc, int vo_cr, bool first, bool last, float coef, const float* alv) {
+    constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
+    f32x4 acc[NT + 1];                                   // first touched (zero C operand) inside the product
+    w_product_all<NT, RA, RB, 0>(acc, A2, ubuf, tx, ty, r16, q, m);
+    if constexpr (RB >= 0) w_accum_row<NT, RB>(acc, Wr, N, tyN, r16, q, vo_rc, vo_cr, first, last, coef, alv);
+    if constexpr (RA >= 0) w_accum_row<NT, RA>(acc + (RB >= 0 ? RB + 1 : 0), Wr, N, tyN, r16, q, vo_rc, vo_cr, first, last, coef, alv);
 }
 
 template <int NT, bool WANT_GRAD, bool WANT_CHOL>
@@ -263,15 +269,17 @@ template <int NT, bool WANT_GRAD, bool WANT_CHOL>
 #endif
 __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_REG_MINW : 2)) void mll_reg_kernel(MllArgs a) {
     constexpr int NP = 16 * NT;
-    constexpr int MAXACC = NT + 1;                       // max tiles per wave
     __shared__ float colbuf[2 * NP];
     __shared__ float wv[NP];
+    __shared__ float dgv[NP];
+    __shared__ __attribute__((aligned(16))) float alv[NP];
     __shared__ float red[20];
     __shared__ __attribute__((aligned(16))) float ubuf[2 * NP * ULD];
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const int lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave id in an SGPR: scalar switch
     const int N = a.N, C = a.C;
     const int tyN = N - 16 * (NT - 1);                  // row N lives at pi = NT-1, ty = tyN; column N at ji = NT-1, tx = tyN
     const bool lower_eq = ty >= tx, upper_eq = tx >= ty;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
         const brsrc yr = make_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, N * 4);
         f32x2 A2[(NT + 1) / 2][NT];
         float rinvcol[NT];
-        float log2sum = 0.f;
+        float log2part = 0.f;                            // this thread's share of sum_k log2 d_k (ty == 0 lanes)
         int fail_at = 0;
         float jit = 0.f;
         for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
@@ -331,10 +339,27 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
                 }
             }
             __syncthreads();          // previous users of colbuf are done
+            sweep_all<NT, 0>(A2, ctx);
+            // ---- pivots: d_j sits raw in the diagonal slot (j, j).  Column scales, log det, first bad pivot ----
+            if (ty == tx) {
 #pragma unroll
-            for (int ji = 0; ji < NT; ++ji) rinvcol[ji] = 1.0f;
-            log2sum = 0.f;
-            fail_at = sweep_all<NT, 0>(A2, rinvcol, log2sum, ctx);
+                for (int ji = 0; ji < NT; ++ji) dgv[tx + 16 * ji] = AE(ji, ji);
+            }
+            __syncthreads();
+            int bad = 0x7fffffff;
+            log2part = 0.f;
+#pragma unroll
+            for (int ji = NT - 1; ji >= 0; --ji) {
+                const float dj = dgv[tx + 16 * ji];
+                const bool valid = (ji < NT - 1) || col_ok;
+                rinvcol[ji] = valid ? __builtin_amdgcn_rsqf(dj) : 1.0f;
+                log2part += valid ? __builtin_amdgcn_logf(dj) : 0.f;          // v_log_f32 = log2
+                bad = (valid && !(dj > 0.f)) ? tx + 16 * ji + 1 : bad;        // descending ji: the smallest index wins
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) bad = min(bad, __shfl_xor(bad, o, DKT_WAVE));
+            bad = __builtin_amdgcn_readfirstlane(bad);       // every 16-lane row of every wave computed the same value
+            fail_at = (bad == 0x7fffffff) ? 0 : bad;
             if (fail_at == 0) break;
         }
         const size_t bc = (size_t)b * C + c;
@@ -375,8 +400,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
         float wj[NT];
 #pragma unroll
         for (int ji = 0; ji < NT; ++ji) wj[ji] = wv[tx + 16 * ji];
-        float alpha[NT];
-        float v5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // quad, sum log d, sum alpha, sum alpha^2, |U|_F^2
+        float v5[5] = {0.f, (ty == 0) ? log2part : 0.f, 0.f, 0.f, 0.f};     // quad, sum log2 d, sum alpha, sum alpha^2, |U|_F^2
         if (ty == tyN) {
 #pragma unroll
             for (int ji = 0; ji < NT; ++ji) v5[0] += wj[ji] * wj[ji];
@@ -396,16 +420,16 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, DKT_WAVE);
             if (pi == NT - 1) { s = row_ok ? s : 0.f; u2 = row_ok ? u2 : 0.f; }
-            alpha[pi] = s;                                          // alpha_p, replicated over the 16 tx lanes
             v5[4] += u2;
             if (tx == 0) {
+                alv[p] = s;                                         // alpha_p for the gradient product (column N of [U | alpha])
                 v5[2] += s;
                 v5[3] += s * s;
                 if (pi < NT - 1 || row_ok) a.alpha[bc * N + p] = s;
             }
         }
         block_sum5(v5, red);
-        const float quad = v5[0], logdet_half = 0.34657359027997264f * log2sum, asum = v5[2], a2 = v5[3], trk = v5[4];
+        const float quad = v5[0], logdet_half = 0.34657359027997264f * v5[1], asum = v5[2], a2 = v5[3], trk = v5[4];
         if (tid == 0) {
             a.logp[bc] = -0.5f * quad - logdet_half - (float)N * DKT_HALF_LOG_2PI;
             a.jitter_used[bc] = jit;
@@ -439,33 +463,16 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
         if constexpr (want_grad) {
             const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
             const float coef = 0.5f * cw * svc;
-            // W += coef (alpha alpha^T - U U^T): alpha rides as column N of the chunked U matrix
+            // W += coef (alpha alpha^T - U U^T): U U^T on MFMA, the rank-1 alpha term in the epilogue (alpha from LDS)
             // The class's contribution is accumulated into W[b] in memory (same lanes, same words, class after class:
             // deterministic, no atomics) so that no accumulator registers stay live across the next class's sweep.
-            f32x4 acc[MAXACC];
-#pragma unroll
-            for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            w_product_all<NT, 0>(acc, A2, ubuf, N, tx, ty, wave, r16, q, coef, alpha, masks);
             const brsrc Wr = make_rsrc(a.W + (size_t)b * N * N, N * N * 4);
-            const bool first = (c == 0);
-            const int tyN16 = tyN;
-            switch (wave) {
-                case 0:
-                    if constexpr (RowsOf<NT, 0>::RA >= 0) w_accum_row<NT, RowsOf<NT, 0>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    if constexpr (RowsOf<NT, 0>::RB >= 0) w_accum_row<NT, RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    break;
-                case 1:
-                    if constexpr (RowsOf<NT, 1>::RA >= 0) w_accum_row<NT, RowsOf<NT, 1>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    if constexpr (RowsOf<NT, 1>::RB >= 0) w_accum_row<NT, RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    break;
-                case 2:
-                    if constexpr (RowsOf<NT, 2>::RA >= 0) w_accum_row<NT, RowsOf<NT, 2>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    if constexpr (RowsOf<NT, 2>::RB >= 0) w_accum_row<NT, RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    break;
-                default:
-                    if constexpr (RowsOf<NT, 3>::RA >= 0) w_accum_row<NT, RowsOf<NT, 3>::RA>(acc, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    if constexpr (RowsOf<NT, 3>::RB >= 0) w_accum_row<NT, RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Wr, N, tyN16, r16, q, vo_rc, vo_cr, first);
-                    break;
+            const bool first = (c == 0), last = (c == C - 1);
+            switch (wave_u) {
+                case 0: w_product_wave<NT, 0>(A2, ubuf, tx, ty, r16, q, masks, Wr, N, tyN, vo_rc, vo_cr, first, last, coef, alv); break;
+                case 1: w_product_wave<NT, 1>(A2, ubuf, tx, ty, r16, q, masks, Wr, N, tyN, vo_rc, vo_cr, first, last, coef, alv); break;
+                case 2: w_product_wave<NT, 2>(A2, ubuf, tx, ty, r16, q, masks, Wr, N, tyN, vo_rc, vo_cr, first, last, coef, alv); break;
+                default: w_product_wave<NT, 3>(A2, ubuf, tx, ty, r16, q, masks, Wr, N, tyN, vo_rc, vo_cr, first, last, coef, alv); break;
             }
         }
         __syncthreads();
