@@ -416,8 +416,8 @@ __device__ __forceinline__ void split3s(float x, __bf16& h, __bf16& m, __bf16& l
     l = (__bf16)(r1 - (float)m);
 }
 
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+template <int NT, int NBUF, int PF>
+__global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3_kernel(const float* __restrict__ W, const float* __restrict__ Z,
                                                                      float* __restrict__ dZ, int N, int D,
                                                                      const float* __restrict__ ep_scale) {
     constexpr int NP = 16 * NT;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
     constexpr int RS = 8 * SU;                           // bf16 per LDS row
     constexpr int PLANE = BD * RS;
     static_assert(SU % 4 == 2 && RS >= KP, "LDS row stride");
-    __shared__ __attribute__((aligned(16))) __bf16 zt[2][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 zt[NBUF][3 * PLANE];
 
     const int b = blockIdx.x;
     const float* Wb = W + (size_t)b * N * N;
@@ -451,8 +451,10 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
     };
     const int nslab = (D + BD - 1) / BD;
     float4 r0[4], r1[4];
-    gload(r0, 0);                                        // the first two slabs fly while W is staged and split
-    if (nslab > 1) gload(r1, BD);
+    gload(r0, 0);                                        // the first slab(s) fly while W is staged and split
+    if constexpr (PF == 2) {
+        if (nslab > 1) gload(r1, BD);
+    }
 
     // A fragments: slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e.  W[b] (N x N fp32, 44 KB) is first
     // copied into the (still unused) staging LDS with coalesced loads, so the row AND the column access of
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
     bf16x8 ah[KS], am[KS], al[KS];
     {
         float* wl = reinterpret_cast<float*>(&zt[0][0]);
-        static_assert(sizeof(zt) >= NP * NP * 4, "W does not fit the staging buffers");
+        static_assert(sizeof(zt) >= NP * NP * 4, "W does not fit the staging buffer(s)");
         const int nn = N * N;
         for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
         __syncthreads();
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
     // columns j in [NP, KP) of the [d][j] image are never staged: zero them once (NaN bit patterns would poison 0 * x)
     if constexpr (KP > NP) {
         constexpr int PADV = (KP - NP) / 8;              // 16-byte pieces per row
-        for (int i = tid; i < 2 * 3 * BD * PADV; i += NTH) {
+        for (int i = tid; i < NBUF * 3 * BD * PADV; i += NTH) {
             const int rowi = i / PADV, pc = i % PADV;    // rowi enumerates (buffer, plane, d)
             __bf16* dst = &zt[0][0] + (size_t)rowi * RS + NP + 8 * pc;
             *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -541,19 +543,29 @@ __global__ __launch_bounds__(64 * NT) void gram_bwd_ep_bf16x3_kernel(const float
         }
     };
 
+    // slab sl: LDS holds slab sl, `rnear` holds slab sl+1 (PF = 2) or is loaded now (PF = 1), `rfar` is issued for sl+2
     auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
-        const int buf = sl & 1;
-        if (sl + 2 < nslab) gload(rfar, (sl + 2) * BD);
+        const int buf = (NBUF == 2) ? (sl & 1) : 0;
+        if constexpr (PF == 2) {
+            if (sl + 2 < nslab) gload(rfar, (sl + 2) * BD);
+        } else {
+            if (sl + 1 < nslab) gload(rnear, (sl + 1) * BD);
+        }
         compute_store(buf, sl * BD);
-        if (sl + 1 < nslab) lstore(rnear, buf ^ 1);
+        if constexpr (NBUF == 1) __syncthreads();
+        if (sl + 1 < nslab) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
         __syncthreads();
     };
     __syncthreads();                                     // pad columns zeroed
     lstore(r0, 0);
     __syncthreads();
-    for (int sl = 0; sl < nslab; sl += 2) {
-        stage(r1, r0, sl);
-        if (sl + 1 < nslab) stage(r0, r1, sl + 1);
+    if constexpr (PF == 2) {
+        for (int sl = 0; sl < nslab; sl += 2) {
+            stage(r1, r0, sl);
+            if (sl + 1 < nslab) stage(r0, r1, sl + 1);
+        }
+    } else {
+        for (int sl = 0; sl < nslab; ++sl) stage(r0, r1, sl);
     }
 }
 
@@ -576,7 +588,14 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream
 
 template <int NT>
 void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, hipStream_t st) {
-    if (bd == 3) hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+    if (bd == 3) {
+        const int v = env_int("DKT_GRAM_BWD_SPLIT_VAR", 11);  // <LDS buffers><prefetch depth>
+        if constexpr (NT <= 7) {                              // one stage buffer must also hold the N x N staging copy of W
+            if (v == 11) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+            if (v == 12) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        }
+        hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+    }
     else if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
     else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
 }

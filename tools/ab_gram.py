@@ -85,3 +85,16 @@ for (b, n, d) in [(2048, 105, 1600), (4096, 75, 512), (1024, 128, 1600), (1024, 
     line += " finite %s" % bool(torch.isfinite(outs[1]).all())
     print(line, flush=True)
 os.environ.pop("DKT_GRAM_SPLIT", None)
+
+print("---- backward variants <LDS buffers><prefetch depth> at cfg2", flush=True)
+z = torch.nn.functional.normalize(torch.randn(2048, 105, 1600, device=dev), dim=2).contiguous()
+w = torch.randn(2048, 105, 105, device=dev)
+ref = ops.gram_bwd(w, z, None)
+for rep in range(2):
+    for var in ("22", "11", "12"):
+        os.environ["DKT_GRAM_BWD_SPLIT_VAR"] = var
+        out = ops.gram_bwd(w, z, None)
+        ms = timed(lambda: ops.gram_bwd(w, z, None), reps=50)
+        print("var %s: %.4f ms  %.0f GB/s  max|diff| vs var 22 %.2e" % (var, ms, 4.0 * 2048 * (2 * 105 * 1600 + 105 * 105) / ms / 1e6,
+                                                                          (out - ref).abs().max().item()), flush=True)
+os.environ.pop("DKT_GRAM_BWD_SPLIT_VAR", None)
