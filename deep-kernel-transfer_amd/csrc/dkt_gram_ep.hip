@@ -159,11 +159,11 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
     }
 }
 
-constexpr int SPLD = 48;   // bf16 per LDS row of a plane: 32 data + 16 pad (96 B; (96/16) mod 16 = 6: conflict-free b128 fragments)
+// bf16 per LDS row of a plane: BK data + 16 pad -> 96 B (BK = 32) or 160 B (BK = 64): 6 / 10 sixteen-byte units,
+// both == 2 mod 4: conflict-free b128 fragment reads
 
-template <int NT, int RA, int RB>
+template <int NT, int RA, int RB, int SPLD, int PLANE>
 __device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* zp, int r16, int q) {
-    constexpr int PLANE = 16 * NT * SPLD;
     const __bf16* base = zp + r16 * SPLD + 8 * q;
     auto frag = [&](int plane, int blk) { return *reinterpret_cast<const bf16x8*>(base + plane * PLANE + blk * 16 * SPLD); };
     auto tile = [&](f32x4& c, const bf16x8& ah, const bf16x8& am, const bf16x8& al, int tj) {
@@ -189,14 +189,18 @@ __device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* 
 
 // NBUF = LDS stage buffers (2: one barrier per stage, 2 workgroups/CU; 1: two barriers, 4 workgroups/CU);
 // PF   = global-load run-ahead in stages (register sets): PF stages x 14 KB per workgroup stay in flight.
-template <int NT, int NBUF, int PF>
-__global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
+template <int NT, int NBUF, int PF, int BK = 32>
+__global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
     constexpr int NP = 16 * NT;
-    constexpr int BK = 32;
+    constexpr int SPLD = BK + 16;
     constexpr int V4_PER_ROW = BK / 4;
     constexpr int NV4 = NP * V4_PER_ROW;
     constexpr int NLD = (NV4 + 255) / 256;
-    constexpr int PLANE = NP * SPLD;
+    // the LDS image has NLD * 256 / V4_PER_ROW >= NP rows, so that EVERY thread stages exactly NLD float4 with no
+    // exec-masked tail: straight-line staging code keeps the compiler's vmcnt bookkeeping exact, which is what lets the
+    // far prefetch (PF = 2) really stay in flight across the MFMA phase.  Rows >= N load as zeros (out-of-range offset).
+    constexpr int NPL = NLD * 256 / V4_PER_ROW;
+    constexpr int PLANE = NPL * SPLD;
     __shared__ __attribute__((aligned(16))) __bf16 zp[NBUF][3 * PLANE];
 
     const int b = blockIdx.x;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_
     for (int i = 0; i < NLD; ++i) {
         const int idx = tid + 256 * i;
         const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
-        voff[i] = ((NV4 % 256 == 0 || idx < NV4) && row < N) ? (row * D + 4 * c4) * 4 : 0x7ffffff0;
+        voff[i] = (row < N) ? (row * D + 4 * c4) * 4 : 0x7ffffff0;
     }
     auto gload = [&](float4 (&rg)[NLD], int k0) {
         const bool ragged = k0 + BK > D;                 // uniform
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
-            if (NV4 % 256 == 0 || idx < NV4) {
+            {
                 bf16x4 h, m, l;
                 split3(rg[i], h, m, l);
                 __bf16* dst = &zp[buf][row * SPLD + 4 * c4];
@@ -245,46 +249,86 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_
 #pragma unroll
     for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
-        if (wave == 0) {
-            if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB>(acc, zp[buf], r16, q);
-        } else if (wave == 1) {
-            if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB>(acc, zp[buf], r16, q);
-        } else if (wave == 2) {
-            if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB>(acc, zp[buf], r16, q);
-        } else {
-            if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB>(acc, zp[buf], r16, q);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const __bf16* zs = zp[buf] + 32 * ks;
+            if (wave == 0) {
+                if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, SPLD, PLANE>(acc, zs, r16, q);
+            } else if (wave == 1) {
+                if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, SPLD, PLANE>(acc, zs, r16, q);
+            } else if (wave == 2) {
+                if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, SPLD, PLANE>(acc, zs, r16, q);
+            } else {
+                if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, SPLD, PLANE>(acc, zs, r16, q);
+            }
         }
     };
 
     const int nk = (D + BK - 1) / BK;
     float4 r0[NLD], r1[NLD];
-    // stage kt: LDS holds slice kt, `rnear` holds slice kt+1 (PF = 2) or is loaded now (PF = 1), `rfar` is issued for kt+2
+#if defined(DKT_EXP_CLOCKS)
+    long long clk[6] = {0, 0, 0, 0, 0, 0};
+    const long long cstart = clock64();
+#endif
+    // stage kt: LDS holds slice kt, `rnear` holds slice kt+1 (PF = 2) or is loaded now (PF = 1), `rfar` is issued for kt+2.
+    // PF = 2 runs with NO conditionals around loads and stores (slices past D load as zeros through the ragged test and
+    // are staged and multiplied as zeros; an odd slice count is rounded up): on a branch-free path the compiler's vmcnt
+    // values are exact, so the 4 far loads really stay in flight while the near ones are consumed.
     auto stage = [&](float4 (&rnear)[NLD], float4 (&rfar)[NLD], int kt) {
         const int buf = (NBUF == 2) ? (kt & 1) : 0;
+#if defined(DKT_EXP_CLOCKS)
+        // phase clocks of wave 0 (measurement build only): issue loads | MFMA phase | barrier 1 | load wait | split+store | barrier 2
+        const long long c0 = clock64();
+#endif
         if constexpr (PF == 2) {
-            if (kt + 2 < nk) gload(rfar, (kt + 2) * BK);
+            gload(rfar, (kt + 2) * BK);
         } else {
             if (kt + 1 < nk) gload(rnear, (kt + 1) * BK);
         }
+#if defined(DKT_EXP_CLOCKS)
+        const long long c1 = clock64();
+#endif
         compute(buf);
+#if defined(DKT_EXP_CLOCKS)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): fragment reads done (MFMAs may still execute)
+        const long long c2 = clock64();
+#endif
         if constexpr (NBUF == 1) __syncthreads();
-        if (kt + 1 < nk) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+#if defined(DKT_EXP_CLOCKS)
+        const long long c3 = clock64();
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);        // vmcnt(0)
+        const long long c4 = clock64();
+#endif
+        if constexpr (PF == 2) {
+            lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        } else {
+            if (kt + 1 < nk) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        }
+#if defined(DKT_EXP_CLOCKS)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const long long c5 = clock64();
+#endif
         __syncthreads();
+#if defined(DKT_EXP_CLOCKS)
+        const long long c6 = clock64();
+        clk[0] += c1 - c0; clk[1] += c2 - c1; clk[2] += c3 - c2; clk[3] += c4 - c3; clk[4] += c5 - c4; clk[5] += c6 - c5;
+#endif
     };
     gload(r0, 0);
-    if constexpr (PF == 2) {
-        if (nk > 1) gload(r1, BK);
-    }
+    if constexpr (PF == 2) gload(r1, BK);
     lstore(r0, 0);
     __syncthreads();
     if constexpr (PF == 2) {
         for (int kt = 0; kt < nk; kt += 2) {
             stage(r1, r0, kt);
-            if (kt + 1 < nk) stage(r0, r1, kt + 1);
+            stage(r0, r1, kt + 1);
         }
     } else {
         for (int kt = 0; kt < nk; ++kt) stage(r0, r1, kt);
     }
+#if defined(DKT_EXP_CLOCKS)
+    const long long cloop = clock64();
+#endif
     if (wave == 0) {
         if constexpr (RowsOf<NT, 0>::RA >= 0) sym_store_row<RowsOf<NT, 0>::RA>(acc, Eb, N, r16, q);
         if constexpr (RowsOf<NT, 0>::RB >= 0) sym_store_row<RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Eb, N, r16, q);
@@ -298,6 +342,16 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7) ? 4 : 2) void gram_sym_
         if constexpr (RowsOf<NT, 3>::RA >= 0) sym_store_row<RowsOf<NT, 3>::RA>(acc, Eb, N, r16, q);
         if constexpr (RowsOf<NT, 3>::RB >= 0) sym_store_row<RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Eb, N, r16, q);
     }
+#if defined(DKT_EXP_CLOCKS)
+    if (tid == 0) {
+        // the clock dump overwrites the (unused in this build) first row of E[b]: E[b][0..7] as integer kilo-ticks
+        const long long cend = clock64();
+        float* dbg = Eb;
+        for (int i = 0; i < 6; ++i) dbg[i] = (float)clk[i];
+        dbg[6] = (float)(cloop - cstart);
+        dbg[7] = (float)(cend - cloop);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,22 +493,23 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
     const float s = ep_scale ? ep_scale[b] : 1.0f;
 
     const int d4 = tid & 15, jg = tid >> 4;              // staging block: rows 4 jg .. 4 jg + 3, features 4 d4 .. 4 d4 + 3
+    // buffer loads: rows j >= N and features d >= D get an out-of-range offset and read as zeros (no exec-masked code)
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) voff[rr] = (4 * jg + rr < N) ? ((4 * jg + rr) * D + 4 * d4) * 4 : 0x7ffffff0;
     auto gload = [&](float4 (&rg)[4], int d0) {
-        const int d = d0 + 4 * d4;
+        const bool in = d0 + 4 * d4 < D;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int j = 4 * jg + rr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < N && d < D) v = *reinterpret_cast<const float4*>(Zb + (size_t)j * D + d);
-            rg[rr] = v;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, in ? voff[rr] : 0x7ffffff0, d0 * 4, 0);
+            rg[rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
     const int nslab = (D + BD - 1) / BD;
     float4 r0[4], r1[4];
     gload(r0, 0);                                        // the first slab(s) fly while W is staged and split
-    if constexpr (PF == 2) {
-        if (nslab > 1) gload(r1, BD);
-    }
+    if constexpr (PF == 2) gload(r1, BD);
 
     // A fragments: slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e.  W[b] (N x N fp32, 44 KB) is first
     // copied into the (still unused) staging LDS with coalesced loads, so the row AND the column access of
@@ -547,13 +602,17 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
     auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
         const int buf = (NBUF == 2) ? (sl & 1) : 0;
         if constexpr (PF == 2) {
-            if (sl + 2 < nslab) gload(rfar, (sl + 2) * BD);
+            gload(rfar, (sl + 2) * BD);                  // unconditional: slabs past D load (and stage, and multiply) as zeros
         } else {
             if (sl + 1 < nslab) gload(rnear, (sl + 1) * BD);
         }
         compute_store(buf, sl * BD);
         if constexpr (NBUF == 1) __syncthreads();
-        if (sl + 1 < nslab) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        if constexpr (PF == 2) {
+            lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        } else {
+            if (sl + 1 < nslab) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        }
         __syncthreads();
     };
     __syncthreads();                                     // pad columns zeroed
@@ -562,7 +621,7 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
     if constexpr (PF == 2) {
         for (int sl = 0; sl < nslab; sl += 2) {
             stage(r1, r0, sl);
-            if (sl + 1 < nslab) stage(r0, r1, sl + 1);
+            stage(r0, r1, sl + 1);                       // an odd slab count runs one all-zero slab (its stores are masked)
         }
     } else {
         for (int sl = 0; sl < nslab; ++sl) stage(r0, r1, sl);
@@ -579,6 +638,8 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream
     if (bk == 3) {
         const int v = env_int("DKT_GRAM_SPLIT_VAR", 11);      // <LDS buffers><prefetch depth>
         if (v == 21) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 611) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 612) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 12) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);

@@ -57,29 +57,45 @@ struct RegCtx {
 // on v_pk_fma_f32: the row-factor pair comes straight out of one ds_read2_b32, the column factor is broadcast.
 #define AE(pi, ji) A2[(pi) >> 1][ji][(pi) & 1]
 
+// Pivot column as a thread sees it: its NT row entries (pairs), its column entries and the pivot itself.
+template <int NT>
+struct PivCol {
+    f32x2 cp2[(NT + 1) / 2];
+    float cj[NT];
+    float d;
+};
+
+template <int NT, int KQ>
+__device__ __forceinline__ void load_pivcol(PivCol<NT>& pc, const float* cb, int tx, int ty, int kr) {
+    constexpr int NP2 = (NT + 1) / 2;
+    pc.d = cb[16 * KQ + kr];
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) {
+        pc.cp2[m][0] = cb[ty + 32 * m];
+        pc.cp2[m][1] = (2 * m + 1 < NT) ? cb[ty + 32 * m + 16] : 0.f;
+    }
+#pragma unroll
+    for (int ji = KQ; ji < NT; ++ji) pc.cj[ji] = cb[tx + 16 * ji];
+}
+
 // One pivot step; PAR = kr & 1 is static so both LDS buffers have compile-time addresses.
+// `cur` holds column k (read from LDS during the previous step); the step updates block column KQ, publishes column
+// k+1, crosses the barrier, ISSUES the LDS reads of column k+1 into `nxt`, and only then updates the remaining block
+// columns with column k -- the LDS round trip of the next step hides behind this step's bulk FMAs.
 template <int NT, int KQ, int PAR>
-__device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c, const int kr, const int kend,
-                                           const bool lower_eq) {
+__device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c, PivCol<NT>& cur, PivCol<NT>& nxt,
+                                           const int kr, const int kend, const bool lower_eq) {
     constexpr int NP = 16 * NT;
     constexpr int NP2 = (NT + 1) / 2;
     const int tx = c.tx, ty = c.ty;
-    const float* cb = c.colbuf + PAR * NP;
-    __syncthreads();
-    const float d = cb[16 * KQ + kr];
+    const float nrd = -__builtin_amdgcn_rcpf(cur.d);                  // -1 / d
     f32x2 cp2[NP2];
     float cj[NT];
-#pragma unroll
-    for (int m = 0; m < NP2; ++m) {
-        cp2[m][0] = cb[ty + 32 * m];
-        cp2[m][1] = (2 * m + 1 < NT) ? cb[ty + 32 * m + 16] : 0.f;
-    }
-#pragma unroll
-    for (int ji = KQ; ji < NT; ++ji) cj[ji] = cb[tx + 16 * ji];
-    const float nrd = -__builtin_amdgcn_rcpf(d);                      // -1 / d
     // row factor -(column / d); the column factor stays raw (product = L_pk L_jk)
 #pragma unroll
-    for (int m = 0; m < NP2; ++m) cp2[m] *= nrd;
+    for (int m = 0; m < NP2; ++m) cp2[m] = cur.cp2[m] * nrd;
+#pragma unroll
+    for (int ji = KQ; ji < NT; ++ji) cj[ji] = cur.cj[ji];
     const float cpK = (ty == kr) ? nrd : cp2[KQ >> 1][KQ & 1];        // row k itself seeds U_kj = -L_jk / d
     cj[KQ] = (tx > kr) ? cj[KQ] : 0.f;                                // only columns j > k are updated
     cj[NT - 1] = c.col_ok ? cj[NT - 1] : 0.f;                         // padding columns j >= N
@@ -110,10 +126,14 @@ __device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const 
         }
     };
     column(KQ);
-    if (kr + 1 < kend && tx == kr + 1) {
+    if (kr + 1 < kend) {
         float* nb = c.colbuf + (PAR ^ 1) * NP;
+        if (tx == kr + 1) {
 #pragma unroll
-        for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
+            for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
+        }
+        __syncthreads();
+        load_pivcol<NT, KQ>(nxt, nb, tx, ty, kr + 1);
     }
 #pragma unroll
     for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
@@ -132,16 +152,16 @@ __device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const
     // half then holds Schur-complement values nobody reads, and is cleared here, when the block becomes the pivot
     // block and its upper half starts to collect U.
     if constexpr (KQ > 0) AE(KQ, KQ) = lower_eq ? AE(KQ, KQ) : 0.f;
-    // Software pipeline: a step's critical path is  barrier -> one LDS round trip -> rcp -> the updates of block
-    // column KQ -> publish of the next pivot column;  the other (NT - KQ - 1) block columns are updated after the
-    // publish, off the path.
     if (tx == 0) {
 #pragma unroll
         for (int pi = 0; pi < NT; ++pi) c.colbuf[ty + 16 * pi] = AE(pi, KQ);
     }
+    __syncthreads();
+    PivCol<NT> s0, s1;
+    load_pivcol<NT, KQ>(s0, c.colbuf, tx, ty, 0);
     for (int kr = 0; kr < kend; kr += 2) {
-        sweep_step<NT, KQ, 0>(A2, c, kr, kend, lower_eq);
-        if (kr + 1 < kend) sweep_step<NT, KQ, 1>(A2, c, kr + 1, kend, lower_eq);
+        sweep_step<NT, KQ, 0>(A2, c, s0, s1, kr, kend, lower_eq);
+        if (kr + 1 < kend) sweep_step<NT, KQ, 1>(A2, c, s1, s0, kr + 1, kend, lower_eq);
     }
 }
 
