@@ -61,6 +61,71 @@ def test_gram_linear_cross(cuda, b, m, n, d):
     assert np.abs(e - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-6
 
 
+# episode-resident kernels (one workgroup per episode; B >= 64, 64 < N <= 128, D % 4 == 0): every tile count NT = 5..8,
+# ragged last slices (D % 32 != 0, D % 64 != 0), odd stage counts, both arithmetic routes and every pipeline variant
+EP_SHAPES = [(64, 65, 36), (64, 75, 512), (70, 80, 1024), (64, 96, 100), (64, 105, 1600), (64, 105, 2916), (64, 112, 1056),
+             (64, 128, 160), (96, 100, 32)]
+
+
+@pytest.mark.parametrize("b,n,d", EP_SHAPES)
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_gram_episode_resident_kernels(cuda, b, n, d, split, monkeypatch):
+    monkeypatch.setenv("DKT_GRAM_SPLIT", split)
+    g = torch.Generator(device=cuda).manual_seed(n * 7 + d)
+    z = torch.randn(b, n, d, generator=g, device=cuda) * torch.exp(2.0 * torch.randn(b, n, d, generator=g, device=cuda))
+    e = ops.gram(z)
+    ref = torch.einsum("bnd,bmd->bnm", z.double(), z.double())
+    mag = torch.einsum("bnd,bmd->bnm", z.double().abs(), z.double().abs())      # what fp32 rounding errors scale with
+    err = ((e.double() - ref).abs() / mag).max().item()
+    tol = max(1e-6, 6.0 * np.sqrt(d) * 2.0 ** -24)      # random-walk growth of fp32 accumulation error over D heavy-tailed terms
+    assert err < tol, (err, tol)
+    assert torch.equal(e, e.transpose(1, 2)), "Gram must be exactly symmetric"
+    assert torch.equal(e, ops.gram(z)), "deterministic"
+    # the generic tile kernel (B below the episode-kernel threshold) agrees
+    e_gen = ops.gram(z[:2].contiguous())
+    gen_err = ((e_gen.double() - ref[:2]).abs() / mag[:2]).max().item()
+    assert gen_err < tol, (gen_err, tol)
+
+
+@pytest.mark.parametrize("var", ["11", "12", "21", "22", "611", "612"])
+def test_gram_split_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
+    z = torch.nn.functional.normalize(torch.randn(64, 105, 1632, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3)), dim=2)
+    monkeypatch.setenv("DKT_GRAM_SPLIT_VAR", "11")
+    ref = ops.gram(z)
+    monkeypatch.setenv("DKT_GRAM_SPLIT_VAR", var)
+    assert torch.equal(ops.gram(z), ref)
+
+
+@pytest.mark.parametrize("b,n,d", EP_SHAPES)
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_gram_bwd_episode_resident_kernels(cuda, b, n, d, split, monkeypatch):
+    monkeypatch.setenv("DKT_GRAM_SPLIT", split)
+    monkeypatch.setenv("DKT_GRAM_BWD_SPLIT_MIND", "32")              # force the split kernel also at small D
+    g = torch.Generator(device=cuda).manual_seed(n * 11 + d)
+    z = torch.randn(b, n, d, generator=g, device=cuda)
+    w = torch.randn(b, n, n, generator=g, device=cuda) * torch.exp(2.0 * torch.randn(b, n, n, generator=g, device=cuda))
+    sc = torch.rand(b, generator=g, device=cuda) + 0.5
+    dz = ops.gram_bwd(w, z, sc)
+    ws = (w + w.transpose(1, 2)).double() * sc.double().view(-1, 1, 1)
+    ref = ws @ z.double()
+    mag = ws.abs() @ z.double().abs()
+    assert ((dz.double() - ref).abs() / mag).max().item() < 2e-6
+    assert torch.equal(dz, ops.gram_bwd(w, z, sc)), "deterministic"
+    dz1 = ops.gram_bwd(w, z, None)                                  # no per-episode scale
+    assert ((dz1.double() - (w + w.transpose(1, 2)).double() @ z.double()).abs() / (mag / sc.double().view(-1, 1, 1))).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("var", ["11", "12", "22"])
+def test_gram_bwd_split_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
+    g = torch.Generator(device=cuda).manual_seed(5)
+    z = torch.randn(64, 105, 1088, generator=g, device=cuda)          # 17 slabs of 64: odd slab count
+    w = torch.randn(64, 105, 105, generator=g, device=cuda)
+    monkeypatch.setenv("DKT_GRAM_BWD_SPLIT_VAR", "11")
+    ref = ops.gram_bwd(w, z, None)
+    monkeypatch.setenv("DKT_GRAM_BWD_SPLIT_VAR", var)
+    assert torch.equal(ops.gram_bwd(w, z, None), ref)
+
+
 @pytest.mark.parametrize("n,d,ls,shift", [(19, 2916, 30.0, 0.4), (5, 2916, 20.0, 0.4), (105, 64, 1.3, 0.0), (70, 33, 0.9, 5.0)])
 def test_gram_rbf(cuda, n, d, ls, shift):
     rng = np.random.default_rng(n + d)
