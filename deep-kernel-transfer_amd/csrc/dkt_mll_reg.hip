@@ -48,7 +48,7 @@ constexpr int ULD = 24;   // LDS row stride (floats) of a 16-column chunk of U: 
 
 template <int NT>
 struct RegCtx {
-    float* colbuf;   // [2][16*NT]
+    float* colbuf;   // [4][16*NT]
     int N, tx, ty, tid;
     bool col_ok;
 };
@@ -139,12 +139,104 @@ __device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
 }
 
+// TWO pivots per barrier (k = 16 KQ + kr and k + 1, kr even).  Both raw columns are published together; every thread
+// applies pivot k to its entries of column k+1 itself (x1' = x1 + F0 e with e = A[k+1][k]; the second pivot
+// d1 = A[k+1][k+1] - e^2 / d0 is a uniform scalar), then does ONE rank-2 update.  The serial chain
+// barrier -> LDS round trip -> rcp -> update of block column KQ -> publish is paid once per two pivots.
+//   row factors   F0[p] = x0[p] (-1/d0)  (seed -1/d0 at p = k),     F1[p] = x1'[p] (-1/d1)  (seed -1/d1 at p = k+1)
+//   column factors y0[j] (j > k),   y1'[j] = y1[j] + y0[j] (-e/d0)  (j > k+1)
+//   A[p][j] += M0(p,j) F0[p] y0[j] + M1(p,j) F1[p] y1'[j],   Mq(p,j) = (p <= k+q) or (p >= j)
+template <int NT, int KQ, int PAR>
+__device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c, const int kr, const int kend,
+                                           const bool lower_eq) {
+    constexpr int NP = 16 * NT;
+    constexpr int NP2 = (NT + 1) / 2;
+    const int tx = c.tx, ty = c.ty;
+    const float* p0 = c.colbuf + (2 * PAR) * NP;          // column k
+    const float* p1 = c.colbuf + (2 * PAR + 1) * NP;      // column k + 1
+    __syncthreads();
+    const float d0 = p0[16 * KQ + kr], e = p0[16 * KQ + kr + 1], d1raw = p1[16 * KQ + kr + 1];
+    f32x2 F0[NP2], F1[NP2];
+    float y0[NT], y1[NT];
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) {
+        F0[m][0] = p0[ty + 32 * m];
+        F0[m][1] = (2 * m + 1 < NT) ? p0[ty + 32 * m + 16] : 0.f;
+        F1[m][0] = p1[ty + 32 * m];
+        F1[m][1] = (2 * m + 1 < NT) ? p1[ty + 32 * m + 16] : 0.f;
+    }
+#pragma unroll
+    for (int ji = KQ; ji < NT; ++ji) {
+        y0[ji] = p0[tx + 16 * ji];
+        y1[ji] = p1[tx + 16 * ji];
+    }
+    const float nrd0 = -__builtin_amdgcn_rcpf(d0);
+    const float g0 = e * nrd0;                                         // -e / d0
+    const float d1 = __builtin_fmaf(g0, e, d1raw);
+    const float nrd1 = -__builtin_amdgcn_rcpf(d1);
+    const f32x2 ev = {e, e};
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) F0[m] *= nrd0;
+    F0[KQ >> 1][KQ & 1] = (ty == kr) ? nrd0 : F0[KQ >> 1][KQ & 1];     // row k seeds U_kj
+#pragma unroll
+    for (int m = 0; m < NP2; ++m) F1[m] = __builtin_elementwise_fma(F0[m], ev, F1[m]) * nrd1;      // x1' (-1/d1)
+    F1[KQ >> 1][KQ & 1] = (ty == kr + 1) ? nrd1 : F1[KQ >> 1][KQ & 1]; // row k+1 seeds U_{k+1,j}
+#pragma unroll
+    for (int ji = KQ; ji < NT; ++ji) y1[ji] = __builtin_fmaf(y0[ji], g0, y1[ji]);                  // y1'
+    y0[KQ] = (tx > kr) ? y0[KQ] : 0.f;                                 // pivot k updates columns j > k
+    y1[KQ] = (tx > kr + 1) ? y1[KQ] : 0.f;                             // pivot k+1 updates columns j > k+1
+    y0[NT - 1] = c.col_ok ? y0[NT - 1] : 0.f;                          // padding columns j >= N
+    y1[NT - 1] = c.col_ok ? y1[NT - 1] : 0.f;
+    const bool le0 = ty <= kr, le1 = ty <= kr + 1;
+    const float f0K = F0[KQ >> 1][KQ & 1], f1K = F1[KQ >> 1][KQ & 1];
+    const float f0_le = le0 ? f0K : 0.f, f0_dd = (le0 || lower_eq) ? f0K : 0.f;
+    const float f1_le = le1 ? f1K : 0.f, f1_dd = (le1 || lower_eq) ? f1K : 0.f;
+    auto column = [&](const int ji) {                                  // ji is an unrolled constant
+        const f32x2 y0v = {y0[ji], y0[ji]}, y1v = {y1[ji], y1[ji]};
+        const float s0 = (ji == KQ) ? f0_dd : f0_le, s1 = (ji == KQ) ? f1_dd : f1_le;
+#pragma unroll
+        for (int m = 0; m < NP2; ++m) {
+            const int q0 = 2 * m, q1 = 2 * m + 1;
+            // 0 none, 1 plain, 2 row block KQ
+            const int k0 = (q0 < KQ) ? 1 : (q0 == KQ) ? 2 : (q0 < ji) ? 0 : 1;
+            const int k1 = (q1 >= NT) ? 0 : (q1 < KQ) ? 1 : (q1 == KQ) ? 2 : (q1 < ji) ? 0 : 1;
+            if (k0 == 1 && k1 == 1) {
+                A2[m][ji] = __builtin_elementwise_fma(F0[m], y0v, A2[m][ji]);
+                A2[m][ji] = __builtin_elementwise_fma(F1[m], y1v, A2[m][ji]);
+            } else if (k0 != 0 && k1 != 0) {
+                const f32x2 v0 = {k0 == 2 ? s0 : F0[m][0], k1 == 2 ? s0 : F0[m][1]};
+                const f32x2 v1 = {k0 == 2 ? s1 : F1[m][0], k1 == 2 ? s1 : F1[m][1]};
+                A2[m][ji] = __builtin_elementwise_fma(v0, y0v, A2[m][ji]);
+                A2[m][ji] = __builtin_elementwise_fma(v1, y1v, A2[m][ji]);
+            } else if (k0 != 0) {
+                A2[m][ji][0] = __builtin_fmaf(k0 == 2 ? s0 : F0[m][0], y0[ji], A2[m][ji][0]);
+                A2[m][ji][0] = __builtin_fmaf(k0 == 2 ? s1 : F1[m][0], y1[ji], A2[m][ji][0]);
+            } else if (k1 != 0) {
+                A2[m][ji][1] = __builtin_fmaf(k1 == 2 ? s0 : F0[m][1], y0[ji], A2[m][ji][1]);
+                A2[m][ji][1] = __builtin_fmaf(k1 == 2 ? s1 : F1[m][1], y1[ji], A2[m][ji][1]);
+            }
+        }
+    };
+    column(KQ);
+    if (kr + 3 < kend) {                                               // another full pair follows: publish it now
+        float* n0 = c.colbuf + (2 * (PAR ^ 1)) * NP;
+        if (tx == kr + 2 || tx == kr + 3) {
+            float* nb = n0 + (tx - (kr + 2)) * NP;
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
+        }
+    }
+#pragma unroll
+    for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
+}
+
 // One block column KQ of the sweep: k = 16*KQ + kr, kr = 0 .. min(16, N - 16*KQ) - 1.
 // Columns are scaled LAZILY (the registers keep the raw columns; 1 / L_kk is applied once after the sweep), and the
 // pivots themselves are not inspected here: d_k stays in the diagonal slot (k, k), from which the caller takes
 // log det, the column scales and the first non-positive pivot after the sweep.
 template <int NT, int KQ>
 __device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c) {
+    constexpr int NP = 16 * NT;
     const int kend = min(16, c.N - 16 * KQ);
     const int tx = c.tx, ty = c.ty;
     const bool lower_eq = ty >= tx;
@@ -152,6 +244,32 @@ __device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const
     // half then holds Schur-complement values nobody reads, and is cleared here, when the block becomes the pivot
     // block and its upper half starts to collect U.
     if constexpr (KQ > 0) AE(KQ, KQ) = lower_eq ? AE(KQ, KQ) : 0.f;
+#if !defined(DKT_MLL_SINGLE_STEP)
+    const int npair2 = kend & ~1;                        // pivots handled two at a time
+    if (npair2 > 0) {
+        if (tx < 2) {
+            float* nb = c.colbuf + tx * NP;
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
+        }
+        for (int kr = 0; kr < npair2; kr += 4) {
+            sweep_pair<NT, KQ, 0>(A2, c, kr, npair2, lower_eq);
+            if (kr + 2 < npair2) sweep_pair<NT, KQ, 1>(A2, c, kr + 2, npair2, lower_eq);
+        }
+    }
+    if (kend & 1) {                                      // odd leftover pivot of the last block
+        const int kr = kend - 1;
+        float* sb = c.colbuf + (((npair2 >> 1) & 1) ? 0 : 2) * NP;     // a vector the last pair did not read
+        if (tx == kr) {
+#pragma unroll
+            for (int pi = 0; pi < NT; ++pi) sb[ty + 16 * pi] = AE(pi, KQ);
+        }
+        __syncthreads();
+        PivCol<NT> s0, s1;
+        load_pivcol<NT, KQ>(s0, sb, tx, ty, kr);
+        sweep_step<NT, KQ, 0>(A2, c, s0, s1, kr, kend, lower_eq);
+    }
+#else
     if (tx == 0) {
 #pragma unroll
         for (int pi = 0; pi < NT; ++pi) c.colbuf[ty + 16 * pi] = AE(pi, KQ);
@@ -163,6 +281,7 @@ __device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const
         sweep_step<NT, KQ, 0>(A2, c, s0, s1, kr, kend, lower_eq);
         if (kr + 1 < kend) sweep_step<NT, KQ, 1>(A2, c, s1, s0, kr + 1, kend, lower_eq);
     }
+#endif
 }
 
 template <int NT, int KQ>
@@ -289,7 +408,7 @@ template <int NT, bool WANT_GRAD, bool WANT_CHOL>
 #endif
 __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_REG_MINW : 2)) void mll_reg_kernel(MllArgs a) {
     constexpr int NP = 16 * NT;
-    __shared__ float colbuf[2 * NP];
+    __shared__ float colbuf[4 * NP];           // two double-buffered pivot-column pairs
     __shared__ float wv[NP];
     __shared__ float dgv[NP];
     __shared__ __attribute__((aligned(16))) float alv[NP];
