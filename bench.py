@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=2048, help="episodes per step per GPU")
+    ap.add_argument("--episodes", type=int, default=8192, help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192})")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
