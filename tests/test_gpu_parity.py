@@ -156,7 +156,10 @@ def _episode_case(c, per, d, seed, corr=0, b=2):
 @pytest.mark.parametrize("c,per,d,corr", [(1, 1, 8, 0), (2, 1, 8, 0), (5, 1, 64, 0), (5, 5, 64, 0), (5, 17, 512, 0),
                                           (3, 5, 16, 0), (4, 4, 16, 0), (1, 17, 16, 0), (3, 37, 24, 0), (4, 28, 24, 0), (7, 18, 24, 0), (1, 127, 24, 0),
                                           (5, 21, 64, 0), (5, 21, 1600, 5), (5, 26, 40, 0), (5, 38, 32, 0),
-                                          (4, 50, 64, 0), (20, 16, 512, 0), (20, 21, 512, 20)])
+                                          (4, 50, 64, 0), (20, 16, 512, 0), (20, 21, 512, 20),
+                                          # block-column boundaries of the two-pivots-per-barrier sweep (even / odd tails)
+                                          (1, 3, 8, 0), (1, 31, 16, 0), (1, 32, 16, 0), (1, 33, 16, 0), (2, 32, 16, 0), (1, 65, 16, 0),
+                                          (2, 48, 16, 0), (1, 97, 16, 0), (1, 113, 16, 0), (1, 126, 16, 0)])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, force_generic):
     """force_generic=False: register-resident kernel for N <= 126, generic LDS/global kernel above;
