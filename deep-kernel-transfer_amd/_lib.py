@@ -16,8 +16,9 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
 SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_blk.hip", "dkt_mll_wave.hip", "dkt_predict.hip",
-           "dkt_diag.hip"]     # dkt_diag: measurement-only kernels, outside the ABI header
-HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"), os.path.join(INCLUDE, "dkt_abi.h")]
+           "dkt_frontend.hip", "dkt_diag.hip"]     # dkt_diag: measurement-only kernels, outside the ABI header
+HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"),
+           os.path.join(CSRC, "dkt_split.h"), os.path.join(INCLUDE, "dkt_abi.h")]
 
 _c_p = ctypes.c_void_p
 _c_i = ctypes.c_int
@@ -37,6 +38,10 @@ SIGNATURES = {
     "dkt_sqdist_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_predict_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_predict_var_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_bn_stats_f32": (_c_i, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_gram_bn_f32": (_c_i, [_c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_gram_bn_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                   _c_i, _c_i, _c_i, _c_p]),
 }
 
 _lock = threading.Lock()

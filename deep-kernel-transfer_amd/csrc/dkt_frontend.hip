@@ -1,0 +1,529 @@
+// dkt_frontend.hip -- the BNCosSim front half of the deep kernel fused into the Gram build:
+//   reference  z = trunk(x) ending in bn_out = BatchNorm1d(D)   (methods/DKT.py:48)
+//              z = F.normalize(z, p=2, dim=1)                   (methods/DKT.py:141-142, 174-175, 236-237)
+//              K = LinearKernel(z, z)                           (methods/DKT.py:375-378)
+// here       dkt_bn_stats_f32   : per-episode batch statistics of the raw trunk output X[b] (train mode), folded into
+//                                 an affine map  y = a x + s   (a = gamma rstd, s = beta - mean a)
+//            dkt_gram_bn_f32    : E = Zn Zn^T with Zn_i = y_i / max(||y_i||, 1e-12) -- the affine map is applied while the
+//                                 slice is staged, the row norms come out of the diagonal of G' = Y Y^T, Zn is never written
+// (dkt_gram_bn_bwd_f32, the matching backward, lives below.)
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+#include "dkt_common.h"
+#include "dkt_tiles.h"
+#include "dkt_split.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+__device__ __forceinline__ brsrc_t mk_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(brsrc_t r, int voff, int soff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+constexpr int OOB = 0x7ffffff0;
+
+// ---------------------------------------------------------------------------------------------
+// Batch statistics: grid (ceil(D/4 / 256), B); a thread owns 4 adjacent features and walks the N rows of its episode
+// (float4 loads, 4 KB contiguous per wave and row).  Sums are taken about the first row (shifted data): no
+// catastrophic cancellation in  E[x^2] - E[x]^2  for features with a large common offset (ReLU outputs).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ s,
+                                                       float* __restrict__ var_unbiased, int N, int D) {
+    const int b = blockIdx.y;
+    const int d = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (d >= D) return;
+    const float* Xb = X + (size_t)b * N * D + d;
+    const float4 x0 = *reinterpret_cast<const float4*>(Xb);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 1; i < N; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(Xb + (size_t)i * D);
+        const float e[4] = {v.x - x0.x, v.y - x0.y, v.z - x0.z, v.w - x0.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s1[t] += e[t];
+            s2[t] = __builtin_fmaf(e[t], e[t], s2[t]);
+        }
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float x0v[4] = {x0.x, x0.y, x0.z, x0.w};
+    float mu[4], rs[4], av[4], sv[4], vu[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float m1 = s1[t] * inv_n;
+        const float var = fmaxf(__builtin_fmaf(-m1, m1, s2[t] * inv_n), 0.f);    // biased variance (normalisation)
+        mu[t] = x0v[t] + m1;
+        rs[t] = 1.0f / sqrtf(var + eps);
+        const float g = gamma ? gamma[d + t] : 1.0f, be = beta ? beta[d + t] : 0.0f;
+        av[t] = g * rs[t];
+        sv[t] = __builtin_fmaf(-mu[t], av[t], be);
+        vu[t] = (N > 1) ? var * (float)N / (float)(N - 1) : var;                  // what torch feeds the running variance
+    }
+    const size_t o = (size_t)b * D + d;
+    *reinterpret_cast<float4*>(mean + o) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+    *reinterpret_cast<float4*>(rstd + o) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+    *reinterpret_cast<float4*>(a + o) = make_float4(av[0], av[1], av[2], av[3]);
+    *reinterpret_cast<float4*>(s + o) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+    if (var_unbiased) *reinterpret_cast<float4*>(var_unbiased + o) = make_float4(vu[0], vu[1], vu[2], vu[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused forward: one 256-thread workgroup per episode, the structure of gram_sym_ep_bf16x3_kernel<NT, 1, 1>.
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_sym_ep_kernel(const float* __restrict__ X, const float* __restrict__ A,
+                                                                              const float* __restrict__ S, long ab_bstride,
+                                                                              float* __restrict__ E, float* __restrict__ rnorm,
+                                                                              int N, int D) {
+    constexpr int NP = 16 * NT;
+    constexpr int BK = 32;
+    constexpr int SPLD = BK + 16;
+    constexpr int V4_PER_ROW = BK / 4;
+    constexpr int NV4 = NP * V4_PER_ROW;
+    constexpr int NLD = (NV4 + 255) / 256;
+    constexpr int NPL = NLD * 256 / V4_PER_ROW;
+    constexpr int PLANE = NPL * SPLD;
+    __shared__ __attribute__((aligned(16))) __bf16 zp[3 * PLANE];
+    __shared__ float rho[NP];
+
+    const int b = blockIdx.x;
+    float* Eb = E + (size_t)b * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const brsrc_t xr = mk_rsrc(X + (size_t)b * N * D, N * D * 4);
+    const brsrc_t ar = mk_rsrc(A + (size_t)b * ab_bstride, D * 4);
+    const brsrc_t sr = mk_rsrc(S + (size_t)b * ab_bstride, D * 4);
+    const int c4 = tid % V4_PER_ROW;                     // the thread's 4 features of every slice (same for all its rows)
+    int voff[NLD];
+    bool rowok[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int row = (tid + 256 * i) / V4_PER_ROW;
+        rowok[i] = row < N;
+        voff[i] = rowok[i] ? (row * D + 4 * c4) * 4 : OOB;
+    }
+    float4 rg[NLD], av, sv;
+    auto gload = [&](int k0) {
+        const bool in = k0 + 4 * c4 < D;                 // ragged last slice: features past D read as zeros (a = s = 0 too)
+        av = bload4(ar, in ? 16 * c4 : OOB, k0 * 4);
+        sv = bload4(sr, in ? 16 * c4 : OOB, k0 * 4);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) rg[i] = bload4(xr, in ? voff[i] : OOB, k0 * 4);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int row = (tid + 256 * i) / V4_PER_ROW;
+            float4 y;
+            y.x = rowok[i] ? __builtin_fmaf(av.x, rg[i].x, sv.x) : 0.f;      // padded rows must stay 0 (their y would be s)
+            y.y = rowok[i] ? __builtin_fmaf(av.y, rg[i].y, sv.y) : 0.f;
+            y.z = rowok[i] ? __builtin_fmaf(av.z, rg[i].z, sv.z) : 0.f;
+            y.w = rowok[i] ? __builtin_fmaf(av.w, rg[i].w, sv.w) : 0.f;
+            bf16x4 h, m, l;
+            split3(y, h, m, l);
+            __bf16* dst = &zp[row * SPLD + 4 * c4];
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+        }
+    };
+
+    f32x4 acc[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (D + BK - 1) / BK;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (wave == 0) {
+            if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, SPLD, PLANE>(acc, zp, r16, q);
+        } else if (wave == 1) {
+            if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, SPLD, PLANE>(acc, zp, r16, q);
+        } else if (wave == 2) {
+            if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, SPLD, PLANE>(acc, zp, r16, q);
+        } else {
+            if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, SPLD, PLANE>(acc, zp, r16, q);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) lstore();
+        __syncthreads();
+    }
+
+    // ---- row norms from the diagonal of G' = Y Y^T, then E_ij = G'_ij rho_i rho_j ----
+    auto put_diag = [&](const f32x4& t, int row_blk) {   // diagonal tile (row_blk, row_blk): lane (r16, q) holds rows 4q+reg, col r16
+        if ((r16 >> 2) == q) {
+            const int rr = r16 & 3;
+            const float v = rr == 0 ? t[0] : rr == 1 ? t[1] : rr == 2 ? t[2] : t[3];
+            rho[16 * row_blk + r16] = 1.0f / fmaxf(sqrtf(fmaxf(v, 0.f)), 1e-12f);    // F.normalize: x / max(||x||, 1e-12)
+        }
+    };
+    auto diag_of = [&](auto w) {
+        constexpr int W = decltype(w)::value;
+        constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
+        if constexpr (RA >= 0) put_diag(acc[RA], RA);
+        if constexpr (RB >= 0) put_diag(acc[RA + 1 + RB], RB);
+    };
+    if (wave == 0) diag_of(std::integral_constant<int, 0>{});
+    else if (wave == 1) diag_of(std::integral_constant<int, 1>{});
+    else if (wave == 2) diag_of(std::integral_constant<int, 2>{});
+    else diag_of(std::integral_constant<int, 3>{});
+    __syncthreads();
+    if (tid < N) rnorm[(size_t)b * N + tid] = rho[tid];
+    auto finish = [&](auto w) {
+        constexpr int W = decltype(w)::value;
+        constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
+        if constexpr (RA >= 0) {
+#pragma unroll
+            for (int tj = 0; tj <= RA; ++tj) {
+                const float rj = rho[16 * tj + r16];
+                const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * RA + 4 * q]);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[tj][reg] *= ri[reg] * rj;
+            }
+            sym_store_row<RA>(acc, Eb, N, r16, q);
+        }
+        if constexpr (RB >= 0) {
+#pragma unroll
+            for (int tj = 0; tj <= RB; ++tj) {
+                const float rj = rho[16 * tj + r16];
+                const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * RB + 4 * q]);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[RA + 1 + tj][reg] *= ri[reg] * rj;
+            }
+            sym_store_row<RB>(acc + RA + 1, Eb, N, r16, q);
+        }
+    };
+    if (wave == 0) finish(std::integral_constant<int, 0>{});
+    else if (wave == 1) finish(std::integral_constant<int, 1>{});
+    else if (wave == 2) finish(std::integral_constant<int, 2>{});
+    else finish(std::integral_constant<int, 3>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused backward.  With A = g (W + W^T) (W = d obj / d E, g = upstream scale of the episode):
+//   dZn = A Zn                                  the Gram backward, Zn re-created from X while it is staged
+//   dY_i = rho_i (dZn_i - zn_i t_i),  t_i = zn_i . dZn_i = sum_j A_ij E_ij      (F.normalize backward; t needs no D-loop)
+//   dbeta_d = sum_i dY_id,  dgamma_d = sum_i dY_id xh_id,  xh = (x - mean) rstd  (BatchNorm1d backward, batch statistics)
+//   dX_id = a_d (dY_id - dbeta_d / N - xh_id dgamma_d / N)
+// Structure of gram_bwd_ep_bf16x3_kernel<NT, 1, 1>: NT waves, wave w owns output rows [16w, 16w+16), its A fragments
+// stay in registers; per 64-feature slab the MFMA result dZn is finished IN REGISTERS: the column sums over the N rows
+// are reduced over the 4 row groups of a wave with shuffles and over the waves through a small LDS table that rides on
+// the slab loop's two existing barriers.  X is read once for staging and once (L2-hot) for the epilogue; dX is written once.
+template <int NT, bool TRAIN_BN>
+__global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float* __restrict__ W, const float* __restrict__ Eg,
+                                                                    const float* __restrict__ X, const float* __restrict__ Aa,
+                                                                    const float* __restrict__ Ss, long ab_bstride,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ rnorm, const float* __restrict__ ep_scale,
+                                                                    float* __restrict__ dX, float* __restrict__ dgamma_part,
+                                                                    float* __restrict__ dbeta_part, int N, int D) {
+    constexpr int NP = 16 * NT;
+    constexpr int NTH = 64 * NT;
+    constexpr int BD = 64;
+    constexpr int KS = (NP + 31) / 32;
+    constexpr int KP = 32 * KS;
+    constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);
+    constexpr int RS = 8 * SU;
+    constexpr int PLANE = BD * RS;
+    constexpr int IMG = 3 * PLANE * 2;                   // bytes of the [d][j] image
+    constexpr int STG = (IMG > NP * NP * 4) ? IMG : NP * NP * 4;     // the image region also stages W, then E (N x N fp32)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STG];
+    __shared__ float rl[NP], tl[NP];
+    __shared__ __attribute__((aligned(16))) float cs[NT][BD][2];
+    __bf16* zt = reinterpret_cast<__bf16*>(smem);
+    float* wl = reinterpret_cast<float*>(smem);
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float g = ep_scale ? ep_scale[b] : 1.0f;
+    const float inv_n = 1.0f / (float)N;
+    const brsrc_t xr = mk_rsrc(X + (size_t)b * N * D, N * D * 4);
+    const brsrc_t ar = mk_rsrc(Aa + (size_t)b * ab_bstride, D * 4);
+    const brsrc_t sr = mk_rsrc(Ss + (size_t)b * ab_bstride, D * 4);
+    const brsrc_t mr = mk_rsrc(TRAIN_BN ? mean + (size_t)b * D : Aa, D * 4);
+    const brsrc_t rr_ = mk_rsrc(TRAIN_BN ? rstd + (size_t)b * D : Aa, D * 4);
+    float* dXb = dX + (size_t)b * N * D;
+
+    // staging task of this thread: rows 4 jg .. 4 jg + 3, features 4 d4 .. 4 d4 + 3 of the slab
+    const int d4 = tid & 15, jg = tid >> 4;
+    int voff[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) voff[rr] = (4 * jg + rr < N) ? ((4 * jg + rr) * D + 4 * d4) * 4 : OOB;
+    float4 rg[4], sa, ss;
+    auto gload = [&](int d0) {
+        const bool in = d0 + 4 * d4 < D;
+        sa = bload4(ar, in ? 16 * d4 : OOB, d0 * 4);
+        ss = bload4(sr, in ? 16 * d4 : OOB, d0 * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rg[rr] = bload4(xr, in ? voff[rr] : OOB, d0 * 4);
+    };
+    const int nslab = (D + BD - 1) / BD;
+    gload(0);                                            // flies while W and E are staged
+
+    // ---- A fragments from W (as in gram_bwd_ep_bf16x3_kernel), then t_i = sum_k A_ik E_ik with E staged the same way ----
+    bf16x8 ah[KS], am[KS], al[KS];
+    const int nn = N * N;
+    const int row = wave * 16 + r16;
+    {
+        const float* Wb = W + (size_t)b * nn;
+        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * q + e;
+                float v = 0.f;
+                if (row < N && k < N) v = g * (wl[row * N + k] + wl[k * N + row]);
+                __bf16 h, m, l;
+                split3s(v, h, m, l);
+                ah[ks][e] = h;
+                am[ks][e] = m;
+                al[ks][e] = l;
+            }
+        }
+        __syncthreads();
+        const float* Eb = Eg + (size_t)b * nn;
+        for (int i = tid; i < nn; i += NTH) wl[i] = Eb[i];
+        if (tid < NP) rl[tid] = (tid < N) ? rnorm[(size_t)b * N + tid] : 0.f;      // padded rows: rho = 0 -> dY = 0
+        __syncthreads();
+        float tp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * q + e;
+                const float aik = (float)ah[ks][e] + (float)am[ks][e] + (float)al[ks][e];      // the split is exact
+                if (row < N && k < N) tp = __builtin_fmaf(aik, wl[row * N + k], tp);
+            }
+        }
+        tp += __shfl_xor(tp, 16, DKT_WAVE);
+        tp += __shfl_xor(tp, 32, DKT_WAVE);
+        if (q == 0) tl[row] = tp;
+        __syncthreads();
+    }
+    // this lane's output rows i = 16 wave + 4 q + reg: rho_i, t_i stay in registers for the whole episode
+    float rho4[4], t4[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        rho4[reg] = rl[16 * wave + 4 * q + reg];
+        t4[reg] = tl[16 * wave + 4 * q + reg];
+    }
+    // rho_j of the staging task's rows
+    float rhoj[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) rhoj[rr] = rl[4 * jg + rr];
+    __syncthreads();                                     // everyone is done with the staged E before the image is written
+    if constexpr (KP > NP) {                             // columns j in [NP, KP) of the image are never staged: zero them once
+        constexpr int PADV = (KP - NP) / 8;
+        for (int i = tid; i < 3 * BD * PADV; i += NTH) {
+            const int rowi = i / PADV, pc = i % PADV;
+            *reinterpret_cast<float4*>(zt + (size_t)rowi * RS + NP + 8 * pc) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    auto lstore = [&]() {                                // zn = (a x + s) rho_j, split, transposed 8-byte stores
+        const float av[4] = {sa.x, sa.y, sa.z, sa.w}, sv[4] = {ss.x, ss.y, ss.z, ss.w};
+        const float x[4][4] = {{rg[0].x, rg[1].x, rg[2].x, rg[3].x}, {rg[0].y, rg[1].y, rg[2].y, rg[3].y},
+                               {rg[0].z, rg[1].z, rg[2].z, rg[3].z}, {rg[0].w, rg[1].w, rg[2].w, rg[3].w}};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float zn = __builtin_fmaf(av[t], x[t][rr], sv[t]) * rhoj[rr];
+                __bf16 hh, mm, ll;
+                split3s(zn, hh, mm, ll);
+                h[rr] = hh;
+                m[rr] = mm;
+                l[rr] = ll;
+            }
+            __bf16* dst = zt + (16 * t + d4) * RS + 4 * jg;
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+        }
+    };
+
+    __syncthreads();                                     // pad columns zeroed
+    lstore();
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int d0 = sl * BD;
+        if (sl + 1 < nslab) gload(d0 + BD);
+        // epilogue operands of this lane's 4 rows x 4 features (d = d0 + 4 r16 + t): issued early, consumed after the MFMAs
+        const bool din = d0 + 4 * r16 < D;
+        float4 xe[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = 16 * wave + 4 * q + reg;
+            xe[reg] = bload4(xr, (din && i < N) ? (i * D + 4 * r16) * 4 : OOB, d0 * 4);
+        }
+        const float4 ea = bload4(ar, din ? 16 * r16 : OOB, d0 * 4), es = bload4(sr, din ? 16 * r16 : OOB, d0 * 4);
+        float4 em = make_float4(0.f, 0.f, 0.f, 0.f), er = em;
+        if constexpr (TRAIN_BN) {
+            em = bload4(mr, din ? 16 * r16 : OOB, d0 * 4);
+            er = bload4(rr_, din ? 16 * r16 : OOB, d0 * 4);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const __bf16* base = zt + r16 * RS + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const __bf16* p = base + 16 * t * RS + 32 * ks;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(p);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(p + PLANE);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(p + 2 * PLANE);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[t], 0, 0, 0);
+            }
+        }
+        // dY (overwrites acc) and the normalised inputs xh (kept for the second half)
+        const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, esv[4] = {es.x, es.y, es.z, es.w};
+        const float emv[4] = {em.x, em.y, em.z, em.w}, erv[4] = {er.x, er.y, er.z, er.w};
+        float xh[4][4];                                  // [t][reg]
+        float c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float xv[4] = {xe[reg].x, xe[reg].y, xe[reg].z, xe[reg].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float zn = __builtin_fmaf(eav[t], xv[t], esv[t]) * rho4[reg];
+                const float dy = rho4[reg] * __builtin_fmaf(-zn, t4[reg], acc[t][reg]);
+                acc[t][reg] = dy;
+                if constexpr (TRAIN_BN) {
+                    xh[t][reg] = (xv[t] - emv[t]) * erv[t];
+                    c1[t] += dy;
+                    c2[t] = __builtin_fmaf(dy, xh[t][reg], c2[t]);
+                }
+            }
+        }
+        if constexpr (TRAIN_BN) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                // over the 4 row groups q of the wave
+                c1[t] += __shfl_xor(c1[t], 16, DKT_WAVE);
+                c1[t] += __shfl_xor(c1[t], 32, DKT_WAVE);
+                c2[t] += __shfl_xor(c2[t], 16, DKT_WAVE);
+                c2[t] += __shfl_xor(c2[t], 32, DKT_WAVE);
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    cs[wave][4 * r16 + t][0] = c1[t];
+                    cs[wave][4 * r16 + t][1] = c2[t];
+                }
+            }
+        }
+        __syncthreads();                                 // image consumed; column partials of every wave published
+        if (sl + 1 < nslab) lstore();
+        float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (TRAIN_BN) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {               // fixed order over the waves: deterministic
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    m1[t] += cs[w][4 * r16 + t][0];
+                    m2[t] += cs[w][4 * r16 + t][1];
+                }
+            }
+            if (wave == 0 && q == 0 && din) {
+                const size_t o = (size_t)b * D + d0 + 4 * r16;
+                *reinterpret_cast<float4*>(dbeta_part + o) = make_float4(m1[0], m1[1], m1[2], m1[3]);
+                *reinterpret_cast<float4*>(dgamma_part + o) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = 16 * wave + 4 * q + reg;
+            float o[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = acc[t][reg];
+                if constexpr (TRAIN_BN) v = v - m1[t] * inv_n - xh[t][reg] * (m2[t] * inv_n);
+                o[t] = eav[t] * v;
+            }
+            if (i < N && din) *reinterpret_cast<float4*>(dXb + (size_t)i * D + d0 + 4 * r16) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();                                 // next image staged; cs free again
+    }
+}
+
+template <int NT>
+void launch_gram_bn_bwd(const float* W, const float* E, const float* X, const float* a, const float* s, long abs, const float* mean,
+                        const float* rstd, const float* rnorm, const float* sc, float* dX, float* dg, float* db, int B, int N, int D,
+                        bool train_bn, hipStream_t st) {
+    if (train_bn) hipLaunchKernelGGL((gram_bn_bwd_ep_kernel<NT, true>), dim3(B), dim3(64 * NT), 0, st, W, E, X, a, s, abs, mean, rstd, rnorm, sc, dX, dg, db, N, D);
+    else hipLaunchKernelGGL((gram_bn_bwd_ep_kernel<NT, false>), dim3(B), dim3(64 * NT), 0, st, W, E, X, a, s, abs, mean, rstd, rnorm, sc, dX, dg, db, N, D);
+}
+
+template <int NT>
+void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st) {
+    hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D);
+}
+
+}  // namespace
+
+extern "C" int dkt_bn_stats_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                float* a, float* s, float* var_unbiased, int B, int N, int D, void* stream) {
+    if (!X || !mean || !rstd || !a || !s || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if ((D & 3) || ((uintptr_t)X & 15)) return DKT_ERR_BAD_ARG;
+    if (B > 65535) return DKT_ERR_TOO_LARGE;
+    dim3 grid((D / 4 + 255) / 256, B);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, gamma, beta, eps, mean, rstd, a, s, var_unbiased, N, D);
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_gram_bn_f32(const float* X, const float* a, const float* s, long ab_bstride, float* E, float* rnorm,
+                               int B, int N, int D, void* stream) {
+    if (!X || !a || !s || !E || !rnorm || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || (ab_bstride & 3)) return DKT_ERR_BAD_ARG;
+    if (N > 128) return DKT_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((N + 15) / 16) {
+        case 1: launch_gram_bn<1>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 2: launch_gram_bn<2>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 3: launch_gram_bn<3>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 4: launch_gram_bn<4>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 5: launch_gram_bn<5>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 6: launch_gram_bn<6>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        case 7: launch_gram_bn<7>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+        default: launch_gram_bn<8>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const float* a, const float* s, long ab_bstride,
+                                   const float* mean, const float* rstd, const float* rnorm, const float* ep_scale, float* dX,
+                                   float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream) {
+    if (!W || !E || !X || !a || !s || !rnorm || !dX || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    const bool train_bn = mean != nullptr;
+    if (train_bn && (!rstd || !dgamma_part || !dbeta_part)) return DKT_ERR_BAD_ARG;
+    if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)dX & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || (ab_bstride & 3)) return DKT_ERR_BAD_ARG;
+    if (N > 128) return DKT_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((N + 15) / 16) {
+        case 1: launch_gram_bn_bwd<1>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 2: launch_gram_bn_bwd<2>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 3: launch_gram_bn_bwd<3>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 4: launch_gram_bn_bwd<4>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 5: launch_gram_bn_bwd<5>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 6: launch_gram_bn_bwd<6>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        case 7: launch_gram_bn_bwd<7>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+        default: launch_gram_bn_bwd<8>(W, E, X, a, s, ab_bstride, mean, rstd, rnorm, ep_scale, dX, dgamma_part, dbeta_part, B, N, D, train_bn, st); break;
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -259,7 +259,8 @@ __device__ __forceinline__ void sweep_block(f32x2 (&A2)[(NT + 1) / 2][NT], const
     }
     if (kend & 1) {                                      // odd leftover pivot of the last block
         const int kr = kend - 1;
-        float* sb = c.colbuf + (((npair2 >> 1) & 1) ? 0 : 2) * NP;     // a vector the last pair did not read
+        // a vector the last pair did NOT read: pair p reads vectors 2 (p & 1), 2 (p & 1) + 1; the last pair is p = npair2/2 - 1
+        float* sb = c.colbuf + (((npair2 >> 1) & 1) ? 2 : 0) * NP;
         if (tx == kr) {
 #pragma unroll
             for (int pi = 0; pi < NT; ++pi) sb[ty + 16 * pi] = AE(pi, KQ);

@@ -1,0 +1,87 @@
+// dkt_split.h -- shared device helpers of the episode-resident kernels that run fp32 contractions on the bf16 MFMA pipe:
+// the exact 3-way bf16 split of an fp32 value, the 6-product tile update with two-level accumulation, and the
+// mirrored store of a tile row of a symmetric result.  Header-only (anonymous namespace: one copy per translation unit).
+#pragma once
+#include "dkt_common.h"
+#include "dkt_tiles.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hi = (__bf16)x[i];
+        const float r1 = x[i] - (float)hi;
+        const __bf16 mi = (__bf16)r1;
+        const float r2 = r1 - (float)mi;
+        h[i] = hi;
+        m[i] = mi;
+        l[i] = (__bf16)r2;
+    }
+}
+
+
+__device__ __forceinline__ void split3s(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+
+// bf16 per LDS row of a plane: BK data + 16 pad -> 96 B (BK = 32) or 160 B (BK = 64): 6 / 10 sixteen-byte units,
+// both == 2 mod 4: conflict-free b128 fragment reads
+
+template <int NT, int RA, int RB, int SPLD, int PLANE>
+__device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* zp, int r16, int q) {
+    const __bf16* base = zp + r16 * SPLD + 8 * q;
+    auto frag = [&](int plane, int blk) { return *reinterpret_cast<const bf16x8*>(base + plane * PLANE + blk * 16 * SPLD); };
+    // Two-level accumulation: the six products of one 32-wide slice are summed in a FRESH accumulator (smallest terms
+    // first) and added to the running tile with v_add_f32.  The bf16 MFMA's final rounding truncates (measured: a
+    // -3e-6 bias on a unit diagonal after 300 chained MFMAs, 10x the logp error of the round-to-nearest fp32 path);
+    // against a slice-sized partial sum that bias is 50x smaller, and the fp32 add rounds to nearest.
+    auto tile = [&](f32x4& c, const bf16x8& ah, const bf16x8& am, const bf16x8& al, int tj) {
+        const bf16x8 bh = frag(0, tj), bm = frag(1, tj), bl = frag(2, tj);
+        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, t, 0, 0, 0);
+        c += t;
+    };
+    {
+        const bf16x8 ah = frag(0, RA), am = frag(1, RA), al = frag(2, RA);
+#pragma unroll
+        for (int tj = 0; tj <= RA; ++tj) tile(acc[tj], ah, am, al, tj);
+    }
+    if constexpr (RB >= 0) {
+        const bf16x8 ah = frag(0, RB), am = frag(1, RB), al = frag(2, RB);
+#pragma unroll
+        for (int tj = 0; tj <= RB; ++tj) tile(acc[RA + 1 + tj], ah, am, al, tj);
+    }
+}
+
+
+template <int ROW>
+__device__ __forceinline__ void sym_store_row(const f32x4* acc, float* Eb, int N, int r16, int q) {
+#pragma unroll
+    for (int tj = 0; tj <= ROW; ++tj) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gi = ROW * 16 + 4 * q + reg, gj = tj * 16 + r16;
+            if (gi < N && gj < N && gj <= gi) {
+                const float v = acc[tj][reg];
+                Eb[gi * N + gj] = v;
+                if (gi != gj) Eb[gj * N + gi] = v;
+            }
+        }
+    }
+}
+
+
+}  // namespace

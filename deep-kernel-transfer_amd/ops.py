@@ -385,6 +385,121 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
         return dz, None, gsv, gmean, gnoise, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------------
+# BNCosSim front half fused into the Gram build (reference methods/DKT.py:48,141-142,375-378)
+# ------------------------------------------------------------------------------------------------------
+def bn_stats(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> dict:
+    """Train-mode BatchNorm1d statistics per episode: x:[B,N,D] -> mean, rstd, a, s, var_unbiased (each [B,D]);
+    y = a x + s is bn_out(x)."""
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    if d % 4:
+        raise RuntimeError("bn_stats: D must be a multiple of 4")
+    gamma = None if gamma is None else _req(gamma.reshape(-1), "gamma", 1)
+    beta = None if beta is None else _req(beta.reshape(-1), "beta", 1)
+    out = {k: torch.empty((b_, d), device=x.device, dtype=torch.float32) for k in ("mean", "rstd", "a", "s", "var_unbiased")}
+    lib = _lib.load()
+    with _timed("dkt_bn_stats_f32"):
+        st = lib.dkt_bn_stats_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(out["mean"]), _p(out["rstd"]), _p(out["a"]),
+                                  _p(out["s"]), _p(out["var_unbiased"]), b_, n, d, _stream())
+    _lib.check(st, "dkt_bn_stats_f32")
+    return out
+
+
+def _ab_stride(a: torch.Tensor, s: torch.Tensor, b_: int, d: int) -> int:
+    if a.shape != s.shape:
+        raise RuntimeError("gram_bn: a and s must have the same shape")
+    if a.dim() == 1 and a.shape[0] == d:
+        return 0
+    if a.dim() == 2 and tuple(a.shape) == (b_, d):
+        return d
+    raise RuntimeError("gram_bn: a / s must be [D] or [B,D]")
+
+
+def gram_bn(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
+    """E[b] = Zn Zn^T with Zn = normalize(a x + s) (never materialised); returns (E [B,N,N], rnorm [B,N])."""
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    if n > 128 or d % 4:
+        raise RuntimeError("gram_bn: needs N <= 128 and D %% 4 == 0 (got N=%d, D=%d)" % (n, d))
+    a = _req(a, "a")
+    s = _req(s, "s")
+    stride = _ab_stride(a, s, b_, d)
+    e = torch.empty((b_, n, n), device=x.device, dtype=torch.float32)
+    rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_gram_bn_f32"):
+        st = lib.dkt_gram_bn_f32(_p(x), _p(a), _p(s), stride, _p(e), _p(rnorm), b_, n, d, _stream())
+    _lib.check(st, "dkt_gram_bn_f32")
+    return e, rnorm
+
+
+def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
+    """Backward of gram_bn (+ train-mode batch statistics when mean/rstd are given): returns (dX, dgamma_part, dbeta_part);
+    the last two are [B,D] per-episode parts (None in eval mode)."""
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    w = _req(w, "w", 3)
+    e = _req(e, "e", 3)
+    a = _req(a, "a")
+    s = _req(s, "s")
+    rnorm = _req(rnorm, "rnorm", 2)
+    stride = _ab_stride(a, s, b_, d)
+    train = mean is not None
+    if train:
+        mean = _req(mean, "mean", 2)
+        rstd = _req(rstd, "rstd", 2)
+    if ep_scale is not None:
+        ep_scale = _req(ep_scale.reshape(-1), "ep_scale", 1)
+    dx = torch.empty_like(x)
+    dg = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
+    db = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
+    lib = _lib.load()
+    with _timed("dkt_gram_bn_bwd_f32"):
+        st = lib.dkt_gram_bn_bwd_f32(_p(w), _p(e), _p(x), _p(a), _p(s), stride, _p(mean), _p(rstd), _p(rnorm), _p(ep_scale),
+                                     _p(dx), _p(dg), _p(db), b_, n, d, _stream())
+    _lib.check(st, "dkt_gram_bn_bwd_f32")
+    return dx, dg, db
+
+
+class _EpisodeLossBnFn(torch.autograd.Function):
+    """Training episode straight from the trunk output X (before bn_out): BatchNorm1d(train) + F.normalize + linear Gram
+    (dkt_bn_stats_f32, dkt_gram_bn_f32) -> MLL (dkt_mll_f32) ; backward dkt_gram_bn_bwd_f32.  The normalised features are
+    never written to memory."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+        st = bn_stats(x, gamma, beta, eps)
+        e, rnorm = gram_bn(x, st["a"], st["s"])
+        out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
+        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        ctx.save_for_backward(x, e, out["w"], st["a"], st["s"], st["mean"], st["rstd"], rnorm, out["dsv"], out["dmean"],
+                              out["dnoise"], cls_weight)
+        ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e, st["mean"], st["var_unbiased"])
+        return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e, st["mean"], st["var_unbiased"]
+
+    @staticmethod
+    def backward(ctx, gobj, *_unused):
+        x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        gobj = gobj.contiguous()
+        dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
+        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
+        ng = ctx.needs_input_grad
+        ggamma = dg.sum(0).reshape(ctx.shapes[3]) if (ng[1] and ctx.shapes[3] is not None) else None
+        gbeta = db.sum(0).reshape(ctx.shapes[4]) if (ng[2] and ctx.shapes[4] is not None) else None
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[5] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[6] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[7] else None
+        return (dx if ng[0] else None), ggamma, gbeta, None, None, gsv, gmean, gnoise, None, None, None
+
+
+def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float = 1e-5, jitter0: float = 1e-6, max_tries: int = 3):
+    """x:[B,N,D] trunk output BEFORE bn_out.  Returns (obj[B], logp, alpha, info, jitter, E, batch_mean[B,D],
+    batch_var_unbiased[B,D]) -- the last two feed the caller's running-statistics update."""
+    return _EpisodeLossBnFn.apply(x, gamma, beta, eps, y, sv, mean, noise, cls_weight, jitter0, max_tries)
+
+
 def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):
     """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E)."""
     return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries)

@@ -143,6 +143,40 @@ int dkt_predict_f32(const float* Ex, const float* alpha, const float* sv, const 
 int dkt_predict_var_f32(const float* Ex, const float* exx, const float* L, const float* sv,
                         const float* noise, float* var, int B, int C, int M, int N, void* stream);
 
+/*
+ * ---- BNCosSim front half fused into the Gram build ------------------------------------
+ * Reference: bn_out = nn.BatchNorm1d(D) appended to the trunk (methods/DKT.py:48), z = F.normalize(trunk(x), p=2, dim=1)
+ * (DKT.py:141-142, 174-175, 236-237), LinearKernel on z (DKT.py:375-378).  X is the trunk output BEFORE bn_out.
+ *
+ * dkt_bn_stats_f32 -- train-mode batch statistics per episode and feature (the "batch" of bn_out is the N images of
+ *   one episode): mean[b,d], rstd[b,d] = 1/sqrt(biased var + eps), the folded affine map  y = a x + s  with
+ *   a = gamma rstd, s = beta - mean a, and the unbiased variance torch feeds the running estimate (may be NULL).
+ *   gamma / beta may be NULL (1 / 0).  D % 4 == 0, X 16-byte aligned.
+ */
+int dkt_bn_stats_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                     float* a, float* s, float* var_unbiased, int B, int N, int D, void* stream);
+
+/*
+ * dkt_gram_bn_f32 -- E[b] = Zn Zn^T,  Zn_i = y_i / max(||y_i||_2, 1e-12),  y = a x + s  applied while X is staged
+ *   (Zn is never written).  a, s: [B,D] with ab_bstride = D (train-mode statistics of dkt_bn_stats_f32) or [D] with
+ *   ab_bstride = 0 (eval mode: a = gamma / sqrt(running_var + eps), s = beta - running_mean a; a = 1, s = 0 for the
+ *   plain cossim kernel).  rnorm[b,i] = 1 / max(||y_i||, 1e-12) is returned for the backward.  N <= 128, D % 4 == 0.
+ */
+int dkt_gram_bn_f32(const float* X, const float* a, const float* s, long ab_bstride, float* E, float* rnorm,
+                    int B, int N, int D, void* stream);
+
+/*
+ * dkt_gram_bn_bwd_f32 -- backward of dkt_gram_bn_f32 (+ the batch-statistics dependence of train-mode BatchNorm1d):
+ *   given W[b] = d obj / d E[b] and the per-episode upstream scale ep_scale[b] (NULL: 1), returns
+ *   dX[B,N,D] = d obj / d X and, when mean/rstd are given (train mode), the per-episode parts
+ *   dgamma_part[b,d] = sum_i dY_id xhat_id, dbeta_part[b,d] = sum_i dY_id (the caller sums over b).
+ *   mean == NULL: the affine map is treated as constant (eval mode / no bn_out), dgamma_part / dbeta_part untouched.
+ * Replaces autograd through matmul, F.normalize and BatchNorm1d (loss.backward(), methods/DKT.py:163).
+ */
+int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const float* a, const float* s, long ab_bstride,
+                        const float* mean, const float* rstd, const float* rnorm, const float* ep_scale, float* dX,
+                        float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,35 @@ def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, force_generi
         assert rel_l2(out["dnoise"][i].cpu().numpy(), dnoise) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("c,per", [(5, 21), (4, 26), (1, 97), (3, 37), (2, 63)])
+def test_mll_full_occupancy_is_race_free(cuda, c, per):
+    """2048 episodes = 4 workgroups per CU, twice over: every LDS hand-off of the sweep (pivot pairs, the odd leftover pivot,
+    block-column prologues, gradient chunks) runs under contention.  Three launches must agree bitwise and sampled
+    episodes must match the oracle (a hand-off race shows up as run-to-run differences in a few dozen episodes)."""
+    n, d, b = c * per, 64, 2048
+    g = torch.Generator(device=cuda).manual_seed(n)
+    z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda), dim=2)
+    e = ops.gram(z)
+    hyp = O.perturbed_hypers(c, 3)
+    y = O.one_vs_rest_targets(c, per)
+    cw = np.full(c, -1.0 / (c * n))
+    args = (e, dev_t(y, cuda), dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda))
+    runs = [ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda)) for _ in range(3)]
+    for k in ("logp", "alpha", "w", "dsv", "dmean", "dnoise"):
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+    assert int(runs[0]["info"].abs().max().item()) == 0
+    e_np = e.cpu().numpy().astype(np.float64)
+    for i in (0, 1, 511, 1024, 1500, 2047):
+        res = O.mll_terms(e_np[i], y, hyp.outputscale, hyp.mean, hyp.noise)
+        assert np.abs((runs[0]["logp"][i].cpu().numpy() - res.logp) / res.logp).max() < MLL_RTOL
+        w_ref, _, _, _ = O.mll_grads(e_np[i], res, hyp.outputscale, hyp.noise, cw)
+        assert rel_l2(runs[0]["w"][i].cpu().numpy(), w_ref) < GRAD_RTOL
+    # every episode against the generic twin (different algorithmic path through LDS)
+    gen = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_generic=True)
+    assert ((runs[0]["logp"] - gen["logp"]).abs() / gen["logp"].abs()).max().item() < 1e-5
+    assert ((runs[0]["w"] - gen["w"]).flatten(1).norm(dim=1) / gen["w"].flatten(1).norm(dim=1)).max().item() < 1e-4
+
+
 @pytest.mark.parametrize("c,per,d,corr", [(5, 21, 64, 0), (5, 21, 1600, 5), (1, 104, 32, 0), (3, 37, 24, 0)])
 def test_mll_wave_per_episode_kernel(cuda, c, per, d, corr, monkeypatch):
     """The barrier-free wave-per-episode kernel (off by default) stays parity-green for its
@@ -434,6 +463,46 @@ def test_full_size_properties_cfg2(cuda):
     assert float((z3.grad - 2.5 * z.grad).norm() / (2.5 * z.grad).norm()) < 1e-4
 
 
+def test_gram_kernels_full_occupancy_are_race_free(cuda):
+    """2048 episodes of the headline shape: every LDS stage buffer hand-off of the streaming kernels under full occupancy.
+    Bitwise repeatable, and sampled episodes equal to float64."""
+    b, n, d = 2048, 105, 1600
+    g = torch.Generator(device=cuda).manual_seed(9)
+    x = torch.randn(b, n, d, generator=g, device=cuda).abs() + 0.5
+    w = torch.randn(b, n, n, generator=g, device=cuda)
+    sc = torch.rand(b, generator=g, device=cuda) + 0.5
+    gamma = torch.rand(d, generator=g, device=cuda) + 0.5
+    beta = torch.randn(d, generator=g, device=cuda) * 0.1
+    z = torch.nn.functional.normalize(x - x.mean(1, keepdim=True), dim=2).contiguous()
+    samples = (0, 777, 2047)
+    e = [ops.gram(z) for _ in range(3)]
+    assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2])
+    dz = [ops.gram_bwd(w, z, sc) for _ in range(3)]
+    assert torch.equal(dz[0], dz[1]) and torch.equal(dz[0], dz[2])
+    st = ops.bn_stats(x, gamma, beta)
+    eb = [ops.gram_bn(x, st["a"], st["s"]) for _ in range(3)]
+    assert torch.equal(eb[0][0], eb[1][0]) and torch.equal(eb[0][0], eb[2][0]) and torch.equal(eb[0][1], eb[2][1])
+    db = [ops.gram_bn_bwd(w, eb[0][0], x, st["a"], st["s"], eb[0][1], st["mean"], st["rstd"], sc) for _ in range(3)]
+    for k in range(3):
+        assert torch.equal(db[0][k], db[1][k]) and torch.equal(db[0][k], db[2][k])
+    for i in samples:
+        zi = z[i].double()
+        assert (e[0][i].double() - zi @ zi.T).abs().max().item() < 2e-6
+        a = (w[i] + w[i].T).double() * sc[i].double()
+        assert float((dz[0][i].double() - a @ zi).norm() / (a @ zi).norm()) < 1e-5
+        # fused front end against float64 autograd of bn_out(train) -> normalize -> <W, E>
+        xi = x[i].double().detach().requires_grad_(True)
+        g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        yi = torch.nn.functional.batch_norm(xi, None, None, g64, b64, True, 0.1, 1e-5)
+        zn = torch.nn.functional.normalize(yi, dim=1)
+        ei = zn @ zn.T
+        assert (eb[0][0][i].double() - ei).abs().max().item() < 2e-6
+        (sc[i].double() * (ei * w[i].double()).sum()).backward()
+        assert float((db[0][0][i].double() - xi.grad).norm() / xi.grad.norm()) < GRAD_RTOL
+        assert float((db[0][1][i].double() - g64.grad).norm() / g64.grad.norm()) < GRAD_RTOL
+        assert float((db[0][2][i].double() - b64.grad).norm() / b64.grad.norm()) < GRAD_RTOL
+
+
 # ----------------------------------------------------------------------------------------------
 # the method surface end to end (DKT class on Conv4S / synthetic Omniglot-shaped images)
 # ----------------------------------------------------------------------------------------------
@@ -481,6 +550,96 @@ def test_dkt_train_step_matches_float64_autograd(cuda):
         assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
         checked += 1
     assert checked >= 18
+
+
+# ----------------------------------------------------------------------------------------------
+# BNCosSim front half fused into the Gram build (bn_out + F.normalize + LinearKernel, DKT.py:48,141-142,375-378)
+# ----------------------------------------------------------------------------------------------
+def _relu_like(rng, b, n, d):
+    """Trunk outputs: non-negative, a large common offset per feature (what BatchNorm has to remove)."""
+    return (np.abs(rng.standard_normal((b, n, d))) * rng.uniform(0.2, 3.0, (1, 1, d)) + rng.uniform(0.0, 5.0, (1, 1, d))).astype(np.float32)
+
+
+@pytest.mark.parametrize("b,n,d", [(2, 5, 12), (3, 25, 64), (2, 85, 512), (2, 105, 1600), (1, 128, 100), (2, 19, 2916)])
+def test_bn_stats_and_fused_gram_train_mode(cuda, b, n, d):
+    rng = np.random.default_rng(n * 31 + d)
+    x = _relu_like(rng, b, n, d)
+    gamma = rng.uniform(0.5, 1.5, d).astype(np.float32)
+    beta = rng.normal(0.0, 0.2, d).astype(np.float32)
+    st = ops.bn_stats(dev_t(x, cuda), dev_t(gamma, cuda), dev_t(beta, cuda), 1e-5)
+    e, rnorm = ops.gram_bn(dev_t(x, cuda), st["a"], st["s"])
+    for i in range(b):
+        y, mu, var_u = O.batchnorm1d_train(x[i].astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+        assert np.abs(st["mean"][i].cpu().numpy() - mu).max() < 1e-5 * (1.0 + np.abs(mu).max())
+        assert rel_l2(st["var_unbiased"][i].cpu().numpy(), var_u) < 2e-5
+        a64 = gamma / np.sqrt(x[i].astype(np.float64).var(0) + 1e-5)
+        assert rel_l2(st["a"][i].cpu().numpy(), a64) < 2e-5
+        zn = O.l2_normalize(y)
+        ref = zn @ zn.T
+        assert np.abs(e[i].cpu().numpy() - ref).max() < 2e-5, np.abs(e[i].cpu().numpy() - ref).max()
+        assert rel_l2(rnorm[i].cpu().numpy(), 1.0 / np.linalg.norm(y, axis=1)) < 2e-5
+    assert torch.equal(e, e.transpose(1, 2))
+
+
+@pytest.mark.parametrize("b,n,d", [(3, 25, 64), (2, 105, 1600), (2, 75, 512)])
+def test_fused_gram_eval_mode_and_plain_cossim(cuda, b, n, d):
+    rng = np.random.default_rng(n + d)
+    x = _relu_like(rng, b, n, d)
+    gamma, beta = rng.uniform(0.5, 1.5, d), rng.normal(0.0, 0.2, d)
+    rm, rv = rng.uniform(0.0, 5.0, d), rng.uniform(0.1, 4.0, d)
+    a = gamma / np.sqrt(rv + 1e-5)
+    s = beta - rm * a
+    e, _ = ops.gram_bn(dev_t(x, cuda), dev_t(a, cuda), dev_t(s, cuda))                    # [D] affine map: running statistics
+    e1, _ = ops.gram_bn(dev_t(x, cuda), torch.ones(d, device=cuda), torch.zeros(d, device=cuda))    # cossim: no bn_out
+    for i in range(b):
+        zn = O.l2_normalize(O.batchnorm1d_eval(x[i].astype(np.float64), rm, rv, gamma, beta))
+        assert np.abs(e[i].cpu().numpy() - zn @ zn.T).max() < 2e-5
+        z1 = O.l2_normalize(x[i].astype(np.float64))
+        assert np.abs(e1[i].cpu().numpy() - z1 @ z1.T).max() < 2e-5
+
+
+@pytest.mark.parametrize("b,c,per,d", [(2, 5, 5, 64), (2, 5, 21, 1600), (3, 5, 17, 512), (2, 3, 6, 40), (1, 2, 64, 128)])
+def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, per, d):
+    """bn_out(train) + F.normalize + Gram + MLL and the whole backward (dX, dgamma, dbeta, hyper-parameters) in the fused
+    kernels vs float64 torch autograd of the reference formulation."""
+    n = c * per
+    rng = np.random.default_rng(b * 100 + n + d)
+    x = _relu_like(rng, b, n, d)
+    gamma = rng.uniform(0.5, 1.5, d).astype(np.float32)
+    beta = rng.normal(0.0, 0.2, d).astype(np.float32)
+    raw_s = rng.normal(0.0, 0.5, c).astype(np.float32)
+    mean = rng.normal(0.0, 0.1, c).astype(np.float32)
+    xt = dev_t(x, cuda).requires_grad_(True)
+    gt, bt = dev_t(gamma, cuda).requires_grad_(True), dev_t(beta, cuda).requires_grad_(True)
+    rst, mt = dev_t(raw_s, cuda).requires_grad_(True), dev_t(mean, cuda).requires_grad_(True)
+    noise = torch.full((c,), 0.1, device=cuda)
+    cls = torch.arange(c, device=cuda).repeat_interleave(per)
+    y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=cuda).unsqueeze(1), 1.0, -1.0).contiguous()
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    obj, logp, alpha, info, jit, e, bmean, bvar = ops.episode_loss_bn(xt, gt, bt, y, torch.nn.functional.softplus(rst), mt, noise, cw)
+    assert int(info.abs().max().item()) == 0
+    w_ep = torch.linspace(0.5, 1.5, b, device=cuda)                # non-uniform upstream gradient per episode
+    (obj * w_ep).sum().backward()
+    # float64 reference
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    g64, b64 = torch.tensor(gamma, dtype=torch.float64, requires_grad=True), torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    rs64, m64 = torch.tensor(raw_s, dtype=torch.float64, requires_grad=True), torch.tensor(mean, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for i in range(b):
+        zi = torch.nn.functional.batch_norm(x64[i], None, None, g64, b64, True, 0.1, 1e-5)
+        loss_i, logp_i, _ = T.classification_loss(zi, c, torch.nn.functional.softplus(rs64), m64, torch.full((c,), 0.1, dtype=torch.float64),
+                                                  normalize=True)
+        assert abs(obj[i].item() - loss_i.item()) < MLL_RTOL * abs(loss_i.item())
+        total = total + float(w_ep[i].item()) * loss_i
+    total.backward()
+    assert rel_l2(xt.grad.cpu().numpy(), x64.grad.numpy()) < GRAD_RTOL
+    assert rel_l2(gt.grad.cpu().numpy(), g64.grad.numpy()) < GRAD_RTOL
+    assert rel_l2(bt.grad.cpu().numpy(), b64.grad.numpy()) < GRAD_RTOL
+    assert rel_l2(rst.grad.cpu().numpy(), rs64.grad.numpy()) < GRAD_RTOL
+    assert rel_l2(mt.grad.cpu().numpy(), m64.grad.numpy()) < GRAD_RTOL
+    # the batch statistics returned for the running-estimate update
+    assert rel_l2(bmean.cpu().numpy(), x.astype(np.float64).mean(1)) < 1e-5
+    assert rel_l2(bvar.cpu().numpy(), x.astype(np.float64).var(1, ddof=1)) < 5e-5
 
 
 @pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2", "linear", "cossim"])
