@@ -144,6 +144,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ok = int(info.abs().max().item()) == 0 and bool(torch.isfinite(loss))
+    # same inputs -> bitwise the same outputs (no atomics, fixed reduction orders): a hand-off race in a kernel would
+    # show up here as a handful of differing episodes
+    _, logp_a, _ = step()
+    grad_a = z.grad.clone()
+    _, logp_b, _ = step()
+    deterministic = bool(torch.equal(logp_a, logp_b)) and bool(torch.equal(grad_a, z.grad))
+    ok = ok and deterministic
 
     if rank == 0:
         eps = world * b * args.steps / dt
@@ -200,7 +207,7 @@ def main():
                        "episodes_per_step_per_gpu": b, "kernel": "bncossim", "parallelism": "episode-dp%d" % world,
                        "arithmetic": "fp32 results; the two Gram contractions run as an exact 3-way bf16 split of every fp32 "
                                      "operand (6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate), the factorisations in fp32"},
-            "valid": ok, "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
+            "valid": ok, "deterministic": deterministic, "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
             "roofline_by_kernel": roofline_all, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
