@@ -155,6 +155,7 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     const float* p0 = c.colbuf + (2 * PAR) * NP;          // column k
     const float* p1 = c.colbuf + (2 * PAR + 1) * NP;      // column k + 1
     __syncthreads();
+    __builtin_amdgcn_s_setprio(2);                        // critical path (pivot columns -> next publish) outranks bulk updates
     const float d0 = p0[16 * KQ + kr], e = p0[16 * KQ + kr + 1], d1raw = p1[16 * KQ + kr + 1];
     f32x2 F0[NP2], F1[NP2];
     float y0[NT], y1[NT];
@@ -226,6 +227,7 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
             for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
 }
