@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from time import gmtime, strftime
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -59,6 +61,15 @@ class _MllView(nn.Module):
         return -loss
 
 
+class _FusableBatchNorm1d(nn.BatchNorm1d):
+    """bn_out (DKT.py:48) with the same parameters / buffers / state-dict keys as nn.BatchNorm1d; `bypass` lets the fused
+    front end (ops.episode_loss_bn) take the trunk output in front of it and run the normalisation inside the Gram kernels."""
+    bypass = False
+
+    def forward(self, x):
+        return x if self.bypass else super().forward(x)
+
+
 class DKT(MetaTemplate):
     def __init__(self, model_func, n_way, n_support, kernel_type=None):
         super(DKT, self).__init__(model_func, n_way, n_support)
@@ -75,7 +86,7 @@ class DKT(MetaTemplate):
         elif self.kernel_type == "bncossim":
             self.normalize = True
             latent_size = int(np.prod(self.feature_extractor.final_feat_dim))
-            self.feature_extractor.trunk.add_module("bn_out", nn.BatchNorm1d(latent_size))
+            self.feature_extractor.trunk.add_module("bn_out", _FusableBatchNorm1d(latent_size))
         else:
             self.normalize = False
         self.jitter0 = 1e-6       # gpytorch psd_safe_cholesky fp32 default
@@ -134,6 +145,50 @@ class DKT(MetaTemplate):
         m = self.model
         return m.scale_times_variance(), m.mean, m.noise
 
+    # ---- fused front end: bn_out + F.normalize folded into the Gram kernels (ops.episode_loss_bn) ----
+    def _trunk_features(self, x):
+        """Backbone output BEFORE bn_out (the module the reference appends to the trunk at DKT.py:48)."""
+        bn = getattr(self.feature_extractor.trunk, "bn_out", None)
+        if bn is None:
+            return self.feature_extractor.forward(x)
+        bn.bypass = True
+        try:
+            return self.feature_extractor.forward(x)
+        finally:
+            bn.bypass = False
+
+    def _fused_front_end(self, n, d):
+        return (self.kernel_type in ("bncossim", "cossim") and n <= 128 and d % 4 == 0
+                and os.environ.get("DKT_FUSED_FRONTEND", "1") != "0")
+
+    def _episode_loss_from_trunk(self, x_feat, y):
+        """Training loss of ONE episode from the trunk output x_feat:[N,D]; bn_out runs in train mode (batch statistics of
+        the episode, running estimates updated exactly as nn.BatchNorm1d does) inside the fused kernels.
+        Returns (loss, aux, z_train) with z_train the normalised train-mode features (detached) the in-loop evaluation
+        conditions on (DKT.py:170-192)."""
+        xb = x_feat.unsqueeze(0).contiguous()
+        n = xb.shape[1]
+        c = y.shape[-2]
+        sv, mean, noise = self._hypers()
+        cw = torch.full((c,), -1.0 / (c * n), device=xb.device, dtype=torch.float32)
+        bn = getattr(self.feature_extractor.trunk, "bn_out", None) if self.kernel_type == "bncossim" else None
+        if bn is not None:
+            outs = ops.episode_loss_bn(xb, bn.weight, bn.bias, y, sv, mean, noise, cw, eps=bn.eps, jitter0=self.jitter0,
+                                       max_tries=self.max_tries, use_bn=True, full=True)
+        else:
+            outs = ops.episode_loss_bn(xb, None, None, y, sv, mean, noise, cw, jitter0=self.jitter0, max_tries=self.max_tries,
+                                       use_bn=False, full=True)
+        obj, logp, alpha, info, jit, e, bmean, bvar, a, s, rnorm = outs
+        with torch.no_grad():
+            if bn is not None and bn.track_running_stats:
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item() + 1)
+                bn.running_mean.mul_(1.0 - mom).add_(bmean[0], alpha=mom)
+                bn.running_var.mul_(1.0 - mom).add_(bvar[0], alpha=mom)
+                bn.num_batches_tracked += 1
+            z_train = (xb[0].detach() * a.reshape(-1, xb.shape[2])[0] + s.reshape(-1, xb.shape[2])[0]) * rnorm[0].unsqueeze(1)
+        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
+        return obj.mean(), aux, z_train
+
     def _episode_loss(self, z, y):
         """loss = -(1/C) sum_c logp_c / N for ONE episode z:[N,D] (or a batch [B,N,D] -> mean over B)."""
         zb = z if z.dim() == 3 else z.unsqueeze(0)
@@ -187,7 +242,13 @@ class DKT(MetaTemplate):
             self.model.train()
             self.likelihood.train()
             self.feature_extractor.train()
-            z_train = self._embed(x_all)
+            x_feat = self._trunk_features(x_all)
+            fused = x_feat.dim() == 2 and self._fused_front_end(x_feat.shape[0], x_feat.shape[1])
+            if not fused:                                 # torch bn_out / F.normalize in front of the Gram kernels
+                bn = getattr(self.feature_extractor.trunk, "bn_out", None)
+                z_train = x_feat if bn is None else bn(x_feat)
+                if self.normalize:
+                    z_train = F.normalize(z_train, p=2, dim=1)
 
             # hyper-parameter means for the log line, read BEFORE the step (DKT.py:145-157); kept on
             # the device, converted to Python floats only when printed
@@ -198,7 +259,10 @@ class DKT(MetaTemplate):
                 log_lengthscale = ls.mean() if ls is not None else torch.zeros((), device=dev)
 
             optimizer.zero_grad()
-            loss, aux = self._episode_loss(z_train, y_targets)
+            if fused:
+                loss, aux, z_train = self._episode_loss_from_trunk(x_feat, y_targets)
+            else:
+                loss, aux = self._episode_loss(z_train, y_targets)
             loss.backward()
             self._sync_grads()
             optimizer.step()

@@ -463,41 +463,54 @@ def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
 
 
 class _EpisodeLossBnFn(torch.autograd.Function):
-    """Training episode straight from the trunk output X (before bn_out): BatchNorm1d(train) + F.normalize + linear Gram
+    """Training episode straight from the trunk output X: [BatchNorm1d(train) +] F.normalize + linear Gram
     (dkt_bn_stats_f32, dkt_gram_bn_f32) -> MLL (dkt_mll_f32) ; backward dkt_gram_bn_bwd_f32.  The normalised features are
-    never written to memory."""
+    never written to memory.  use_bn=False is the plain cossim kernel (no bn_out: affine map = identity)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, y, sv, mean, noise, cls_weight, jitter0, max_tries):
-        st = bn_stats(x, gamma, beta, eps)
-        e, rnorm = gram_bn(x, st["a"], st["s"])
+    def forward(ctx, x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+        b_, n, d = x.shape
+        if use_bn:
+            st = bn_stats(x, gamma, beta, eps)
+            a, s, bmean, rstd, bvar = st["a"], st["s"], st["mean"], st["rstd"], st["var_unbiased"]
+        else:
+            a = torch.ones(d, device=x.device, dtype=torch.float32)
+            s = torch.zeros(d, device=x.device, dtype=torch.float32)
+            bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
+        e, rnorm = gram_bn(x, a, s)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
         obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
-        ctx.save_for_backward(x, e, out["w"], st["a"], st["s"], st["mean"], st["rstd"], rnorm, out["dsv"], out["dmean"],
-                              out["dnoise"], cls_weight)
+        ctx.use_bn = bool(use_bn)
+        ctx.save_for_backward(x, e, out["w"], a, s, bmean, rstd, rnorm, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
-        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e, st["mean"], st["var_unbiased"])
-        return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e, st["mean"], st["var_unbiased"]
+        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm)
+        return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
         x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
+        if ctx.use_bn:
+            dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
+        else:
+            dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, None, None, gobj)
         gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
         ng = ctx.needs_input_grad
-        ggamma = dg.sum(0).reshape(ctx.shapes[3]) if (ng[1] and ctx.shapes[3] is not None) else None
-        gbeta = db.sum(0).reshape(ctx.shapes[4]) if (ng[2] and ctx.shapes[4] is not None) else None
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[5] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[6] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[7] else None
-        return (dx if ng[0] else None), ggamma, gbeta, None, None, gsv, gmean, gnoise, None, None, None
+        ggamma = dg.sum(0).reshape(ctx.shapes[3]) if (dg is not None and ng[1] and ctx.shapes[3] is not None) else None
+        gbeta = db.sum(0).reshape(ctx.shapes[4]) if (db is not None and ng[2] and ctx.shapes[4] is not None) else None
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[6] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[7] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[8] else None
+        return (dx if ng[0] else None), ggamma, gbeta, None, None, None, gsv, gmean, gnoise, None, None, None
 
 
-def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float = 1e-5, jitter0: float = 1e-6, max_tries: int = 3):
+def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float = 1e-5, jitter0: float = 1e-6, max_tries: int = 3,
+                    use_bn: bool = True, full: bool = False):
     """x:[B,N,D] trunk output BEFORE bn_out.  Returns (obj[B], logp, alpha, info, jitter, E, batch_mean[B,D],
-    batch_var_unbiased[B,D]) -- the last two feed the caller's running-statistics update."""
-    return _EpisodeLossBnFn.apply(x, gamma, beta, eps, y, sv, mean, noise, cls_weight, jitter0, max_tries)
+    batch_var_unbiased[B,D]) -- the last two feed the caller's running-statistics update -- plus, with full=True, the folded
+    affine map a, s and the row scales rnorm (zn = (a x + s) rnorm: what a caller needs to re-create the normalised features)."""
+    out = _EpisodeLossBnFn.apply(x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries)
+    return out if full else out[:8]
 
 
 def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):

@@ -552,6 +552,50 @@ def test_dkt_train_step_matches_float64_autograd(cuda):
     assert checked >= 18
 
 
+@pytest.mark.parametrize("kernel", ["bncossim", "cossim"])
+def test_dkt_train_step_fused_front_end_matches_float64_autograd(cuda, kernel):
+    """The drop-in training step with bn_out + F.normalize inside the Gram kernels (DKT._episode_loss_from_trunk):
+    loss, every backbone / bn_out / GP gradient and the running statistics vs the float64 torch restatement."""
+    import copy
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type=kernel).to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
+        m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+        if kernel == "bncossim":
+            m.feature_extractor.trunk.bn_out.weight.uniform_(0.5, 1.5)
+            m.feature_extractor.trunk.bn_out.bias.normal_(0.0, 0.1)
+    ref = copy.deepcopy(m).cpu().double()
+    x = torch.rand(5, 21, 3, 28, 28, generator=torch.Generator().manual_seed(1))
+    x_all = x.view(105, 3, 28, 28)
+    m.train()
+    x_feat = m._trunk_features(x_all.to(cuda))
+    assert m._fused_front_end(x_feat.shape[0], x_feat.shape[1])
+    y = m._targets(5, 21, cuda)
+    loss, aux, z_train = m._episode_loss_from_trunk(x_feat, y)
+    loss.backward()
+    ref.train()
+    zr = ref._embed(x_all.double())
+    loss_r, _, _ = T.classification_loss(zr, 5, ref.model.outputscale, ref.model.mean, ref.model.noise)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    assert rel_l2(z_train.cpu().numpy(), zr.detach().numpy()) < 1e-5
+    checked = 0
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None, name
+            continue
+        diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+        assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+        checked += 1
+    assert checked >= 16
+    if kernel == "bncossim":
+        bn, bnr = m.feature_extractor.trunk.bn_out, ref.feature_extractor.trunk.bn_out
+        assert rel_l2(bn.running_mean.cpu().numpy(), bnr.running_mean.numpy()) < 1e-5
+        assert rel_l2(bn.running_var.cpu().numpy(), bnr.running_var.numpy()) < 1e-4
+        assert int(bn.num_batches_tracked.item()) == int(bnr.num_batches_tracked.item()) == 1
+
+
 # ----------------------------------------------------------------------------------------------
 # BNCosSim front half fused into the Gram build (bn_out + F.normalize + LinearKernel, DKT.py:48,141-142,375-378)
 # ----------------------------------------------------------------------------------------------
