@@ -155,7 +155,7 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     const float* p0 = c.colbuf + (2 * PAR) * NP;          // column k
     const float* p1 = c.colbuf + (2 * PAR + 1) * NP;      // column k + 1
     __syncthreads();
-    __builtin_amdgcn_s_setprio(2);                        // critical path (pivot columns -> next publish) outranks bulk updates
+    __builtin_amdgcn_s_setprio(3);                        // critical path (pivot columns -> next publish) outranks bulk updates
     const float d0 = p0[16 * KQ + kr], e = p0[16 * KQ + kr + 1], d1raw = p1[16 * KQ + kr + 1];
     f32x2 F0[NP2], F1[NP2];
     float y0[NT], y1[NT];
@@ -227,7 +227,7 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
             for (int pi = 0; pi < NT; ++pi) nb[ty + 16 * pi] = AE(pi, KQ);
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(1);                        // bulk updates of a sweep still outrank the gradient product phases
 #pragma unroll
     for (int ji = KQ + 1; ji < NT; ++ji) column(ji);
 }
@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256, ((NT <= 7 && !(WANT_GRAD && WANT_CHOL)) ? DKT_
             }
             __syncthreads();          // previous users of colbuf are done
             sweep_all<NT, 0>(A2, ctx);
+            __builtin_amdgcn_s_setprio(0);
             // ---- pivots: d_j sits raw in the diagonal slot (j, j).  Column scales, log det, first bad pivot ----
             if (ty == tx) {
 #pragma unroll
