@@ -347,6 +347,23 @@ template <int NT, int ROW>
 __device__ __forceinline__ void w_accum_row(const f32x4* acc, brsrc Wr, int N, int tyN, int r16, int q, int vo_rc, int vo_cr,
                                             bool first, bool last, float coef, const float* alv) {
     const f32x4 ai = *reinterpret_cast<const f32x4*>(alv + 16 * ROW + 4 * q) * coef;
+    // read-modify-write of the running sum over the classes: ALL loads of the tile row are issued before the first store
+    // (the compiler may not move a load above a store to the same buffer, so the obvious per-element form pays one
+    // memory round trip per element: 28 serialized latencies per wave and class)
+    float prev[ROW + 1][4];
+#pragma unroll
+    for (int tj = 0; tj <= ROW; ++tj) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int pl = 4 * q + reg;
+            bool ok = true;
+            if (ROW == NT - 1) ok = ok && (pl < tyN);
+            if (tj == NT - 1) ok = ok && (r16 < tyN);
+            if (tj == ROW) ok = ok && (r16 <= pl);
+            // an out-of-range offset reads as 0 through the descriptor (masked lanes, first class)
+            prev[tj][reg] = bload(Wr, (ok && !first) ? vo_rc : 0x7ffffff0, ((16 * ROW + reg) * N + 16 * tj) * 4);
+        }
+    }
 #pragma unroll
     for (int tj = 0; tj <= ROW; ++tj) {
         const float aj = alv[16 * tj + r16];
@@ -359,8 +376,7 @@ __device__ __forceinline__ void w_accum_row(const f32x4* acc, brsrc Wr, int N, i
             if (tj == ROW) ok = ok && (r16 <= pl);                       // lower triangle of the diagonal tile
             if (ok) {
                 const int so = ((16 * ROW + reg) * N + 16 * tj) * 4;
-                float v = __builtin_fmaf(ai[reg], aj, -coef * acc[tj][reg]);
-                if (!first) v += bload(Wr, vo_rc, so);
+                const float v = __builtin_fmaf(ai[reg], aj, -coef * acc[tj][reg]) + prev[tj][reg];
                 bstore(Wr, v, vo_rc, so);
                 // the strided mirror write happens once, when the sum over the classes is complete
                 if (last && !(tj == ROW && r16 == pl)) bstore(Wr, v, vo_cr, (16 * tj * N + 16 * ROW + reg) * 4);
