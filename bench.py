@@ -210,6 +210,35 @@ def main():
             "valid": ok, "deterministic": deterministic, "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
             "roofline_by_kernel": roofline_all, "kernels": kernels,
         }
+        if world == 1:
+            # the forward-only test-time episode (`correct`, DKT.py:199-272) reported separately:
+            # condition on the 25 support features, predict the 75 queries (Gram, MLL without gradients, cross Gram, mean + arg-max)
+            bt = min(b, 4096)
+            z_te = synthetic_batch(bt, n, d, 77, dev)        # [support; query] features of a test episode, support rows first
+            ns = c * s
+            cls_s = torch.arange(c, device=dev).repeat_interleave(s)
+            ys = torch.where(cls_s.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
+            svt = torch.nn.functional.softplus(raw_s.detach())
+
+            def test_episode():
+                # ONE pass over the episode's features: the symmetric episode-resident Gram of [support; query] holds both
+                # k(support, support) and k(query, support) (the query-query block is the price of streaming at full rate)
+                e_all = ops.gram(z_te)
+                o = ops.mll(e_all[:, :ns, :ns].contiguous(), ys, svt, mean.detach(), noise)
+                return ops.predict(e_all[:, ns:, :ns].contiguous(), o["alpha"], svt, mean.detach())
+
+            for _ in range(3):
+                test_episode()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                mu_t, lab_t = test_episode()
+            torch.cuda.synchronize()
+            dt_t = (time.perf_counter() - t1) / 10
+            out["test_time_forward"] = {"value": round(bt / dt_t, 1), "unit": "episodes/s", "episodes_per_step": bt,
+                                        "ms_per_step": round(1e3 * dt_t, 4),
+                                        "workload": "N_support=%d, N_query=%d, D=%d, C=%d: Gram + MLL (no grad) + cross Gram + posterior mean/arg-max"
+                                                    % (c * s, c * q, d, c)}
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
             from oracle import dkt_oracle as O

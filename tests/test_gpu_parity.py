@@ -396,6 +396,29 @@ def test_golden_test_episode_prediction(cuda, path):
     assert float((labels[0].cpu().numpy() == np.repeat(np.arange(c), q)).sum()) == float(g["correct"])
 
 
+def test_batched_test_episodes_single_pass_gram(cuda):
+    """bench.py's test-time formulation: the symmetric Gram of [support; query] (episode-resident kernel, B >= 64) holds
+    k(s, s) and k(q, s); posterior means / labels equal the two-Gram path and the oracle."""
+    b, c, s_, q_, d = 64, 5, 5, 16, 256
+    ns, n = c * s_, c * (s_ + q_)
+    g = torch.Generator(device=cuda).manual_seed(4)
+    z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda) + 2.0 * torch.randn(b, 1, d, generator=g, device=cuda), dim=2)
+    hyp = O.perturbed_hypers(c, 5)
+    sv, mean, noise = dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda)
+    ys = dev_t(O.one_vs_rest_targets(c, s_), cuda)
+    e_all = ops.gram(z)
+    o1 = ops.mll(e_all[:, :ns, :ns].contiguous(), ys, sv, mean, noise)
+    mu1, lab1 = ops.predict(e_all[:, ns:, :ns].contiguous(), o1["alpha"], sv, mean)
+    zs, zq = z[:, :ns].contiguous(), z[:, ns:].contiguous()
+    o2 = ops.mll(ops.gram(zs), ys, sv, mean, noise)
+    mu2, lab2 = ops.predict(ops.gram(zq, zs), o2["alpha"], sv, mean)
+    assert (mu1 - mu2).abs().max().item() < 2e-5
+    for i in (0, 31, 63):
+        ref = O.eval_episode(zs[i].cpu().numpy().astype(np.float64), zq[i].cpu().numpy().astype(np.float64), c, hyp)
+        assert np.abs(mu1[i].cpu().numpy() - ref["mu"]).max() < 1e-4
+        assert (lab1[i].cpu().numpy() == ref["labels"]).all()
+
+
 def test_predict_first_max_wins_on_ties(cuda):
     ex = torch.ones(1, 3, 2, device=cuda)
     alpha = torch.zeros(1, 4, 2, device=cuda)
