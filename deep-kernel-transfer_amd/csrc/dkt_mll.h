@@ -35,3 +35,10 @@ bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st);
 bool dkt_mll_blk_launch(const MllArgs& a, hipStream_t st);
 // Wave-per-episode path (no barriers): N + 1 in (104, 112].  Returns false when N is out of range / disabled.
 bool dkt_mll_wave_launch(const MllArgs& a, hipStream_t st);
+
+// Batched factorisation + inversion of nb x nb diagonal blocks (nb <= 127) with the register-resident sweep (dkt_mll_reg.hip).
+void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int ldl, long sL, float* U, int ldu, long sU, int nb,
+                               int pivot_base, int32_t* info, int nmat, hipStream_t st);
+// Blocked path for N > 127 (dkt_mll_big.hip).
+size_t dkt_mll_big_workspace_bytes(int B, int C, int N);
+int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);

@@ -189,10 +189,11 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
 }  // namespace
 
 extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
-    (void)C;
-    if (B <= 0 || N <= 0) return 0;
-    if (mll_fits_lds(N)) return 0;
-    return (size_t)B * mll_mat_floats(N) * sizeof(float);
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    if (N + 1 <= 128) return 0;                              // register-resident kernel
+    const size_t big = dkt_mll_big_workspace_bytes(B, C, N); // blocked path; also covers the generic kernel's global matrices
+    const size_t gen = mll_fits_lds(N) ? 0 : (size_t)B * mll_mat_floats(N) * sizeof(float);
+    return big > gen ? big : gen;
 }
 
 extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv, const float* mean,
@@ -214,6 +215,8 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_wave_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_blk_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (!(flags & DKT_MLL_FORCE_GENERIC) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))
+        return dkt_mll_big_launch(a, workspace, workspace_bytes, st);
     if (mll_fits_lds(N)) {
         const size_t lds = (mll_vec_floats(N) + mll_mat_floats(N)) * sizeof(float);
         if (lds > 48 * 1024) {
@@ -223,7 +226,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
         }
         hipLaunchKernelGGL(mll_generic_kernel<false>, dim3(B), dim3(256), lds, st, a);
     } else {
-        const size_t need = dkt_mll_workspace_bytes(B, C, N);
+        const size_t need = (size_t)B * mll_mat_floats(N) * sizeof(float);
         if (!workspace || workspace_bytes < need) return DKT_ERR_WORKSPACE;
         const size_t lds = mll_vec_floats(N) * sizeof(float);
         hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(B), dim3(256), lds, st, a);

@@ -1,0 +1,308 @@
+// dkt_mll_big.hip -- exact-GP marginal likelihood for N > 127 (the 20-way shapes: N = 320 / 420, "batched Cholesky
+// stress" of BASELINE.json), built from blocks the small-N machinery already masters:
+//   * every (episode, class) matrix K = sv E + (noise + jitter) I is processed in nbk x nbk blocks of nb <= 111 rows,
+//   * diagonal blocks are factored AND inverted by the register-resident sweep (chol_inv_block_kernel in dkt_mll_reg.hip:
+//     L_jj below, U_jj = L_jj^-T above), so the panel step needs no triangular solve:  L_ij = A_ij U_jj  is a GEMM,
+//   * trailing updates, V = L^-T (block back-substitution with the explicit U_jj) and K^-1 = V V^T are batched fp32-MFMA
+//     GEMMs over all B x C matrices of a chunk (one launch per block operation, independent of C),
+//   * alpha = V (V^T r), log det from the diagonal of L, the scalar identities of dkt_mll_reg.hip for the hyper-gradients,
+//   * W[b] = sum_c coef_c (alpha_c alpha_c^T - K_c^-1) summed over the classes in a fixed order (deterministic).
+// Jitter retries follow GPyTorch's psd_safe_cholesky per matrix; the host reads one failure counter per attempt.
+// Replaces the same reference lines as dkt_mll.hip (methods/DKT.py:161-163,177,187,252-254,265,330).
+#include "dkt_mll.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Batched strided GEMM on sub-blocks:  C = beta C + alpha op(A) op(B),  op(A): M x K, op(B): K x N.
+struct GemmOp {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    long sA, sB, sC;            // batch strides (floats)
+    float alpha, beta;
+};
+
+constexpr int GLD = 20;         // LDS row stride of a [64][16] tile
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
+    __shared__ float As[64 * GLD], Bs[64 * GLD];
+    const int bz = blockIdx.z;
+    const float* A = g.A + (size_t)bz * g.sA;
+    const float* B = g.B + (size_t)bz * g.sB;
+    float* C = g.C + (size_t)bz * g.sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        // stage op(A)[m0..m0+64][k0..k0+16] as As[m][k] and op(B)^T as Bs[n][k]; the fast index of the loads follows memory
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int m, k;
+            if (!TA) { m = tid >> 2; k = 4 * (tid & 3) + e; } else { k = tid >> 4; m = 4 * (tid & 15) + e; }
+            float v = 0.f;
+            if (m0 + m < g.M && k0 + k < g.K) v = TA ? A[(size_t)(k0 + k) * g.lda + m0 + m] : A[(size_t)(m0 + m) * g.lda + k0 + k];
+            As[m * GLD + k] = v;
+            int n, kb;
+            if (TB) { n = tid >> 2; kb = 4 * (tid & 3) + e; } else { kb = tid >> 4; n = 4 * (tid & 15) + e; }
+            float u = 0.f;
+            if (n0 + n < g.N && k0 + kb < g.K) u = TB ? B[(size_t)(n0 + n) * g.ldb + k0 + kb] : B[(size_t)(k0 + kb) * g.ldb + n0 + n];
+            Bs[n * GLD + kb] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float a = As[(16 * wave + r16) * GLD + 4 * kk + q];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[(16 * ct + r16) * GLD + 4 * kk + q], acc[ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + 16 * wave + 4 * q + reg, n = n0 + 16 * ct + r16;
+            if (m < g.M && n < g.N) {
+                float* c = C + (size_t)m * g.ldc + n;
+                const float v = g.alpha * acc[ct][reg];
+                *c = (g.beta == 0.f) ? v : __builtin_fmaf(g.beta, *c, v);
+            }
+        }
+    }
+}
+
+void gemm(hipStream_t st, int nmat, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, long sA,
+          const float* B, int ldb, long sB, float beta, float* C, int ldc, long sC) {
+    GemmOp g{A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha, beta};
+    dim3 grid((N + 63) / 64, (M + 63) / 64, nmat), blk(256);
+    if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, blk, 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, blk, 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, blk, 0, st, g);
+    else hipLaunchKernelGGL((bgemm_kernel<true, true>), grid, blk, 0, st, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kw[m] = sv_c E[b] + (noise_c + jit[m]) I  (full N x N; only the lower block triangle is consumed);  Vm[m] = 0
+__global__ __launch_bounds__(256) void big_form_kernel(const float* __restrict__ E, const float* __restrict__ sv,
+                                                       const float* __restrict__ noise, const float* __restrict__ jit,
+                                                       float* __restrict__ Kw, float* __restrict__ Vm, int b0, int C, int N) {
+    const int m = blockIdx.y, b = b0 + m / C, c = m % C;
+    const float* Eb = E + (size_t)b * N * N;
+    float* K = Kw + (size_t)m * N * N;
+    float* V = Vm + (size_t)m * N * N;
+    const float s = sv[c], dg = noise[c] + jit[m];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * N; idx += gridDim.x * 256) {
+        const int i = idx / N, j = idx - i * N;
+        K[idx] = s * Eb[idx] + (i == j ? dg : 0.f);
+        V[idx] = 0.f;
+    }
+}
+
+// after a factorisation attempt: matrices whose info != 0 move to the next jitter level; counts them
+__global__ void big_retry_kernel(const int32_t* __restrict__ info, float* __restrict__ jit, int* __restrict__ attempt_of,
+                                 int* __restrict__ nfail, float jitter0, int max_tries, int nmat) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nmat) return;
+    if (info[m] != 0 && attempt_of[m] < max_tries) {
+        const int a = ++attempt_of[m];
+        float j = jitter0;
+        for (int i = 1; i < a; ++i) j *= 10.f;
+        jit[m] = j;
+        atomicAdd(nfail, 1);
+    }
+}
+
+// w = V^T r (TR = true) or alpha = V w (TR = false) with V upper (block-)triangular, one workgroup per matrix
+template <bool TR>
+__global__ __launch_bounds__(256) void big_matvec_kernel(const float* __restrict__ Vm, const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ Y, long y_bstride, const float* __restrict__ mean,
+                                                         int b0, int C, int N, bool x_is_targets) {
+    const int m = blockIdx.x, b = b0 + m / C, c = m % C;
+    const float* V = Vm + (size_t)m * N * N;
+    const float* xv = x_is_targets ? (Y + (size_t)b * y_bstride + (size_t)c * N) : (x + (size_t)m * N);
+    const float shift = x_is_targets ? mean[c] : 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < N; i += 4) {                 // one wave per output element
+        float s = 0.f;
+        if (TR) { for (int k = lane; k <= i; k += 64) s = __builtin_fmaf(V[(size_t)k * N + i], xv[k] - shift, s); }   // (V^T r)_i = sum_{k<=i} V_ki r_k
+        else { for (int k = i + lane; k < N; k += 64) s = __builtin_fmaf(V[(size_t)i * N + k], xv[k] - shift, s); }   // (V w)_i = sum_{k>=i} V_ik w_k
+        s = wave_sum(s);
+        if (lane == 0) y[(size_t)m * N + i] = s;
+    }
+}
+
+// per matrix: logp, alpha out, hyper-gradient scalars (tr K^-1 = |V|_F^2), jitter_used
+__global__ __launch_bounds__(256) void big_finish_kernel(MllArgs a, const float* __restrict__ Lm, const float* __restrict__ Vm,
+                                                         const float* __restrict__ wv, const float* __restrict__ al,
+                                                         const float* __restrict__ jit, const int32_t* __restrict__ info_m, int b0) {
+    __shared__ float red[8];
+    const int m = blockIdx.x, N = a.N, C = a.C, b = b0 + m / C, c = m % C, tid = threadIdx.x;
+    const size_t bc = (size_t)b * C + c;
+    const float* L = Lm + (size_t)m * N * N;
+    const float* V = Vm + (size_t)m * N * N;
+    const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
+    const int bad = info_m[m];
+    if (bad != 0) {
+        const float qnan = __int_as_float(0x7fc00000);
+        if (tid == 0) {
+            a.logp[bc] = qnan; a.jitter_used[bc] = jit[m]; a.info[bc] = bad;
+            if (a.flags & DKT_MLL_WANT_GRAD) { a.dsv[bc] = qnan; a.dmean[bc] = qnan; a.dnoise[bc] = qnan; }
+        }
+        for (int i = tid; i < N; i += 256) a.alpha[bc * N + i] = qnan;
+        return;
+    }
+    float ld = 0.f, quad = 0.f, asum = 0.f, a2 = 0.f, ra = 0.f, vf = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        ld += logf(L[(size_t)i * N + i]);
+        const float w = wv[(size_t)m * N + i], av = al[(size_t)m * N + i];
+        quad = __builtin_fmaf(w, w, quad);
+        asum += av;
+        a2 = __builtin_fmaf(av, av, a2);
+        ra = __builtin_fmaf(yc[i] - a.mean[c], av, ra);
+        a.alpha[bc * N + i] = av;
+    }
+    for (int idx = tid; idx < N * N; idx += 256) {
+        const int i = idx / N, j = idx - i * N;
+        if (j >= i) { const float v = V[idx]; vf = __builtin_fmaf(v, v, vf); }
+    }
+    ld = block_sum_256(ld, red); quad = block_sum_256(quad, red); asum = block_sum_256(asum, red);
+    a2 = block_sum_256(a2, red); ra = block_sum_256(ra, red); vf = block_sum_256(vf, red);
+    if (tid == 0) {
+        a.logp[bc] = -0.5f * quad - ld - (float)N * DKT_HALF_LOG_2PI;
+        a.jitter_used[bc] = jit[m];
+        a.info[bc] = 0;
+        if (a.flags & DKT_MLL_WANT_GRAD) {
+            const float nz_eff = a.noise[c] + jit[m];
+            a.dmean[bc] = asum;
+            a.dnoise[bc] = 0.5f * (a2 - vf);
+            a.dsv[bc] = 0.5f * ((ra - (float)N) - nz_eff * (a2 - vf)) / a.sv[c];
+        }
+    }
+}
+
+// W[b] = sum_c coef_c (alpha_c alpha_c^T - Kinv_c), Kinv given by its lower block triangle (mirrored here); NaN if any class failed
+__global__ __launch_bounds__(256) void big_w_kernel(MllArgs a, const float* __restrict__ Kinv, const float* __restrict__ al,
+                                                    const int32_t* __restrict__ info_m, int b0, int nb) {
+    const int bl = blockIdx.y, b = b0 + bl, N = a.N, C = a.C;
+    float* Wb = a.W + (size_t)b * N * N;
+    bool poisoned = false;
+    for (int c = 0; c < C; ++c) poisoned = poisoned || info_m[bl * C + c] != 0;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * N; idx += gridDim.x * 256) {
+        const int i = idx / N, j = idx - i * N;
+        if (j > i) continue;                              // lower triangle computed, mirrored
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t m = (size_t)bl * C + c;
+            const float coef = 0.5f * (a.cls_weight ? a.cls_weight[c] : 1.0f) * a.sv[c];
+            // Kinv block (bi, bj) with bi >= bj was computed; (i, j) with i >= j lies in such a block or in a diagonal block
+            const float kinv = (i / nb >= j / nb) ? Kinv[m * N * N + (size_t)i * N + j] : Kinv[m * N * N + (size_t)j * N + i];
+            s += coef * (al[m * N + i] * al[m * N + j] - kinv);
+        }
+        if (poisoned) s = __int_as_float(0x7fc00000);
+        Wb[(size_t)i * N + j] = s;
+        Wb[(size_t)j * N + i] = s;
+    }
+}
+
+// L[b,c] <- lower triangle of Lm (upper zero)
+__global__ __launch_bounds__(256) void big_chol_out_kernel(MllArgs a, const float* __restrict__ Lm, const int32_t* __restrict__ info_m, int b0) {
+    const int m = blockIdx.y, N = a.N, C = a.C, b = b0 + m / C, c = m % C;
+    float* Lo = a.L + ((size_t)b * C + c) * N * N;
+    const float* L = Lm + (size_t)m * N * N;
+    const bool bad = info_m[m] != 0;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * N; idx += gridDim.x * 256) {
+        const int i = idx / N, j = idx - i * N;
+        Lo[idx] = bad ? __int_as_float(0x7fc00000) : (j <= i ? L[idx] : 0.f);
+    }
+}
+
+inline int big_nb(int N) { const int nbk = (N + 110) / 111; return (N + nbk - 1) / nbk; }
+constexpr int BIG_CHUNK = 128;          // episodes per chunk of the workspace
+
+inline size_t big_ws_floats(int Bc, int C, int N) {
+    const size_t nmat = (size_t)Bc * C, nn = (size_t)N * N;
+    return nmat * (4 * nn + 2 * (size_t)N + 4) + 16;       // Kw, Lm, Vm, Kinv/T | w, alpha | jit, attempt, info | counter
+}
+
+}  // namespace
+
+size_t dkt_mll_big_workspace_bytes(int B, int C, int N) {
+    const int bc = B < BIG_CHUNK ? B : BIG_CHUNK;
+    return big_ws_floats(bc, C, N) * sizeof(float);
+}
+
+// Returns 0 on success, a negative DKT status otherwise.
+int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st) {
+    const int N = a.N, C = a.C;
+    if (ws_bytes < dkt_mll_big_workspace_bytes(a.B, C, N) || !workspace) return DKT_ERR_WORKSPACE;
+    const int nb = big_nb(N), nbk = (N + nb - 1) / nb;
+    const long nn = (long)N * N;
+    const int Bc = a.B < BIG_CHUNK ? a.B : BIG_CHUNK;
+    const size_t nmat_max = (size_t)Bc * C;
+    float* Kw = (float*)workspace;
+    float* Lm = Kw + nmat_max * nn;
+    float* Vm = Lm + nmat_max * nn;
+    float* Kinv = Vm + nmat_max * nn;                      // also the temp T of the V recursion (Kinv is formed last)
+    float* wv = Kinv + nmat_max * nn;
+    float* al = wv + nmat_max * N;
+    float* jit = al + nmat_max * N;
+    int* attempt_of = (int*)(jit + nmat_max);
+    int32_t* info_m = (int32_t*)(attempt_of + nmat_max);
+    int* nfail = (int*)(info_m + nmat_max);
+    const bool want_grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
+    auto off = [&](int i) { return i * nb; };
+    auto sz = [&](int i) { return (i == nbk - 1) ? N - i * nb : nb; };
+    auto blk = [&](float* base, int i, int j) { return base + (size_t)off(i) * N + off(j); };
+
+    for (int b0 = 0; b0 < a.B; b0 += Bc) {
+        const int bcnt = (a.B - b0 < Bc) ? a.B - b0 : Bc;
+        const int nmat = bcnt * C;
+        if (hipMemsetAsync(jit, 0, nmat_max * sizeof(float) * 3, st) != hipSuccess) return DKT_ERR_LAUNCH;   // jit, attempt_of, info_m
+        for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
+            hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, Vm, b0, C, N);
+            if (hipMemsetAsync(info_m, 0, nmat * sizeof(int32_t), st) != hipSuccess) return DKT_ERR_LAUNCH;
+            // ---- blocked Cholesky with explicit inverses of the diagonal blocks ----
+            for (int j = 0; j < nbk; ++j) {
+                dkt_chol_inv_block_launch(blk(Kw, j, j), N, nn, blk(Lm, j, j), N, nn, blk(Vm, j, j), N, nn, sz(j), off(j), info_m, nmat, st);
+                for (int i = j + 1; i < nbk; ++i)          // L_ij = A_ij U_jj
+                    gemm(st, nmat, false, false, sz(i), sz(j), sz(j), 1.f, blk(Kw, i, j), N, nn, blk(Vm, j, j), N, nn, 0.f, blk(Lm, i, j), N, nn);
+                for (int i = j + 1; i < nbk; ++i)          // A_ii' -= L_ij L_i'j^T  (lower block triangle)
+                    for (int i2 = j + 1; i2 <= i; ++i2)
+                        gemm(st, nmat, false, true, sz(i), sz(i2), sz(j), -1.f, blk(Lm, i, j), N, nn, blk(Lm, i2, j), N, nn, 1.f, blk(Kw, i, i2), N, nn);
+            }
+            if (attempt == a.max_tries) break;
+            if (hipMemsetAsync(nfail, 0, sizeof(int), st) != hipSuccess) return DKT_ERR_LAUNCH;
+            hipLaunchKernelGGL(big_retry_kernel, dim3((nmat + 255) / 256), dim3(256), 0, st, info_m, jit, attempt_of, nfail, a.jitter0, a.max_tries, nmat);
+            int h_fail = 0;
+            if (hipMemcpyAsync(&h_fail, nfail, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return DKT_ERR_LAUNCH;
+            if (hipStreamSynchronize(st) != hipSuccess) return DKT_ERR_LAUNCH;
+            if (h_fail == 0) break;
+        }
+        // ---- V = L^-T, upper block triangular: V_jj = U_jj (already in Vm), V_ij = -U_ii sum_{k=i+1..j} L_ki^T V_kj ----
+        for (int j = 1; j < nbk; ++j) {
+            for (int i = j - 1; i >= 0; --i) {
+                for (int k = i + 1; k <= j; ++k)
+                    gemm(st, nmat, true, false, sz(i), sz(j), sz(k), 1.f, blk(Lm, k, i), N, nn, blk(Vm, k, j), N, nn, (k == i + 1) ? 0.f : 1.f, blk(Kinv, i, j), N, nn);
+                gemm(st, nmat, false, false, sz(i), sz(j), sz(i), -1.f, blk(Vm, i, i), N, nn, blk(Kinv, i, j), N, nn, 0.f, blk(Vm, i, j), N, nn);
+            }
+        }
+        // ---- w = V^T r, alpha = V w ----
+        hipLaunchKernelGGL((big_matvec_kernel<true>), dim3(nmat), dim3(256), 0, st, Vm, (const float*)nullptr, wv, a.Y, a.y_bstride, a.mean, b0, C, N, true);
+        hipLaunchKernelGGL((big_matvec_kernel<false>), dim3(nmat), dim3(256), 0, st, Vm, wv, al, a.Y, a.y_bstride, a.mean, b0, C, N, false);
+        hipLaunchKernelGGL(big_finish_kernel, dim3(nmat), dim3(256), 0, st, a, Lm, Vm, wv, al, jit, info_m, b0);
+        if (a.flags & DKT_MLL_WANT_CHOL) hipLaunchKernelGGL(big_chol_out_kernel, dim3(32, nmat), dim3(256), 0, st, a, Lm, info_m, b0);
+        if (want_grad) {
+            // ---- K^-1 = V V^T, lower block triangle: (i, j), i >= j: sum_{k >= i} V_ik V_jk^T ----
+            for (int i = 0; i < nbk; ++i)
+                for (int j = 0; j <= i; ++j)
+                    for (int k = i; k < nbk; ++k)
+                        gemm(st, nmat, false, true, sz(i), sz(j), sz(k), 1.f, blk(Vm, i, k), N, nn, blk(Vm, j, k), N, nn, (k == i) ? 0.f : 1.f, blk(Kinv, i, j), N, nn);
+            hipLaunchKernelGGL(big_w_kernel, dim3(32, bcnt), dim3(256), 0, st, a, Kinv, al, info_m, b0, nb);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -25,8 +25,10 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
     assert sorted(dkt_amd._lib.SIGNATURES) == declared
     assert lib.dkt_abi_version() == 1
     # pure host queries (no GPU needed)
-    assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # LDS resident
-    assert lib.dkt_mll_workspace_bytes(2, 20, 420) == 2 * 421 * 421 * 4  # global workspace
+    assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # register resident
+    # N > 127: blocked path, per (episode, class) four N x N matrices + two vectors + bookkeeping
+    assert lib.dkt_mll_workspace_bytes(2, 20, 420) == (2 * 20 * (4 * 420 * 420 + 2 * 420 + 4) + 16) * 4
+    assert lib.dkt_mll_workspace_bytes(2, 20, 420) >= 2 * 421 * 421 * 4  # also covers the generic kernel's global matrices
     assert lib.dkt_mll_workspace_bytes(0, 5, 105) == 0
 
 

@@ -298,6 +298,49 @@ def test_jitter_retry_and_failure_info(cuda, force_generic):
     assert int(o["info"].item()) == 0 and o["jitter"].item() == 0.0
 
 
+@pytest.mark.parametrize("n", [150, 230, 333])
+def test_jitter_retry_and_failure_info_blocked_path(cuda, n):
+    """N > 127: blocked path (diagonal-block sweeps + batched GEMMs).  A batch mixes healthy matrices, matrices that need
+    1e-5 / 1e-4 of jitter and a hopeless one; every matrix must retry on its own (GPyTorch psd_safe_cholesky per matrix)."""
+    rng = np.random.default_rng(n)
+    qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    base = np.linspace(0.3, 2.0, n)
+    mins = [0.2, -0.1 - 5e-6, -0.1 - 5e-5, -0.5, 0.25]
+    es = []
+    for mn in mins:
+        ev = base.copy()
+        ev[n // 2] = mn                                   # the bad direction sits in the middle (second diagonal block)
+        e = qm @ np.diag(ev) @ qm.T
+        es.append(0.5 * (e + e.T))
+    e_all = np.stack(es)
+    y = np.sign(rng.standard_normal((2, n)))
+    sv, mean, noise = np.array([1.0, 1.0]), np.array([0.0, 0.1]), np.array([0.1, 0.1])
+    o = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), want_grad=True, want_chol=True,
+                cls_weight=dev_t([1.0, 1.0], cuda))
+    info, jit = o["info"].cpu().numpy(), o["jitter"].cpu().numpy()
+    assert (info[[0, 1, 2, 4]] == 0).all() and (info[3] > 0).all()
+    assert np.allclose(jit[0], 0.0) and np.allclose(jit[4], 0.0)
+    assert np.allclose(jit[1], 1e-5, rtol=1e-5) and np.allclose(jit[2], 1e-4, rtol=1e-5)
+    assert torch.isnan(o["logp"][3]).all() and torch.isnan(o["alpha"][3]).all() and torch.isnan(o["w"][3]).all()
+    for i in (0, 1, 2, 4):
+        for c in range(2):
+            k = sv[c] * e_all[i] + (noise[c] + jit[i, c]) * np.eye(n)
+            l = np.linalg.cholesky(k)
+            r = y[c] - mean[c]
+            alpha = np.linalg.solve(k, r)
+            logp = -0.5 * r @ alpha - np.log(np.diag(l)).sum() - 0.5 * n * np.log(2 * np.pi)
+            # jittered matrices are ill-conditioned (min eigenvalue ~5e-5): compare at the accuracy fp32 allows there
+            tol = 1e-4 if jit[i, c] == 0.0 else 5e-2
+            assert abs(o["logp"][i, c].item() - logp) < tol * abs(logp)
+            if jit[i, c] == 0.0:
+                assert rel_l2(o["alpha"][i, c].cpu().numpy(), alpha) < 5e-4
+                assert rel_l2(o["chol"][i, c].cpu().numpy(), l) < 5e-5
+    # the generic twin agrees on what failed and which jitter was used
+    g = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), force_generic=True)
+    assert (g["info"].cpu().numpy() != 0).tolist() == (info != 0).tolist()
+    assert np.allclose(g["jitter"].cpu().numpy(), jit)
+
+
 def test_duplicate_rows_rank_deficient_gram(cuda):
     g = np.load(os.path.join(GOLD, "degenerate.npz"))
     z = g["z"]
