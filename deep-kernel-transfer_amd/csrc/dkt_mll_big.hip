@@ -20,13 +20,53 @@ struct GemmOp {
     int M, N, K, lda, ldb, ldc;
     long sA, sB, sC;            // batch strides (floats)
     float alpha, beta;
+    bool vecA, vecB;            // 16-byte loads legal for A / B
 };
 
-constexpr int GLD = 20;         // LDS row stride of a [64][16] tile
+constexpr int GLD = 24;         // LDS row stride (floats) of a [64][16] tile: 6 sixteen-byte units -> conflict-free b128 fragment reads
+
+// One 64 x 16 operand tile into LDS as T[row][k].  `TR` = the operand's memory has the tile ROW index as the fast index
+// (op = transpose): the thread then loads 4 consecutive rows of one k and scatters them; otherwise 4 consecutive k of one row.
+// vec: 16-byte loads are legal (leading dimension, base and offsets multiples of 4 floats).
+template <bool TR>
+__device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P, int ld, int r0, int nrows, int k0, int K, int tid, bool vec) {
+    if (!TR) {
+        const int r = tid >> 2, k = 4 * (tid & 3);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < nrows) {
+            const float* p = P + (size_t)(r0 + r) * ld + k0 + k;
+            if (vec && k0 + k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k0 + k + 0 < K) v.x = p[0];
+                if (k0 + k + 1 < K) v.y = p[1];
+                if (k0 + k + 2 < K) v.z = p[2];
+                if (k0 + k + 3 < K) v.w = p[3];
+            }
+        }
+        *reinterpret_cast<float4*>(T + r * GLD + k) = v;
+    } else {
+        const int k = tid >> 4, r = 4 * (tid & 15);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + k < K) {
+            const float* p = P + (size_t)(k0 + k) * ld + r0 + r;
+            if (vec && r0 + r + 3 < nrows) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (r0 + r + 0 < nrows) v.x = p[0];
+                if (r0 + r + 1 < nrows) v.y = p[1];
+                if (r0 + r + 2 < nrows) v.z = p[2];
+                if (r0 + r + 3 < nrows) v.w = p[3];
+            }
+        }
+        T[(r + 0) * GLD + k] = v.x;
+        T[(r + 1) * GLD + k] = v.y;
+        T[(r + 2) * GLD + k] = v.z;
+        T[(r + 3) * GLD + k] = v.w;
+    }
+}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
-    __shared__ float As[64 * GLD], Bs[64 * GLD];
+    __shared__ __attribute__((aligned(16))) float As[64 * GLD], Bs[64 * GLD];
     const int bz = blockIdx.z;
     const float* A = g.A + (size_t)bz * g.sA;
     const float* B = g.B + (size_t)bz * g.sB;
@@ -37,27 +77,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < g.K; k0 += 16) {
-        // stage op(A)[m0..m0+64][k0..k0+16] as As[m][k] and op(B)^T as Bs[n][k]; the fast index of the loads follows memory
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int m, k;
-            if (!TA) { m = tid >> 2; k = 4 * (tid & 3) + e; } else { k = tid >> 4; m = 4 * (tid & 15) + e; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < g.K) v = TA ? A[(size_t)(k0 + k) * g.lda + m0 + m] : A[(size_t)(m0 + m) * g.lda + k0 + k];
-            As[m * GLD + k] = v;
-            int n, kb;
-            if (TB) { n = tid >> 2; kb = 4 * (tid & 3) + e; } else { kb = tid >> 4; n = 4 * (tid & 15) + e; }
-            float u = 0.f;
-            if (n0 + n < g.N && k0 + kb < g.K) u = TB ? B[(size_t)(n0 + n) * g.ldb + k0 + kb] : B[(size_t)(k0 + kb) * g.ldb + n0 + n];
-            Bs[n * GLD + kb] = u;
-        }
+        // op(A)[m][k] is A[m][k] (rows = m, fast index k) or A[k][m] (TA: fast index m);  op(B)^T[n][k] is B[n][k] (TB) or B[k][n]
+        stage_tile<TA>(As, A, g.lda, m0, g.M, k0, g.K, tid, g.vecA);
+        stage_tile<!TB>(Bs, B, g.ldb, n0, g.N, k0, g.K, tid, g.vecB);
         __syncthreads();
+        // lane group q holds k = 4q .. 4q+3 of the 16-wide slice (one b128 read); the t-th MFMA contracts k = {t, 4+t, 8+t, 12+t}
+        const f32x4 a = *reinterpret_cast<const f32x4*>(As + (16 * wave + r16) * GLD + 4 * q);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float a = As[(16 * wave + r16) * GLD + 4 * kk + q];
+        for (int ct = 0; ct < 4; ++ct) {
+            const f32x4 bfr = *reinterpret_cast<const f32x4*>(Bs + (16 * ct + r16) * GLD + 4 * q);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[(16 * ct + r16) * GLD + 4 * kk + q], acc[ct], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bfr[t], acc[ct], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -75,9 +105,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
     }
 }
 
+inline bool vec_ok(const float* p, int ld, long stride) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0 && (stride & 3) == 0; }
+
 void gemm(hipStream_t st, int nmat, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, long sA,
           const float* B, int ldb, long sB, float beta, float* C, int ldc, long sC) {
-    GemmOp g{A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha, beta};
+    GemmOp g{A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha, beta, vec_ok(A, lda, sA), vec_ok(B, ldb, sB)};
     dim3 grid((N + 63) / 64, (M + 63) / 64, nmat), blk(256);
     if (!ta && !tb) hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, blk, 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, blk, 0, st, g);
@@ -86,19 +118,17 @@ void gemm(hipStream_t st, int nmat, bool ta, bool tb, int M, int N, int K, float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kw[m] = sv_c E[b] + (noise_c + jit[m]) I  (full N x N; only the lower block triangle is consumed);  Vm[m] = 0
+// Kw[m] = sv_c E[b] + (noise_c + jit[m]) I on the lower block triangle (all the factorisation reads)
 __global__ __launch_bounds__(256) void big_form_kernel(const float* __restrict__ E, const float* __restrict__ sv,
                                                        const float* __restrict__ noise, const float* __restrict__ jit,
-                                                       float* __restrict__ Kw, float* __restrict__ Vm, int b0, int C, int N) {
+                                                       float* __restrict__ Kw, int b0, int C, int N, int nb) {
     const int m = blockIdx.y, b = b0 + m / C, c = m % C;
     const float* Eb = E + (size_t)b * N * N;
     float* K = Kw + (size_t)m * N * N;
-    float* V = Vm + (size_t)m * N * N;
     const float s = sv[c], dg = noise[c] + jit[m];
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * N; idx += gridDim.x * 256) {
         const int i = idx / N, j = idx - i * N;
-        K[idx] = s * Eb[idx] + (i == j ? dg : 0.f);
-        V[idx] = 0.f;
+        if (j / nb <= i / nb) K[idx] = s * Eb[idx] + (i == j ? dg : 0.f);
     }
 }
 
@@ -116,22 +146,34 @@ __global__ void big_retry_kernel(const int32_t* __restrict__ info, float* __rest
     }
 }
 
-// w = V^T r (TR = true) or alpha = V w (TR = false) with V upper (block-)triangular, one workgroup per matrix
+// w = V^T r (TR = true) or alpha = V w (TR = false) with V upper (block-)triangular, one workgroup per matrix.
+// TR: a thread owns output i and walks down column i (consecutive threads read consecutive addresses of a row of V);
+// non-TR: a wave owns output i and reduces over the row.
 template <bool TR>
 __global__ __launch_bounds__(256) void big_matvec_kernel(const float* __restrict__ Vm, const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ Y, long y_bstride, const float* __restrict__ mean,
                                                          int b0, int C, int N, bool x_is_targets) {
+    extern __shared__ float xs[];
     const int m = blockIdx.x, b = b0 + m / C, c = m % C;
     const float* V = Vm + (size_t)m * N * N;
     const float* xv = x_is_targets ? (Y + (size_t)b * y_bstride + (size_t)c * N) : (x + (size_t)m * N);
     const float shift = x_is_targets ? mean[c] : 0.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < N; i += 4) {                 // one wave per output element
-        float s = 0.f;
-        if (TR) { for (int k = lane; k <= i; k += 64) s = __builtin_fmaf(V[(size_t)k * N + i], xv[k] - shift, s); }   // (V^T r)_i = sum_{k<=i} V_ki r_k
-        else { for (int k = i + lane; k < N; k += 64) s = __builtin_fmaf(V[(size_t)i * N + k], xv[k] - shift, s); }   // (V w)_i = sum_{k>=i} V_ik w_k
-        s = wave_sum(s);
-        if (lane == 0) y[(size_t)m * N + i] = s;
+    for (int i = threadIdx.x; i < N; i += 256) xs[i] = xv[i] - shift;
+    __syncthreads();
+    if (TR) {
+        for (int i = threadIdx.x; i < N; i += 256) {    // (V^T r)_i = sum_{k<=i} V_ki r_k
+            float s = 0.f;
+            for (int k = 0; k <= i; ++k) s = __builtin_fmaf(V[(size_t)k * N + i], xs[k], s);
+            y[(size_t)m * N + i] = s;
+        }
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = wave; i < N; i += 4) {             // (V w)_i = sum_{k>=i} V_ik w_k
+            float s = 0.f;
+            for (int k = i + lane; k < N; k += 64) s = __builtin_fmaf(V[(size_t)i * N + k], xs[k], s);
+            s = wave_sum(s);
+            if (lane == 0) y[(size_t)m * N + i] = s;
+        }
     }
 }
 
@@ -220,7 +262,8 @@ __global__ __launch_bounds__(256) void big_chol_out_kernel(MllArgs a, const floa
     }
 }
 
-inline int big_nb(int N) { const int nbk = (N + 110) / 111; return (N + nbk - 1) / nbk; }
+// block size: <= 108 rows (the register sweep needs nb + 1 <= 112), a multiple of 4 so that block origins stay 16-byte aligned
+inline int big_nb(int N) { const int nbk = (N + 107) / 108; return (((N + nbk - 1) / nbk) + 3) & ~3; }
 constexpr int BIG_CHUNK = 128;          // episodes per chunk of the workspace
 
 inline size_t big_ws_floats(int Bc, int C, int N) {
@@ -263,7 +306,7 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
         const int nmat = bcnt * C;
         if (hipMemsetAsync(jit, 0, nmat_max * sizeof(float) * 3, st) != hipSuccess) return DKT_ERR_LAUNCH;   // jit, attempt_of, info_m
         for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
-            hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, Vm, b0, C, N);
+            hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, b0, C, N, nb);
             if (hipMemsetAsync(info_m, 0, nmat * sizeof(int32_t), st) != hipSuccess) return DKT_ERR_LAUNCH;
             // ---- blocked Cholesky with explicit inverses of the diagonal blocks ----
             for (int j = 0; j < nbk; ++j) {
@@ -291,8 +334,8 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
             }
         }
         // ---- w = V^T r, alpha = V w ----
-        hipLaunchKernelGGL((big_matvec_kernel<true>), dim3(nmat), dim3(256), 0, st, Vm, (const float*)nullptr, wv, a.Y, a.y_bstride, a.mean, b0, C, N, true);
-        hipLaunchKernelGGL((big_matvec_kernel<false>), dim3(nmat), dim3(256), 0, st, Vm, wv, al, a.Y, a.y_bstride, a.mean, b0, C, N, false);
+        hipLaunchKernelGGL((big_matvec_kernel<true>), dim3(nmat), dim3(256), N * sizeof(float), st, Vm, (const float*)nullptr, wv, a.Y, a.y_bstride, a.mean, b0, C, N, true);
+        hipLaunchKernelGGL((big_matvec_kernel<false>), dim3(nmat), dim3(256), N * sizeof(float), st, Vm, wv, al, a.Y, a.y_bstride, a.mean, b0, C, N, false);
         hipLaunchKernelGGL(big_finish_kernel, dim3(nmat), dim3(256), 0, st, a, Lm, Vm, wv, al, jit, info_m, b0);
         if (a.flags & DKT_MLL_WANT_CHOL) hipLaunchKernelGGL(big_chol_out_kernel, dim3(32, nmat), dim3(256), 0, st, a, Lm, info_m, b0);
         if (want_grad) {

@@ -705,8 +705,10 @@ __global__ __launch_bounds__(256, NT <= 7 ? 4 : 2) void chol_inv_block_kernel(co
             const int p = ty + 16 * pi, j = tx + 16 * ji;
             if (p < nb && j < nb) {
                 const float v = AE(pi, ji) * rinvcol[ji];
-                if (p > j) Lb[(size_t)p * ldl + j] = v;
-                else if (p < j) Ub[(size_t)p * ldu + j] = v;
+                if (p > j) {
+                    Lb[(size_t)p * ldl + j] = v;
+                    Ub[(size_t)p * ldu + j] = 0.f;          // consumers multiply with the full U block: its lower part must be 0
+                } else if (p < j) Ub[(size_t)p * ldu + j] = v;
                 else {
                     Lb[(size_t)p * ldl + j] = 1.0f / rinvcol[ji];
                     Ub[(size_t)p * ldu + j] = rinvcol[ji];
