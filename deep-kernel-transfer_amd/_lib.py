@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
-SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_blk.hip", "dkt_mll_wave.hip", "dkt_predict.hip",
+SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_blk.hip", "dkt_mll_wave.hip", "dkt_predict.hip", "dkt_spectral.hip",
            "dkt_frontend.hip", "dkt_diag.hip"]     # dkt_diag: measurement-only kernels, outside the ABI header
 HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"),
            os.path.join(CSRC, "dkt_split.h"), os.path.join(INCLUDE, "dkt_abi.h")]
@@ -42,6 +42,8 @@ SIGNATURES = {
     "dkt_gram_bn_f32": (_c_i, [_c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_gram_bn_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                    _c_i, _c_i, _c_i, _c_p]),
+    "dkt_smk_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_smk_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
 }
 
 _lock = threading.Lock()

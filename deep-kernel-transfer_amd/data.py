@@ -57,3 +57,48 @@ def get_episode_loader(params, split, n_way, n_support, n_query, n_episode, imag
     sizes = {'base': 64, 'val': 32, 'novel': 40}
     return SyntheticEpisodeLoader(n_way, n_support, n_query, n_episode, image_size, n_classes=max(sizes[split], n_way),
                                   class_offset=offsets[split], seed=seed + {'base': 0, 'val': 1, 'novel': 2}[split])
+
+
+class SyntheticHeadPoseSampler:
+    """Stand-in for the QMUL head-pose sampler (reference data/qmul_loader.py:41-59 `get_batch`): a call returns
+    (inputs [P, 19, 3, 100, 100], targets [P, 19]) -- one trajectory of 19 frames per person, the target being the
+    normalised pitch in [-1, 1] that follows amp * sin(phase + t), amp ~ U(-3, 3), phase ~ U(-5, 5), quantised to the
+    dataset's 10-degree grid exactly as the reference maps the curve to image files.  The frame of (person, pitch, angle)
+    is that person's fixed low-frequency "face" shifted vertically with the pitch and horizontally with the yaw angle,
+    plus pixel noise, so a backbone can learn the pose.  24 train / 5 test people like the dataset's split."""
+
+    def __init__(self, seed=0, image_size=100, num_samples=19, n_train=24, n_test=5, noise=0.05):
+        self.hw, self.num_samples, self.noise = image_size, num_samples, noise
+        self.people = {"train": list(range(n_train)), "test": list(range(n_train, n_train + n_test))}
+        self.rng = __import__("numpy").random.RandomState(1234 + seed)
+        self.gen = torch.Generator().manual_seed(4321 + seed)
+        self._faces = {}
+
+    def _face(self, person):
+        f = self._faces.get(person)
+        if f is None:
+            g = torch.Generator().manual_seed(104729 * (person + 1))
+            low = torch.rand(3, 6, 6, generator=g)
+            f = torch.nn.functional.interpolate(low[None], size=(self.hw + 40, self.hw + 40), mode='bilinear', align_corners=False)[0]
+            self._faces[person] = f
+        return f
+
+    def __call__(self, split="train"):
+        np = __import__("numpy")
+        amp, phase = self.rng.uniform(-3, 3), self.rng.uniform(-5, 5)
+        wave = [amp * np.sin(phase + x) for x in range(self.num_samples)]
+        angles = [10 * x for x in range(self.num_samples)]
+        pitches = [int(round((y + 3) * 10 + 60, -1)) for y in wave]
+        inputs, targets = [], []
+        for person in self.people[split]:
+            face = self._face(person)
+            frames = []
+            for pitch, angle in zip(pitches, angles):
+                dy = 20 + int(round((pitch - 90) / 30.0 * 18))          # pitch 60..120 -> vertical shift
+                dx = 20 + int(round((angle - 90) / 90.0 * 18))          # yaw 0..180 -> horizontal shift
+                frames.append(face[:, dy:dy + self.hw, dx:dx + self.hw])
+            x = torch.stack(frames)
+            x = (x + self.noise * torch.randn(x.shape, generator=self.gen)).clamp(0.0, 1.0)
+            inputs.append(x)
+            targets.append(torch.tensor([2.0 * ((p - 60) / 60.0) - 1.0 for p in pitches], dtype=torch.float32))
+        return torch.stack(inputs), torch.stack(targets)

@@ -218,6 +218,31 @@ class DKT(MetaTemplate):
         mu, labels = ops.predict(ex, out["alpha"], sv.detach(), mean.detach())
         return mu[0], labels[0], out
 
+    def _posterior_fused_eval(self, x_support, x_query, y):
+        """Test-time episode with bn_out (eval mode: running statistics) + F.normalize folded into ONE Gram launch over the
+        stacked [support; query] trunk features (one backbone pass instead of two): E_all = Zn Zn^T, the conditioning matrix is
+        its [:ns, :ns] block and the cross kernel its [ns:, :ns] block.  Returns None when the fused kernels do not apply."""
+        ns, nq = x_support.shape[0], x_query.shape[0]
+        bn = getattr(self.feature_extractor.trunk, "bn_out", None) if self.kernel_type == "bncossim" else None
+        if self.feature_extractor.training or (bn is not None and not bn.track_running_stats):
+            return None
+        x_feat = self._trunk_features(torch.cat([x_support, x_query], 0)).detach()
+        d = x_feat.shape[1]
+        if x_feat.dim() != 2 or not self._fused_front_end(ns + nq, d):
+            return None
+        if bn is not None:
+            a = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps) if bn.affine else torch.rsqrt(bn.running_var + bn.eps)
+            s = (bn.bias.detach() if bn.affine else 0.0) - bn.running_mean * a
+        else:
+            a = torch.ones(d, device=x_feat.device, dtype=torch.float32)
+            s = torch.zeros(d, device=x_feat.device, dtype=torch.float32)
+        e_all, _ = ops.gram_bn(x_feat.unsqueeze(0).contiguous(), a.contiguous(), s.contiguous())
+        sv, mean, noise = self._hypers()
+        out = ops.mll(e_all[:, :ns, :ns].contiguous(), y, sv.detach(), mean.detach(), noise.detach(), jitter0=self.jitter0,
+                      max_tries=self.max_tries)
+        mu, labels = ops.predict(e_all[:, ns:, :ns].contiguous(), out["alpha"], sv.detach(), mean.detach())
+        return mu[0], labels[0], out
+
     def _sync_grads(self):
         if distributed.is_distributed():
             if self._grad_bucket is None:
@@ -328,7 +353,11 @@ class DKT(MetaTemplate):
 
         dev = self.device
         y_targets = self._targets(self.n_way, self.n_support, dev)
-        z_train = self._embed(x_support).detach()
+        fused = None
+        if N == 0:
+            with torch.no_grad():
+                fused = self._posterior_fused_eval(x_support, x_query, y_targets)
+        z_train = self._embed(x_support).detach() if fused is None else None
 
         self.model.train()
         self.likelihood.train()
@@ -348,8 +377,11 @@ class DKT(MetaTemplate):
             self.model.eval()
             self.likelihood.eval()
             self.feature_extractor.eval()
-            z_query = self._embed(x_query).detach()
-            _, labels, out = self._posterior(z_train, y_targets, z_query)
+            if fused is None:
+                z_query = self._embed(x_query).detach()
+                _, labels, out = self._posterior(z_train, y_targets, z_query)
+            else:
+                _, labels, out = fused
             y_q = torch.arange(self.n_way, device=dev, dtype=torch.int32).repeat_interleave(self.n_query)
             stats = torch.stack([(labels == y_q).sum().float(), out["info"].abs().max().float()]).cpu()
             if stats[1].item() != 0:
@@ -388,11 +420,16 @@ class DKT(MetaTemplate):
         self._check_way(self.n_way)
         x_support, x_query = self._split(x)
         y_targets = self._targets(self.n_way, self.n_support, self.device)
-        z_train = self._embed(x_support).detach()
+        with torch.no_grad():
+            fused = self._posterior_fused_eval(x_support, x_query, y_targets)
+        z_train = self._embed(x_support).detach() if fused is None else None
         with torch.no_grad():
             self.model.eval()
             self.likelihood.eval()
             self.feature_extractor.eval()
-            z_query = self._embed(x_query).detach()
-            mu, _, _ = self._posterior(z_train, y_targets, z_query)
+            if fused is None:
+                z_query = self._embed(x_query).detach()
+                mu, _, _ = self._posterior(z_train, y_targets, z_query)
+            else:
+                mu = fused[0]
         return mu.t().contiguous()    # [n_way*n_query, n_way] raw posterior means (DKT.py:331-335)

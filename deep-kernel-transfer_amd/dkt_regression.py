@@ -18,17 +18,18 @@ import torch
 import torch.nn as nn
 
 from . import configs, ops
-from .gp import ExactGPHypers, RBF_KINDS
+from .gp import ExactGPHypers, RBF_KINDS, SPECTRAL_KINDS
 
 
 class DKT(nn.Module):
-    def __init__(self, backbone, kernel_type=None, batch_fn=None):
+    def __init__(self, backbone, kernel_type=None, batch_fn=None, num_mixtures=4, ard_num_dims=2916):
         super(DKT, self).__init__()
         self.kernel_type = configs.kernel_type if kernel_type is None else kernel_type
-        if self.kernel_type not in RBF_KINDS:
-            # 'spectral' (SpectralMixtureKernel, DKT_regression.py:121-122) is not built yet
+        if self.kernel_type not in RBF_KINDS + SPECTRAL_KINDS:
             raise ValueError("[ERROR] the kernel '" + str(self.kernel_type) +
-                             "' is not supported for regression, use 'rbf'.")
+                             "' is not supported for regression, use 'rbf' or 'spectral'.")
+        # SpectralMixtureKernel(num_mixtures=4, ard_num_dims=2916), DKT_regression.py:122 (2916 = Conv3's feature size)
+        self.num_mixtures, self.ard_num_dims = num_mixtures, ard_num_dims
         self.feature_extractor = backbone
         self.batch_fn = batch_fn
         self.jitter0 = 1e-6
@@ -36,7 +37,8 @@ class DKT(nn.Module):
         self.get_model_likelihood_mll()
 
     def get_model_likelihood_mll(self, train_x=None, train_y=None):
-        self.model = ExactGPHypers(1, self.kernel_type, fixed_noise=None)
+        self.model = ExactGPHypers(1, self.kernel_type, fixed_noise=None, num_mixtures=self.num_mixtures,
+                                   ard_num_dims=self.ard_num_dims)
         self.likelihood = self.model       # the Gaussian noise is stored with the GP hyper-parameters
         self.mse = nn.MSELoss()
         return self.model, self.likelihood, None
@@ -58,7 +60,10 @@ class DKT(nn.Module):
         n = zb.shape[1]
         m = self.model
         cw = torch.full((1,), -1.0 / n, device=zb.device, dtype=torch.float32)
-        e = ops.base_matrix(zb, self.kernel_type, m.lengthscale)
+        if self.kernel_type in SPECTRAL_KINDS:
+            e = ops.spectral_mixture_matrix(zb, m.mixture_weights, m.mixture_means, m.mixture_scales)
+        else:
+            e = ops.base_matrix(zb, self.kernel_type, m.lengthscale)
         obj, logp, alpha, info, jit = ops.mll_objective(e, yb, m.scale_times_variance(), m.mean, m.noise, cw,
                                                         self.jitter0, self.max_tries)
         return obj.mean(), dict(logp=logp, alpha=alpha, info=info, jitter=jit)
@@ -85,14 +90,21 @@ class DKT(nn.Module):
         m = self.model
         sv, mean, noise, ls = m.scale_times_variance(), m.mean, m.noise, m.lengthscale
         zs = z_support.unsqueeze(0)
-        e = ops.gram(zs, None, ops.KERNEL_RBF, ls)
+        spectral = self.kernel_type in SPECTRAL_KINDS
+        if spectral:
+            mix = (m.mixture_weights, m.mixture_means, m.mixture_scales)
+            e = ops.smk(zs, None, *mix)[0]
+        else:
+            e = ops.gram(zs, None, ops.KERNEL_RBF, ls)
         out = ops.mll(e, y_support.reshape(1, 1, -1).to(torch.float32), sv, mean, noise, want_chol=with_variance,
                       jitter0=self.jitter0, max_tries=self.max_tries)
-        ex = ops.gram(z_all.unsqueeze(0), zs, ops.KERNEL_RBF, ls)
+        ex = ops.smk(z_all.unsqueeze(0), zs, *mix)[0] if spectral else ops.gram(z_all.unsqueeze(0), zs, ops.KERNEL_RBF, ls)
         mu, _ = ops.predict(ex, out["alpha"], sv, mean, want_labels=False)
         if not with_variance:
             return mu[0, 0], None
-        exx = torch.ones((1, z_all.shape[0]), device=z_all.device, dtype=torch.float32)   # k(x,x) = 1 for RBF
+        # k(x,x): 1 for RBF, sum of the mixture weights for the spectral mixture (tau = 0)
+        kxx = float(m.mixture_weights.sum()) if spectral else 1.0
+        exx = torch.full((1, z_all.shape[0]), kxx, device=z_all.device, dtype=torch.float32)
         var = ops.predict_var(ex, exx, out["chol"], sv, noise)
         return mu[0, 0], var[0, 0]
 

@@ -8,6 +8,9 @@ methods/DKT_regression.py:25-37, 112-129):
   * LinearKernel.variance   -> `raw_variance` [1]; cossim/bncossim: variance = 1.0 and frozen (DKT.py:366-370)
   * RBFKernel / MaternKernel(nu=2.5).lengthscale -> `raw_lengthscale` [1], lengthscale = softplus(raw), init ln 2
   * PolynomialKernel.offset -> `raw_offset` [1] (poli1, poli2), offset = softplus(raw), init ln 2
+  * SpectralMixtureKernel(num_mixtures=Q, ard_num_dims=D) (regression only, DKT_regression.py:121-122; NOT wrapped in a
+                               ScaleKernel) -> `raw_mixture_weights` [Q], `raw_mixture_means` [Q,1,D],
+                               `raw_mixture_scales` [Q,1,D] (GPyTorch's shapes), all softplus(raw), raw init 0
   * GaussianLikelihood      -> `raw_noise` [C], noise = softplus(raw) + 1e-4 (GreaterThan(1e-4));
                                classification: noise forced to 0.1 and frozen (DKT.py:346-347);
                                regression: learned, init softplus(0) + 1e-4.
@@ -29,6 +32,7 @@ LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
 MATERN_KINDS = ("matern",)
 POLY_KINDS = ("poli1", "poli2")
+SPECTRAL_KINDS = ("spectral",)
 SUPPORTED_CLASSIFICATION = LINEAR_KINDS + RBF_KINDS + MATERN_KINDS + POLY_KINDS
 
 
@@ -37,14 +41,23 @@ def inv_softplus(y: float) -> float:
 
 
 class ExactGPHypers(nn.Module):
-    def __init__(self, n_models: int, kernel: str = "bncossim", fixed_noise: Optional[float] = 0.1):
+    def __init__(self, n_models: int, kernel: str = "bncossim", fixed_noise: Optional[float] = 0.1,
+                 num_mixtures: int = 4, ard_num_dims: Optional[int] = None):
         super().__init__()
-        if kernel not in SUPPORTED_CLASSIFICATION:
+        if kernel not in SUPPORTED_CLASSIFICATION + SPECTRAL_KINDS:
             raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
         self.n_models = n_models
         self.kernel = kernel
         self.mean_constant = nn.Parameter(torch.zeros(n_models))
-        self.raw_outputscale = nn.Parameter(torch.zeros(n_models))
+        if kernel in SPECTRAL_KINDS:      # no ScaleKernel around the spectral mixture: the base matrix enters K unscaled
+            if n_models != 1 or not ard_num_dims:
+                raise ValueError("the spectral kernel needs a single GP and ard_num_dims")
+            self.register_parameter("raw_outputscale", None)
+            self.raw_mixture_weights = nn.Parameter(torch.zeros(num_mixtures))
+            self.raw_mixture_means = nn.Parameter(torch.zeros(num_mixtures, 1, ard_num_dims))
+            self.raw_mixture_scales = nn.Parameter(torch.zeros(num_mixtures, 1, ard_num_dims))
+        else:
+            self.raw_outputscale = nn.Parameter(torch.zeros(n_models))
         if kernel in ("cossim", "bncossim"):
             # variance = 1.0, frozen
             self.raw_variance = nn.Parameter(torch.full((1,), inv_softplus(1.0)), requires_grad=False)
@@ -69,7 +82,21 @@ class ExactGPHypers(nn.Module):
     # ---- constrained values (differentiable torch ops on [C]-sized tensors) ----
     @property
     def outputscale(self) -> torch.Tensor:
+        if self.raw_outputscale is None:
+            return torch.ones(self.n_models, device=self.mean_constant.device, dtype=torch.float32)
         return F.softplus(self.raw_outputscale)
+
+    @property
+    def mixture_weights(self) -> torch.Tensor:
+        return F.softplus(self.raw_mixture_weights)
+
+    @property
+    def mixture_means(self) -> torch.Tensor:
+        return F.softplus(self.raw_mixture_means)
+
+    @property
+    def mixture_scales(self) -> torch.Tensor:
+        return F.softplus(self.raw_mixture_scales)
 
     @property
     def variance(self) -> Optional[torch.Tensor]:
@@ -119,7 +146,7 @@ class ExactGPHypers(nn.Module):
                     base + "covar_module.raw_outputscale": (self.raw_outputscale, c),
                     base + "likelihood.noise_covar.raw_noise": (self.raw_noise, c),
                 }.items():
-                    if key in state:
+                    if key in state and dst is not None:
                         dst[idx] = state[key].reshape(-1)[0].to(dst)
                         used += 1
                 for key, dst in {
@@ -147,7 +174,8 @@ class _ModelView:
     def covar_module(self):
         h, c = self._h, self._c
         ls = h.lengthscale
-        return _Attr(outputscale=h.outputscale[c], raw_outputscale=h.raw_outputscale[c],
+        return _Attr(outputscale=h.outputscale[c],
+                     raw_outputscale=None if h.raw_outputscale is None else h.raw_outputscale[c],
                      base_kernel=_Attr(lengthscale=ls, variance=h.variance))
 
     @property

@@ -44,6 +44,28 @@ def parse_args(script, argv=None):
     return parser.parse_args(argv)
 
 
+def parse_args_regression(script, argv=None):
+    """Flags of the reference's regression drivers (io_utils.py:48-63).  `--dataset synthetic` (default here) draws
+    head-pose-like trajectories from `data.SyntheticHeadPoseSampler`; QMUL needs the image tree + torchvision.
+    `--spectral` selects the SpectralMixture kernel (the reference parses the flag but only reads configs.kernel_type)."""
+    parser = argparse.ArgumentParser(description='few-shot script %s' % script)
+    parser.add_argument('--seed', default=0, type=int, help='Seed for Numpy and pyTorch. Default: 0 (None)')
+    parser.add_argument('--model', default='Conv3', help='model: Conv{3}')
+    parser.add_argument('--method', default='DKT', help='DKT (the feature-transfer baseline is out of scope)')
+    parser.add_argument('--dataset', default='synthetic', help='synthetic / QMUL')
+    parser.add_argument('--spectral', action='store_true', help='Use a spectral covariance kernel function')
+    if script == 'train_regression':
+        parser.add_argument('--start_epoch', default=0, type=int, help='Starting epoch')
+        parser.add_argument('--stop_epoch', default=100, type=int, help='Stopping epoch')
+        parser.add_argument('--resume', action='store_true', help='continue from previous trained model with largest epoch')
+    elif script == 'test_regression':
+        parser.add_argument('--n_support', default=5, type=int, help='Number of points on trajectory to be given as support points')
+        parser.add_argument('--n_test_epochs', default=10, type=int, help='How many test people?')
+    else:
+        raise ValueError('Unknown script')
+    return parser.parse_args(argv)
+
+
 def get_assigned_file(checkpoint_dir, num):
     return os.path.join(checkpoint_dir, '{:d}.tar'.format(num))
 

@@ -268,6 +268,56 @@ def predict_var(ex: torch.Tensor, exx: torch.Tensor, chol: torch.Tensor, sv: tor
     return var
 
 
+def smk(x1: torch.Tensor, x2: Optional[torch.Tensor], weights: torch.Tensor, means: torch.Tensor, scales: torch.Tensor,
+        want_terms: bool = False):
+    """Spectral-mixture matrix E[b] = k(x1[b], x2[b]) (x2 None: symmetric); weights [Q], means / scales [Q,D]
+    (constrained values).  Returns (E, Eq) with Eq [B,Q,M,N] the per-mixture terms (None unless want_terms)."""
+    x1 = _req(x1, "x1", 3)
+    b_, m, d = x1.shape
+    if x2 is not None:
+        x2 = _req(x2, "x2", 3)
+        if x2.shape[0] != b_ or x2.shape[2] != d:
+            raise RuntimeError("smk: shape mismatch %s vs %s" % (tuple(x1.shape), tuple(x2.shape)))
+        n = x2.shape[1]
+    else:
+        n = m
+    weights = _req(weights.reshape(-1), "weights", 1)
+    q = weights.numel()
+    means = _req(means.reshape(q, -1), "means", 2)
+    scales = _req(scales.reshape(q, -1), "scales", 2)
+    if means.shape[1] != d or scales.shape[1] != d:
+        raise RuntimeError("smk: means / scales must be [Q,D] with D = %d" % d)
+    e = torch.empty((b_, m, n), device=x1.device, dtype=torch.float32)
+    eq = torch.empty((b_, q, m, n), device=x1.device, dtype=torch.float32) if want_terms else None
+    lib = _lib.load()
+    with _timed("dkt_smk_f32"):
+        st = lib.dkt_smk_f32(_p(x1), _p(x2), _p(weights), _p(means), _p(scales), _p(e), _p(eq), b_, m, n, d, q, _stream())
+    _lib.check(st, "dkt_smk_f32")
+    return e, eq
+
+
+def smk_bwd(ge: torch.Tensor, eq: torch.Tensor, x: torch.Tensor, weights: torch.Tensor, means: torch.Tensor,
+            scales: torch.Tensor):
+    """Chain rule of the symmetric spectral-mixture matrix: (dx [B,N,D], dmeans [B,Q,D], dscales [B,Q,D])."""
+    ge = _req(ge, "ge", 3)
+    eq = _req(eq, "eq", 4)
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    q = eq.shape[1]
+    weights = _req(weights.reshape(-1), "weights", 1)
+    means = _req(means.reshape(q, -1), "means", 2)
+    scales = _req(scales.reshape(q, -1), "scales", 2)
+    dx = torch.empty_like(x)
+    dmeans = torch.empty((b_, q, d), device=x.device, dtype=torch.float32)
+    dscales = torch.empty((b_, q, d), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_smk_bwd_f32"):
+        st = lib.dkt_smk_bwd_f32(_p(ge), _p(eq), _p(x), _p(weights), _p(means), _p(scales), _p(dx), _p(dmeans), _p(dscales),
+                                 b_, n, d, q, _stream())
+    _lib.check(st, "dkt_smk_bwd_f32")
+    return dx, dmeans, dscales
+
+
 # ------------------------------------------------------------------------------------------------
 # autograd
 # ------------------------------------------------------------------------------------------------
@@ -310,6 +360,31 @@ class _SqDistFn(torch.autograd.Function):
         dz = gram_bwd(wp, z) if ctx.needs_input_grad[0] else None
         dl = dlb.sum().reshape(lengthscale.shape) if ctx.needs_input_grad[1] else None
         return dz, dl
+
+
+class _SpectralMixtureFn(torch.autograd.Function):
+    """E = SpectralMixtureKernel(z, z) differentiable in z, the mixture weights, means and scales."""
+
+    @staticmethod
+    def forward(ctx, z, weights, means, scales):
+        e, eq = smk(z, None, weights, means, scales, want_terms=True)
+        ctx.save_for_backward(z, eq, weights, means, scales)
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        z, eq, weights, means, scales = ctx.saved_tensors
+        ge = ge.contiguous()
+        dz, dmb, dsb = smk_bwd(ge, eq, z, weights, means, scales)
+        dw = (ge.unsqueeze(1) * eq).sum((0, 2, 3)).reshape(weights.shape) if ctx.needs_input_grad[1] else None
+        dm = dmb.sum(0).reshape(means.shape) if ctx.needs_input_grad[2] else None
+        ds = dsb.sum(0).reshape(scales.shape) if ctx.needs_input_grad[3] else None
+        return (dz if ctx.needs_input_grad[0] else None), dw, dm, ds
+
+
+def spectral_mixture_matrix(z: torch.Tensor, weights: torch.Tensor, means: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """Differentiable symmetric spectral-mixture matrix [B,N,N] of z [B,N,D] (reference DKT_regression.py:121-122)."""
+    return _SpectralMixtureFn.apply(z, weights, means, scales)
 
 
 def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None,

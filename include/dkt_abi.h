@@ -177,6 +177,26 @@ int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const fl
                         const float* mean, const float* rstd, const float* rnorm, const float* ep_scale, float* dX,
                         float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream);
 
+/*
+ * dkt_smk_f32 -- spectral-mixture base kernel of the regression head
+ *   (gpytorch.kernels.SpectralMixtureKernel(num_mixtures=4, ard_num_dims=2916), methods/DKT_regression.py:121-122):
+ *   E[b,i,j] = sum_q weights[q] prod_d exp(-2 pi^2 (scales[q,d] tau_d)^2) cos(2 pi means[q,d] tau_d),
+ *   tau = x1[b,i,:] - x2[b,j,:].   x1:[B,M,D]; x2:[B,N,D] or NULL (symmetric, M == N); weights:[Q]; means, scales:[Q,D]
+ *   (constrained values); Q <= 8.  Eq[B,Q,M,N] (nullable) receives the per-mixture terms the backward needs.
+ */
+int dkt_smk_f32(const float* x1, const float* x2, const float* weights, const float* means, const float* scales,
+                float* E, float* Eq, int B, int M, int N, int D, int Q, void* stream);
+
+/*
+ * dkt_smk_bwd_f32 -- chain rule of the symmetric spectral-mixture matrix: given gE[b] = d obj / d E[b] (any, not
+ *   necessarily symmetric) and Eq of the forward, returns dx[B,N,D] and the per-episode parts dmeans[B,Q,D],
+ *   dscales[B,Q,D] (the caller sums over b; d obj / d weights[q] = sum_bij gE Eq is an element-wise reduction left to
+ *   the caller).  N <= 232.  Replaces autograd through the kernel's forward (loss.backward(), DKT_regression.py:56).
+ */
+int dkt_smk_bwd_f32(const float* gE, const float* Eq, const float* x, const float* weights, const float* means,
+                    const float* scales, float* dx, float* dmeans, float* dscales, int B, int N, int D, int Q,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

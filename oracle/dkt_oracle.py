@@ -22,6 +22,7 @@ Reference call sites restated here (file:line under /root/reference):
   methods/DKT.py:297-335            get_logits                         -> posterior_mean (stacked [M, C])
   methods/DKT_regression.py:45-64   loss = -ExactMLL(pred, targets)    -> regression_loss
   methods/DKT_regression.py:66-97   condition on support, predict all, MSE -> regression_predict
+  methods/DKT_regression.py:121-122 SpectralMixtureKernel(num_mixtures=4, ard_num_dims=2916) -> gram_spectral_mixture
 GPyTorch 1.0.1 semantics restated (from its published source, recalled):
   utils/cholesky.py psd_safe_cholesky  : try plain Cholesky, then total diagonal jitter
                                          1e-6, 1e-5, 1e-4 (fp32) / 1e-8.. (fp64), 3 tries.
@@ -31,6 +32,8 @@ GPyTorch 1.0.1 semantics restated (from its published source, recalled; see DESI
   constraints: Positive() = softplus(raw); GaussianLikelihood noise = softplus(raw) + 1e-4
   kernels/rbf_kernel.py + kernel.py    : x/lengthscale, squared distance through the centred
                                          norm expansion, clamp >= 0, exp(-d2/2)
+  kernels/spectral_mixture_kernel.py   : k = sum_q w_q prod_d exp(-2 pi^2 (x1 s_qd - x2 s_qd)^2) cos(2 pi (x1 m_qd - x2 m_qd));
+                                         weights [Q], means / scales [Q,1,D], all softplus(raw), raw init 0; no ScaleKernel
   models/exact_prediction_strategies.py: mean_cache = (K + s2 I)^-1 (y - m);  mu* = m + K*^T mean_cache;
                                          cov* = K** - K*^T (K + s2 I)^-1 K*  (+ s2 I through the likelihood)
 """
@@ -145,6 +148,22 @@ def gram_matern25(za, zb=None, lengthscale=1.0):
 def gram_poly(za, zb=None, power=1, offset=0.0):
     """PolynomialKernel(power): (a.b + offset)^power, offset = softplus(raw_offset)."""
     return (gram_linear(za, zb) + offset) ** power
+
+
+def gram_spectral_mixture(za, zb, weights, means, scales, terms=False):
+    """SpectralMixtureKernel: sum_q w_q prod_d exp(-2 pi^2 (sigma_qd tau_d)^2) cos(2 pi mu_qd tau_d), tau = a - b.
+    weights [Q], means / scales [Q,D] (constrained values).  terms=True also returns the per-mixture matrices [Q,M,N]."""
+    za = np.asarray(za, dtype=np.float64)
+    zb = za if zb is None else np.asarray(zb, dtype=np.float64)
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    mu = np.asarray(means, dtype=np.float64).reshape(w.size, -1)
+    sg = np.asarray(scales, dtype=np.float64).reshape(w.size, -1)
+    tau = za[:, None, :] - zb[None, :, :]                                   # [M,N,D]
+    eq = np.empty((w.size, za.shape[0], zb.shape[0]))
+    for q in range(w.size):
+        eq[q] = (np.exp(-2.0 * math.pi ** 2 * (tau * sg[q]) ** 2) * np.cos(2.0 * math.pi * tau * mu[q])).prod(-1)
+    e = np.tensordot(w, eq, axes=(0, 0))
+    return (e, eq) if terms else e
 
 
 # ----------------------------------------------------------------------------------------------
@@ -325,6 +344,7 @@ class GPHypers:
     noise: np.ndarray
     lengthscale: float = math.log(2.0)
     variance: float = 1.0
+    mixture: tuple = None      # spectral kernel only: (weights [Q], means [Q,D], scales [Q,D]), constrained values
 
     @staticmethod
     def init_classification(n_way):
@@ -346,6 +366,8 @@ def base_matrix(za, zb, kernel, hyp: GPHypers):
         return gram_poly(za, zb, 1, hyp.lengthscale)  # offset carried in .lengthscale slot
     if kernel == "poli2":
         return gram_poly(za, zb, 2, hyp.lengthscale)
+    if kernel == "spectral":
+        return gram_spectral_mixture(za, zb, *hyp.mixture)
     raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
 
 
@@ -413,7 +435,10 @@ def regression_predict(z_support, y_support, z_all, hyp: GPHypers, kernel="rbf",
     res = mll_terms(e, np.asarray(y_support, dtype=np.float64)[None, :], sv, hyp.mean, hyp.noise, jitter0)
     ex = base_matrix(za, zs, kernel, hyp)
     mu = posterior_mean(ex, res.alpha, sv, hyp.mean)[0]
-    exx_diag = np.ones(za.shape[0]) if kernel in ("rbf", "RBF", "matern") else (za * za).sum(1)
+    if kernel == "spectral":
+        exx_diag = np.full(za.shape[0], float(np.sum(hyp.mixture[0])))      # tau = 0: every mixture term is 1
+    else:
+        exx_diag = np.ones(za.shape[0]) if kernel in ("rbf", "RBF", "matern") else (za * za).sum(1)
     var = posterior_var(ex, exx_diag, res.chol, sv, hyp.noise, add_noise=True)[0]
     return dict(mean=mu, var=var, lower=mu - 2.0 * np.sqrt(var), upper=mu + 2.0 * np.sqrt(var))
 

@@ -51,6 +51,16 @@ def base_matrix(za, zb, kernel, lengthscale=None):
     raise ValueError(kernel)
 
 
+def spectral_mixture(za, zb, weights, means, scales):
+    """SpectralMixtureKernel (DKT_regression.py:121-122) with torch ops, differentiable in every argument."""
+    zb_ = za if zb is None else zb
+    q = weights.numel()
+    tau = za[:, None, :] - zb_[None, :, :]
+    mu, sg = means.reshape(q, 1, 1, -1), scales.reshape(q, 1, 1, -1)
+    res = torch.exp(-2.0 * math.pi ** 2 * (tau * sg) ** 2) * torch.cos(2.0 * math.pi * tau * mu)
+    return (res.prod(-1) * weights.reshape(q, 1, 1)).sum(0)
+
+
 def psd_safe_cholesky(k, jitter0=None, max_tries=3):
     l, info = torch.linalg.cholesky_ex(k)
     if int(info) == 0:

@@ -104,5 +104,40 @@ def main():
     print("wrote degenerate; jitter used for the singular case:", tiny.jitter)
 
 
+def make_spectral():
+    """Regression head with the SpectralMixture kernel (DKT_regression.py:121-122): numpy restatement cross-checked against
+    an independent torch float64 formulation (whose autograd supplies the expected gradients) and scipy's logpdf."""
+    import torch
+    from scipy.stats import multivariate_normal
+    from oracle import dkt_oracle_torch as T
+    rng = np.random.default_rng(11)
+    n, d, q = 19, 48, 4
+    z = rng.standard_normal((n, d)) * 0.15
+    labels = rng.uniform(-1.0, 1.0, n)
+    w, mu, sg = rng.random(q) * 0.6 + 0.3, rng.random((q, d)) * 0.6 + 0.1, rng.random((q, d)) * 0.6 + 0.1
+    hyp = O.GPHypers(np.ones(1), np.array([0.1]), np.array([0.25]), mixture=(w, mu, sg))
+    out = O.regression_episode(z, labels, hyp, kernel="spectral")
+    ref = multivariate_normal(mean=np.full(n, 0.1), cov=out["e"] + 0.25 * np.eye(n)).logpdf(labels)
+    assert abs(ref - out["logp"][0]) < 1e-9 * abs(ref)
+    t = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (z, w, mu, sg)]
+    e_t = T.spectral_mixture(t[0], None, t[1], t[2], t[3])
+    assert np.abs(e_t.detach().numpy() - out["e"]).max() < 1e-13
+    lp, _ = T.gp_logp(e_t, torch.tensor(labels), torch.ones((), dtype=torch.float64), torch.tensor(0.1, dtype=torch.float64),
+                      torch.tensor(0.25, dtype=torch.float64))
+    (-lp / n).backward()
+    sup = [0, 3, 7, 11, 18]
+    pred = O.regression_predict(z[sup], labels[sup], z, hyp, kernel="spectral")
+    np.savez_compressed(os.path.join(OUT, "regression_spectral_q4.npz"), z=z, labels=labels, weights=w, means=mu, scales=sg,
+                        mean=hyp.mean, noise=hyp.noise, e=out["e"], logp=out["logp"], loss=out["loss"], alpha=out["alpha"],
+                        dz=t[0].grad.numpy(), dweights=t[1].grad.numpy(), dmeans=t[2].grad.numpy(), dscales=t[3].grad.numpy(),
+                        dmean=out["dmean"], dnoise=out["dnoise"], support=np.array(sup), pred_mean=pred["mean"], pred_var=pred["var"],
+                        logp_scipy=ref)
+    print("wrote regression_spectral_q4: loss", out["loss"])
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["spectral"]:
+        make_spectral()
+    else:
+        main()
+        make_spectral()

@@ -5,9 +5,9 @@ import numpy as np
 import torch
 
 import dkt_amd
-from dkt_amd.data import SyntheticEpisodeLoader, get_episode_loader
+from dkt_amd.data import SyntheticEpisodeLoader, SyntheticHeadPoseSampler, get_episode_loader
 from dkt_amd.io_utils import (checkpoint_dir_for, default_image_size, get_assigned_file, get_best_file,
-                              get_resume_file, parse_args)
+                              get_resume_file, parse_args, parse_args_regression)
 
 
 def test_parse_args_defaults_match_reference_flags():
@@ -19,6 +19,28 @@ def test_parse_args_defaults_match_reference_flags():
     assert (t.repeat, t.split, t.save_iter, t.adaptation) == (2, 'val', -1, False)
     assert default_image_size('Conv4', 'CUB') == 84 and default_image_size('Conv4S', 'omniglot') == 28
     assert default_image_size('ResNet10', 'miniImagenet') == 224
+
+
+def test_regression_flags_and_head_pose_sampler_contract():
+    """Reference io_utils.py:48-63 flags; data/qmul_loader.py:41-59 batch contract ([P,19,3,100,100], targets in [-1,1]
+    on the dataset's 10-degree pitch grid, one shared trajectory per call, 24 train / 5 test people)."""
+    p = parse_args_regression('train_regression', [])
+    assert (p.seed, p.model, p.method, p.spectral, p.start_epoch, p.stop_epoch, p.resume) == (0, 'Conv3', 'DKT', False, 0, 100, False)
+    t = parse_args_regression('test_regression', ['--spectral', '--n_support', '7'])
+    assert (t.spectral, t.n_support, t.n_test_epochs) == (True, 7, 10)
+    sampler = SyntheticHeadPoseSampler(seed=3)
+    x, y = sampler("train")
+    assert x.shape == (24, 19, 3, 100, 100) and x.dtype == torch.float32 and y.shape == (24, 19)
+    xt, yt = sampler("test")
+    assert xt.shape == (5, 19, 3, 100, 100) and yt.shape == (5, 19)
+    assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+    assert (y == y[:1]).all(), "every person follows the same trajectory within a batch"
+    grid = (y + 1.0) * 3.0                                   # pitch 60..120 in steps of 10 -> 0, 1/3, ..., 2 -> 0..6
+    assert torch.allclose(grid, grid.round(), atol=1e-5) and float(y.min()) >= -1.0 and float(y.max()) <= 1.0
+    x2, y2 = SyntheticHeadPoseSampler(seed=3)("train")
+    assert torch.equal(x, x2) and torch.equal(y, y2)
+    # the pose is visible in the frame: frames of one person differ along the trajectory
+    assert (x[0, 0] - x[0, 9]).abs().mean() > 0.01
 
 
 def test_checkpoint_path_helpers(tmp_path):

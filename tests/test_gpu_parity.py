@@ -830,6 +830,36 @@ def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
     assert countb == 75 and np.isfinite(avg) and avg != 0.0
 
 
+@pytest.mark.parametrize("kernel", ["bncossim", "cossim"])
+def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
+    """correct() / get_logits() with bn_out (running statistics) + F.normalize folded into one Gram launch over the stacked
+    [support; query] trunk features, against torch's BatchNorm1d / F.normalize in front of the same GP kernels."""
+    torch.manual_seed(1)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type=kernel).to(cuda)
+    m.train()
+    m.train_loop(0, _Loader(3, 5, 21, 28, 0), None)          # non-trivial running statistics and hyper-parameters
+    m.eval()
+    x = _Loader(1, 5, 20, 28, 5).x[0]
+    m.n_query = 15
+    used = []
+    orig = ops.gram_bn
+    monkeypatch.setattr(ops, "gram_bn", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+    logits_f = m.get_logits(x)
+    top_f = m.correct(x)
+    assert len(used) == 2, "the fused eval path must have run"
+    monkeypatch.setenv("DKT_FUSED_FRONTEND", "0")
+    logits_u = m.get_logits(x)
+    top_u = m.correct(x)
+    assert len(used) == 2
+    assert (logits_f - logits_u).abs().max().item() < 5e-5 * max(1.0, logits_u.abs().max().item())
+    assert top_f == top_u
+    # in train mode (batch statistics) the fused eval path must not be taken
+    monkeypatch.delenv("DKT_FUSED_FRONTEND")
+    m.train()
+    m.get_logits(x)
+    assert len(used) == 2
+
+
 def test_dkt_regression_surface(cuda):
     torch.manual_seed(0)
     bb = dkt_amd.backbone.Conv3()
@@ -858,6 +888,161 @@ def test_dkt_regression_surface(cuda):
     m.train_loop(0, opt, batch, labels)
     mse = m.test_loop(5, inputs=batch, targets=labels)
     assert mse.dim() == 0 and torch.isfinite(mse)
+
+
+# ----------------------------------------------------------------------------------------------
+# spectral-mixture kernel of the regression head (DKT_regression.py:121-122)
+# ----------------------------------------------------------------------------------------------
+def _smk_case(rng, b, m, n, d, q, spread):
+    a = (rng.standard_normal((b, m, d)) * spread).astype(np.float32)
+    c = (rng.standard_normal((b, n, d)) * spread).astype(np.float32)
+    w = (rng.random(q) + 0.2).astype(np.float32)
+    mu = (rng.random((q, d)) * 0.8 + 0.05).astype(np.float32)
+    sg = (rng.random((q, d)) * 0.8 + 0.05).astype(np.float32)
+    return a, c, w, mu, sg
+
+
+@pytest.mark.parametrize("b,m,n,d,q,spread", [(3, 19, 19, 2916, 4, 0.01), (2, 19, 5, 2916, 4, 0.01), (2, 7, 7, 70, 3, 0.2),
+                                               (1, 33, 9, 257, 1, 0.1), (2, 12, 12, 64, 8, 0.3), (1, 19, 19, 2916, 4, 1.0)])
+def test_spectral_mixture_forward_matches_oracle(cuda, b, m, n, d, q, spread):
+    """spread = 1.0 is the regime of raw backbone features: every off-diagonal product of 2916 cosines leaves the fp32
+    range, the matrix is sum(w) on the diagonal and (numerically) zero elsewhere -- in the oracle and on the GPU."""
+    rng = np.random.default_rng(b * 100 + d + q)
+    a, c, w, mu, sg = _smk_case(rng, b, m, n, d, q, spread)
+    sym = m == n
+    e, eq = ops.smk(dev_t(a, cuda), None if sym else dev_t(c, cuda), dev_t(w, cuda), dev_t(mu, cuda), dev_t(sg, cuda),
+                    want_terms=True)
+    e, eq = e.cpu().numpy(), eq.cpu().numpy()
+    for i in range(b):
+        ref, refq = O.gram_spectral_mixture(a[i], None if sym else c[i], w, mu, sg, terms=True)
+        assert np.abs(e[i] - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-30, np.abs(e[i] - ref).max()
+        assert np.abs(eq[i] - refq).max() <= 2e-5
+        if sym:
+            assert (e[i] == e[i].T).all()
+            np.testing.assert_allclose(np.diag(e[i]), np.full(m, w.astype(np.float64).sum()), rtol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,d,q,spread", [(2, 9, 70, 3, 0.2), (2, 19, 2916, 4, 0.01), (1, 30, 129, 2, 0.1)])
+def test_spectral_mixture_backward_matches_float64_autograd(cuda, b, n, d, q, spread):
+    rng = np.random.default_rng(n * 10 + q)
+    a, _, w, mu, sg = _smk_case(rng, b, n, n, d, q, spread)
+    ge = rng.standard_normal((b, n, n)).astype(np.float32)          # not symmetric on purpose
+    leaves = [dev_t(v, cuda).requires_grad_(True) for v in (a, w, mu, sg)]
+    e = ops.spectral_mixture_matrix(*leaves)
+    (e * dev_t(ge, cuda)).sum().backward()
+    ref = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (a, w, mu, sg)]
+    tot = 0.0
+    for i in range(b):
+        tot = tot + (T.spectral_mixture(ref[0][i], None, ref[1], ref[2], ref[3]) * torch.tensor(ge[i], dtype=torch.float64)).sum()
+    tot.backward()
+    for name, g, r in zip(("dz", "dweights", "dmeans", "dscales"), leaves, ref):
+        assert rel_l2(g.grad.cpu().numpy(), r.grad.numpy()) <= GRAD_RTOL, (name, rel_l2(g.grad.cpu().numpy(), r.grad.numpy()))
+
+
+def test_dkt_regression_spectral_kernel(cuda):
+    """DKT(backbone, 'spectral'): the loss and every gradient (mixture weights / means / scales, noise, mean, features)
+    against float64 autograd of the restated formulation, then the train / test loops run."""
+    torch.manual_seed(0)
+    d = 96
+    m = dkt_amd.DKTRegression(torch.nn.Identity(), "spectral", ard_num_dims=d).to(cuda)
+    assert sorted(n for n, _ in m.model.named_parameters()) == ["mean_constant", "raw_mixture_means", "raw_mixture_scales",
+                                                                "raw_mixture_weights", "raw_noise"]
+    assert tuple(m.model.raw_mixture_means.shape) == (4, 1, d) and tuple(m.model.raw_mixture_weights.shape) == (4,)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        m.model.raw_mixture_means.copy_(torch.randn(4, 1, d, generator=g) * 0.5 - 1.0)
+        m.model.raw_mixture_scales.copy_(torch.randn(4, 1, d, generator=g) * 0.5 - 1.0)
+        m.model.raw_mixture_weights.copy_(torch.randn(4, generator=g) * 0.3)
+        m.model.mean_constant.fill_(0.1)
+    z = (torch.randn(19, d, generator=g) * 0.15).to(cuda).requires_grad_(True)
+    labels = torch.rand(19, generator=g) * 2 - 1
+    loss, aux = m._loss(z, labels.to(cuda))
+    loss.backward()
+    import copy
+    ref = copy.deepcopy(m.model).cpu().double()
+    for p in ref.parameters():
+        p.grad = None
+    zr = z.detach().cpu().double().requires_grad_(True)
+    e = T.spectral_mixture(zr, None, ref.mixture_weights, ref.mixture_means, ref.mixture_scales)
+    lp, _ = T.gp_logp(e, labels.double(), torch.ones((), dtype=torch.float64), ref.mean[0], ref.noise[0])
+    loss_r = -lp / 19
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    assert rel_l2(z.grad.cpu().numpy(), zr.grad.numpy()) <= GRAD_RTOL
+    for (name, p), (_, pr) in zip(m.model.named_parameters(), ref.named_parameters()):
+        assert rel_l2(p.grad.cpu().numpy(), pr.grad.numpy()) <= GRAD_RTOL, name
+    # prediction against the oracle
+    hyp = O.GPHypers(np.ones(1), ref.mean.detach().numpy(), ref.noise.detach().numpy(),
+                     mixture=(ref.mixture_weights.detach().numpy(), ref.mixture_means.detach().numpy().reshape(4, d),
+                              ref.mixture_scales.detach().numpy().reshape(4, d)))
+    zn, yn = z.detach().cpu().numpy().astype(np.float64), labels.numpy().astype(np.float64)
+    sup = [0, 3, 7, 11, 18]
+    mu, var = m.predict(z.detach()[sup], labels.to(cuda)[sup], z.detach(), with_variance=True)
+    pr = O.regression_predict(zn[sup], yn[sup], zn, hyp, kernel="spectral")
+    np.testing.assert_allclose(mu.cpu().numpy(), pr["mean"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(var.cpu().numpy(), pr["var"], rtol=2e-4, atol=2e-5)
+    # full surface with the real backbone (raw Conv3 features: the matrix degenerates to sum(w) I, as in the reference)
+    bb = dkt_amd.backbone.Conv3()
+    m2 = dkt_amd.DKTRegression(bb, "spectral").to(cuda)
+    opt = torch.optim.Adam([{'params': m2.model.parameters(), 'lr': 1e-3}, {'params': m2.feature_extractor.parameters(), 'lr': 1e-3}])
+    batch = torch.rand(2, 19, 3, 100, 100, generator=g)
+    lab = torch.rand(2, 19, generator=g) * 2 - 1
+    m2.train_loop(0, opt, batch, lab)
+    mse = m2.test_loop(5, inputs=batch, targets=lab)
+    assert mse.dim() == 0 and torch.isfinite(mse)
+    assert all(torch.isfinite(p).all() for p in m2.parameters())
+
+
+def test_golden_spectral_regression_episode(cuda):
+    """The committed spectral-mixture fixture through the product path: loss, alpha, every gradient, the prediction."""
+    g = np.load(os.path.join(GOLD, "regression_spectral_q4.npz"))
+    d = g["z"].shape[1]
+    m = dkt_amd.DKTRegression(torch.nn.Identity(), "spectral", ard_num_dims=d).to(cuda)
+    inv = lambda v: torch.log(torch.expm1(torch.as_tensor(v, dtype=torch.float64))).float()      # softplus^-1
+    with torch.no_grad():
+        m.model.raw_mixture_weights.copy_(inv(g["weights"]))
+        m.model.raw_mixture_means.copy_(inv(g["means"]).reshape(4, 1, d))
+        m.model.raw_mixture_scales.copy_(inv(g["scales"]).reshape(4, 1, d))
+        m.model.mean_constant.copy_(torch.as_tensor(g["mean"]).float())
+        m.model.raw_noise.copy_(inv(g["noise"] - 1e-4))
+    z = dev_t(g["z"], cuda).requires_grad_(True)
+    hy = m.model
+    w, mu, sg = [v.detach().requires_grad_(True) for v in (hy.mixture_weights, hy.mixture_means, hy.mixture_scales)]
+    e = ops.spectral_mixture_matrix(z.unsqueeze(0), w, mu, sg)
+    np.testing.assert_allclose(e[0].detach().cpu().numpy(), g["e"], rtol=2e-5, atol=2e-6)
+    cw = torch.full((1,), -1.0 / 19, device=cuda)
+    obj, logp, alpha, info, jit = ops.mll_objective(e, dev_t(g["labels"], cuda).reshape(1, 1, -1), hy.scale_times_variance(),
+                                                    hy.mean.detach(), hy.noise.detach(), cw)
+    obj.sum().backward()
+    assert int(info.abs().sum()) == 0 and float(jit.abs().sum()) == 0.0
+    assert abs(obj.item() - float(g["loss"])) < MLL_RTOL * abs(float(g["loss"]))
+    assert rel_l2(alpha[0].cpu().numpy(), g["alpha"]) < 1e-4
+    for name, got, ref in (("dz", z.grad, g["dz"]), ("dweights", w.grad, g["dweights"]), ("dmeans", mu.grad.reshape(4, d), g["dmeans"]),
+                           ("dscales", sg.grad.reshape(4, d), g["dscales"])):
+        assert rel_l2(got.cpu().numpy(), ref) <= GRAD_RTOL, name
+    sup = g["support"].tolist()
+    pm, pv = m.predict(z.detach()[sup], dev_t(g["labels"], cuda)[sup], z.detach(), with_variance=True)
+    np.testing.assert_allclose(pm.cpu().numpy(), g["pred_mean"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(pv.cpu().numpy(), g["pred_var"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("flags", [[], ["--spectral"]])
+def test_regression_drivers_end_to_end(cuda, tmp_path, monkeypatch, capsys, flags):
+    """train_regression.py -> checkpoint file -> test_regression.py report (reference train_regression.py / test_regression.py)."""
+    import importlib
+    monkeypatch.chdir(tmp_path)
+    tr = importlib.import_module("train_regression")
+    te = importlib.import_module("test_regression")
+    model = tr.main(["--seed", "2", "--stop_epoch", "2"] + flags)
+    ckpt = tmp_path / "save" / "checkpoints" / "synthetic" / "Conv3_DKT"
+    assert ckpt.is_file()
+    state = torch.load(ckpt, map_location="cpu")
+    assert set(state) == {"gp", "likelihood", "net"} and "layer1.weight" in state["net"]
+    assert ("raw_mixture_means" in state["gp"]) == bool(flags)
+    mse = te.main(["--seed", "2", "--n_test_epochs", "3", "--n_support", "5"] + flags)
+    assert len(mse) == 3 and all(np.isfinite(v) and v >= 0.0 for v in mse)
+    out = capsys.readouterr().out
+    assert "[0] - Loss:" in out and "Average MSE: " in out and " +- " in out
 
 
 def test_drivers_end_to_end(cuda, tmp_path, monkeypatch, capsys):

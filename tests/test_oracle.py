@@ -154,3 +154,29 @@ def test_eval_episode_golden():
                              O.GPHypers(g["outputscale"], g["mean"], g["noise"]))
         np.testing.assert_allclose(out["mu"], g["mu"], rtol=1e-9, atol=1e-11)
         assert (out["labels"] == g["labels"]).all()
+
+
+def test_spectral_mixture_restatement_and_golden():
+    """SpectralMixtureKernel (DKT_regression.py:121-122): the numpy restatement against (i) the closed form for one
+    mixture in one dimension, (ii) an independent torch formulation, (iii) the committed fixture (generated with a scipy
+    logpdf cross-check, tests/golden/make_golden.py)."""
+    import torch
+    from oracle import dkt_oracle_torch as T
+    x = np.array([[0.3], [-0.2], [1.1]])
+    e = O.gram_spectral_mixture(x, None, [0.7], [[0.4]], [[0.9]])
+    tau = x - x.T
+    np.testing.assert_allclose(e, 0.7 * np.exp(-2 * np.pi ** 2 * (0.9 * tau) ** 2) * np.cos(2 * np.pi * 0.4 * tau), rtol=1e-13)
+    g = np.load(os.path.join(GOLD, "regression_spectral_q4.npz"))
+    hyp = O.GPHypers(np.ones(1), g["mean"], g["noise"], mixture=(g["weights"], g["means"], g["scales"]))
+    out = O.regression_episode(g["z"], g["labels"], hyp, kernel="spectral")
+    np.testing.assert_allclose(out["e"], g["e"], rtol=1e-12, atol=1e-15)
+    assert abs(out["loss"] - float(g["loss"])) < 1e-12 and abs(out["logp"][0] - float(g["logp_scipy"])) < 1e-9 * abs(out["logp"][0])
+    et = T.spectral_mixture(torch.tensor(g["z"]), None, torch.tensor(g["weights"]), torch.tensor(g["means"]), torch.tensor(g["scales"]))
+    np.testing.assert_allclose(et.numpy(), g["e"], rtol=1e-11, atol=1e-14)
+    # the matrix is symmetric PSD with sum(w) on the diagonal
+    np.testing.assert_allclose(np.diag(out["e"]), np.full(19, g["weights"].sum()), rtol=1e-13)
+    assert np.linalg.eigvalsh(out["e"]).min() > -1e-10
+    sup = g["support"]
+    pred = O.regression_predict(g["z"][sup], g["labels"][sup], g["z"], hyp, kernel="spectral")
+    np.testing.assert_allclose(pred["mean"], g["pred_mean"], rtol=1e-10)
+    np.testing.assert_allclose(pred["var"], g["pred_var"], rtol=1e-10)
