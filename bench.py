@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--episodes", type=int, default=8192, help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192})")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-test-time", action="store_true",
+                    help="skip the separately reported forward-only test-time episode (profiling runs: keeps the per-kernel "
+                         "averages of the trace to the training step's launches)")
     args = ap.parse_args()
 
     import dkt_amd
@@ -112,12 +115,16 @@ def main():
     cw = torch.full((c,), -1.0 / (c * n), device=dev)
     bucket = distributed.GradBucket([raw_s, mean])
 
+    UNIT_ROWS = os.environ.get("DKT_BENCH_UNIT", "1") != "0"
+
     def step():
         z.grad = None
         raw_s.grad = None
         mean.grad = None
         sv = torch.nn.functional.softplus(raw_s)
-        obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw)
+        # the features are bn_out'ed + L2-normalised rows (the cossim / bncossim contract): unit_rows lets the Gram kernels
+        # take the scaled 2-way f16 split; DKT_BENCH_UNIT=0 runs the range-agnostic 3-way bf16 split instead
+        obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=UNIT_ROWS)
         loss = obj.mean()
         loss.backward()
         bucket.allreduce_mean()          # the path's only exchange: shared hyper-parameter gradients
@@ -205,12 +212,15 @@ def main():
             "config": {"workload": "%s: %s; N=%d D=%d C=%d; training episode fwd+bwd (Gram + %d jittered Cholesky/"
                                    "solve/logdet + MLL + backward)" % (args.config, desc, n, d, c, c),
                        "episodes_per_step_per_gpu": b, "kernel": "bncossim", "parallelism": "episode-dp%d" % world,
-                       "arithmetic": "fp32 results; the two Gram contractions run as an exact 3-way bf16 split of every fp32 "
-                                     "operand (6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate), the factorisations in fp32"},
+                       "arithmetic": ("fp32 results; the two Gram contractions split every fp32 operand into two f16 pieces after an "
+                                      "exact power-of-two scaling (unit-norm rows; 22 of 24 significand bits, 3 "
+                                      "v_mfma_f32_16x16x32_f16 products, fp32 accumulate), the factorisations in fp32" if UNIT_ROWS else
+                                      "fp32 results; the two Gram contractions run as an exact 3-way bf16 split of every fp32 "
+                                      "operand (6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate), the factorisations in fp32")},
             "valid": ok, "deterministic": deterministic, "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
             "roofline_by_kernel": roofline_all, "kernels": kernels,
         }
-        if world == 1:
+        if world == 1 and not args.no_test_time:
             # the forward-only test-time episode (`correct`, DKT.py:199-272) reported separately:
             # condition on the 25 support features, predict the 75 queries (Gram, MLL without gradients, cross Gram, mean + arg-max)
             bt = min(b, 4096)
@@ -223,7 +233,7 @@ def main():
             def test_episode():
                 # ONE pass over the episode's features: the symmetric episode-resident Gram of [support; query] holds both
                 # k(support, support) and k(query, support) (the query-query block is the price of streaming at full rate)
-                e_all = ops.gram(z_te)
+                e_all = ops.gram(z_te, None, ops.KERNEL_LINEAR_UNIT if UNIT_ROWS else ops.KERNEL_LINEAR)
                 o = ops.mll(e_all[:, :ns, :ns].contiguous(), ys, svt, mean.detach(), noise)
                 return ops.predict(e_all[:, ns:, :ns].contiguous(), o["alpha"], svt, mean.detach())
 

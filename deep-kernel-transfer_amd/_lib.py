@@ -33,7 +33,7 @@ SIGNATURES = {
     "dkt_mll_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_i,
                            ctypes.c_uint, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                            _c_p, ctypes.c_size_t, _c_p]),
-    "dkt_gram_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "dkt_gram_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, ctypes.c_uint, _c_p]),
     "dkt_rbf_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_sqdist_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_predict_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused forward: one 256-thread workgroup per episode, the structure of gram_sym_ep_bf16x3_kernel<NT, 1, 1>.
+// Fused forward: one 256-thread workgroup per episode, the structure of gram_sym_ep_split_kernel<NT, 1, 1> (bf16 split).
 template <int NT>
 __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_sym_ep_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                                               const float* __restrict__ S, long ab_bstride,

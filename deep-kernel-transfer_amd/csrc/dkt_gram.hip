@@ -15,8 +15,8 @@
 #include "dkt_common.h"
 #include "../../include/dkt_abi.h"
 
-bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipStream_t st);
-bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st);
+bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
+bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st);
 
 namespace {
 
@@ -351,12 +351,15 @@ extern "C" int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* l
 extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, int M, int N, int D, int kind,
                             const float* lengthscale, void* stream) {
     if (!A || !E || B <= 0 || M <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    // LINEAR_UNIT = LINEAR plus the caller's promise |a_ik| <= 1: it only widens the choice of kernels
+    const bool unit = (kind == DKT_KERNEL_LINEAR_UNIT);
+    if (unit) kind = DKT_KERNEL_LINEAR;
     if (kind != DKT_KERNEL_LINEAR && kind != DKT_KERNEL_RBF && kind != DKT_KERNEL_SQDIST) return DKT_ERR_BAD_ARG;
     if (kind != DKT_KERNEL_LINEAR && !lengthscale) return DKT_ERR_BAD_ARG;
     const bool sym = (Bm == nullptr);
     if (sym && M != N) return DKT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, st))
+    if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, unit, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, B), block(256);
@@ -374,9 +377,9 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
 }
 
 extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
-                                const float* ep_scale, void* stream) {
-    if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
-    if (dkt_gram_bwd_ep_launch(W, Z, dZ, B, N, D, ep_scale, (hipStream_t)stream))
+                                const float* ep_scale, unsigned flags, void* stream) {
+    if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0 || (flags & ~DKT_GRAM_UNIT_ROWS)) return DKT_ERR_BAD_ARG;
+    if (dkt_gram_bwd_ep_launch(W, Z, dZ, B, N, D, ep_scale, (flags & DKT_GRAM_UNIT_ROWS) != 0, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((D + GT - 1) / GT, (N + GT - 1) / GT, B), block(256);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// gram_sym_ep_bf16x3_kernel<NT>: the same episode-resident symmetric Gram on the bf16 MFMA pipe.
+// gram_sym_ep_split_kernel<NT>: the same episode-resident symmetric Gram on the bf16 MFMA pipe.
 // Every fp32 feature is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 significand bits) while it is
 // staged into LDS (v_cvt_pk_bf16_f32 + subtract, three bf16 planes), and each fp32 product is rebuilt from the six
 // leading cross terms  hh + hm + mh + hl + lh + mm  with v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The dropped
@@ -129,8 +129,15 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 // leaves the fp32-MFMA roof (157 TF) and becomes HBM-bound.
 // NBUF = LDS stage buffers (2: one barrier per stage, 2 workgroups/CU; 1: two barriers, 4 workgroups/CU);
 // PF   = global-load run-ahead in stages (register sets): PF stages x 14 KB per workgroup stay in flight.
-template <int NT, int NBUF, int PF, int BK = 32>
-__global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2) void gram_sym_ep_bf16x3_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
+// SPL = 3: the bf16 split above (any operand range).  SPL = 2: 2-way f16 split of features scaled by 2^15 (dkt_split.h), for
+// rows the caller declares bounded by 1 in magnitude (DKT_KERNEL_LINEAR_UNIT: the cossim / bncossim features after
+// F.normalize); an element beyond 1.999 overflows f16 and poisons the episode with inf / NaN (loud, not silent).
+// The MFMA flushes f16 subnormals: the low piece of an element below 2^-18 (and all of one below 2^-29) is dropped, an
+// absolute error of at most 2^-30 |b| per product -- far below the fp32 resolution of a cosine similarity.
+#define DKT_F16_SCALE 32768.f
+#define DKT_F16_UNSCALE (1.f / (32768.f * 32768.f))
+template <int NT, int NBUF, int PF, int BK = 32, int SPL = 3, int MINWG = ((NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2)>
+__global__ __launch_bounds__(256, MINWG) void gram_sym_ep_split_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
     constexpr int NP = 16 * NT;
     constexpr int SPLD = BK + 16;
     constexpr int V4_PER_ROW = BK / 4;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 
     // far prefetch (PF = 2) really stay in flight across the MFMA phase.  Rows >= N load as zeros (out-of-range offset).
     constexpr int NPL = NLD * 256 / V4_PER_ROW;
     constexpr int PLANE = NPL * SPLD;
-    __shared__ __attribute__((aligned(16))) __bf16 zp[NBUF][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 zp[NBUF][SPL * PLANE];
 
     const int b = blockIdx.x;
     const float* Zb = Z + (size_t)b * N * D;
@@ -174,13 +181,19 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / V4_PER_ROW, c4 = idx % V4_PER_ROW;
-            {
+            if constexpr (SPL == 3) {
                 bf16x4 h, m, l;
                 split3(rg[i], h, m, l);
                 __bf16* dst = &zp[buf][row * SPLD + 4 * c4];
                 *reinterpret_cast<bf16x4*>(dst) = h;
                 *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
                 *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+            } else {
+                f16x4 h, m;
+                split2h(rg[i], DKT_F16_SCALE, h, m);
+                _Float16* dst = reinterpret_cast<_Float16*>(&zp[buf][row * SPLD + 4 * c4]);
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE) = m;
             }
         }
     };
@@ -188,19 +201,21 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 
     f32x4 acc[NT + 1];
 #pragma unroll
     for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto tiles = [&](auto rows, const __bf16* zs) {
+        using R = decltype(rows);
+        if constexpr (R::RA >= 0) {
+            if constexpr (SPL == 3) sym_tiles_mfma_bf16x3<NT, R::RA, R::RB, SPLD, PLANE>(acc, zs, r16, q);
+            else sym_tiles_mfma_f16x2<NT, R::RA, R::RB, SPLD, PLANE>(acc, reinterpret_cast<const _Float16*>(zs), r16, q);
+        }
+    };
     auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const __bf16* zs = zp[buf] + 32 * ks;
-            if (wave == 0) {
-                if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, SPLD, PLANE>(acc, zs, r16, q);
-            } else if (wave == 1) {
-                if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, SPLD, PLANE>(acc, zs, r16, q);
-            } else if (wave == 2) {
-                if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, SPLD, PLANE>(acc, zs, r16, q);
-            } else {
-                if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, SPLD, PLANE>(acc, zs, r16, q);
-            }
+            if (wave == 0) tiles(RowsOf<NT, 0>{}, zs);
+            else if (wave == 1) tiles(RowsOf<NT, 1>{}, zs);
+            else if (wave == 2) tiles(RowsOf<NT, 2>{}, zs);
+            else tiles(RowsOf<NT, 3>{}, zs);
         }
     };
 
@@ -269,19 +284,16 @@ __global__ __launch_bounds__(256, (NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 
 #if defined(DKT_EXP_CLOCKS)
     const long long cloop = clock64();
 #endif
-    if (wave == 0) {
-        if constexpr (RowsOf<NT, 0>::RA >= 0) sym_store_row<RowsOf<NT, 0>::RA>(acc, Eb, N, r16, q);
-        if constexpr (RowsOf<NT, 0>::RB >= 0) sym_store_row<RowsOf<NT, 0>::RB>(acc + RowsOf<NT, 0>::RA + 1, Eb, N, r16, q);
-    } else if (wave == 1) {
-        if constexpr (RowsOf<NT, 1>::RA >= 0) sym_store_row<RowsOf<NT, 1>::RA>(acc, Eb, N, r16, q);
-        if constexpr (RowsOf<NT, 1>::RB >= 0) sym_store_row<RowsOf<NT, 1>::RB>(acc + RowsOf<NT, 1>::RA + 1, Eb, N, r16, q);
-    } else if (wave == 2) {
-        if constexpr (RowsOf<NT, 2>::RA >= 0) sym_store_row<RowsOf<NT, 2>::RA>(acc, Eb, N, r16, q);
-        if constexpr (RowsOf<NT, 2>::RB >= 0) sym_store_row<RowsOf<NT, 2>::RB>(acc + RowsOf<NT, 2>::RA + 1, Eb, N, r16, q);
-    } else {
-        if constexpr (RowsOf<NT, 3>::RA >= 0) sym_store_row<RowsOf<NT, 3>::RA>(acc, Eb, N, r16, q);
-        if constexpr (RowsOf<NT, 3>::RB >= 0) sym_store_row<RowsOf<NT, 3>::RB>(acc + RowsOf<NT, 3>::RA + 1, Eb, N, r16, q);
-    }
+    constexpr float OUT_SCALE = (SPL == 3) ? 1.f : DKT_F16_UNSCALE;
+    auto store = [&](auto rows) {
+        using R = decltype(rows);
+        if constexpr (R::RA >= 0) sym_store_row<R::RA>(acc, Eb, N, r16, q, OUT_SCALE);
+        if constexpr (R::RB >= 0) sym_store_row<R::RB>(acc + R::RA + 1, Eb, N, r16, q, OUT_SCALE);
+    };
+    if (wave == 0) store(RowsOf<NT, 0>{});
+    else if (wave == 1) store(RowsOf<NT, 1>{});
+    else if (wave == 2) store(RowsOf<NT, 2>{});
+    else store(RowsOf<NT, 3>{});
 #if defined(DKT_EXP_CLOCKS)
     if (tid == 0) {
         // the clock dump overwrites the (unused in this build) first row of E[b]: E[b][0..7] as integer kilo-ticks
@@ -561,29 +573,210 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gram_bwd_ep_f16x2_kernel<NT>: dZ = s (W + W^T) Z with the 2-way scaled-f16 split (dkt_split.h) for unit-norm rows of Z
+// (DKT_GRAM_UNIT_ROWS).  Same data movement as the bf16 kernel above; differences:
+//   * Z is scaled by 2^15 and split into two f16 planes (two thirds of the LDS stores, half the MFMAs);
+//   * the A operand s (W + W^T) has no a-priori range, so every ROW is scaled by its own power of two (row maximum ->
+//     [2^14, 2^15)) before the split -- exact, and undone per output row in the epilogue together with the 2^-15 of Z;
+//   * the staging copy of W shares the LDS with both stage buffers (74 KB, 2 workgroups per CU).
+template <int NT, int NBUF, int PF>
+__global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+                                                                      float* __restrict__ dZ, int N, int D,
+                                                                      const float* __restrict__ ep_scale) {
+    constexpr int NP = 16 * NT;
+    constexpr int NTH = 64 * NT;
+    constexpr int BD = 64;
+    constexpr int KS = (NP + 31) / 32;
+    constexpr int KP = 32 * KS;
+    constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);
+    constexpr int RS = 8 * SU;
+    constexpr int PLANE = BD * RS;
+    static_assert(SU % 4 == 2 && RS >= KP, "LDS row stride");
+    constexpr int STAGE_BYTES = NBUF * 2 * PLANE * 2;
+    constexpr int LDS_BYTES = STAGE_BYTES > NP * NP * 4 ? STAGE_BYTES : NP * NP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __shared__ float rowinv[NP];
+    _Float16* zt = reinterpret_cast<_Float16*>(lds);     // [NBUF][2 * PLANE]
+
+    const int b = blockIdx.x;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* dZb = dZ + (size_t)b * N * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const float s = ep_scale ? ep_scale[b] : 1.0f;
+
+    const int d4 = tid & 15, jg = tid >> 4;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) voff[rr] = (4 * jg + rr < N) ? ((4 * jg + rr) * D + 4 * d4) * 4 : 0x7ffffff0;
+    auto gload = [&](float4 (&rg)[4], int d0) {
+        const bool in = d0 + 4 * d4 < D;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, in ? voff[rr] : 0x7ffffff0, d0 * 4, 0);
+            rg[rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    const int nslab = (D + BD - 1) / BD;
+    float4 r0[4], r1[4];
+    gload(r0, 0);
+    if constexpr (PF == 2) gload(r1, BD);
+
+    f16x8 ah[KS], am[KS];
+    {
+        float* wl = reinterpret_cast<float*>(lds);
+        const int nn = N * N;
+        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        __syncthreads();
+        const int row = wave * 16 + r16;
+        float v[KS][8];
+        float rmax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * ks + 8 * q + e;
+                v[ks][e] = (row < N && k < N) ? s * (wl[row * N + k] + wl[k * N + row]) : 0.f;
+                rmax = fmaxf(rmax, fabsf(v[ks][e]));
+            }
+        }
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 16, DKT_WAVE));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, DKT_WAVE));
+        // power-of-two row scale: row maximum -> [2^14, 2^15); clamped so that its inverse (times 2^-15) stays normal
+        const int eb = (int)((__float_as_uint(rmax) >> 23) & 0xffu);
+        const int sexp = min(268 - eb, 237);
+        const float rscale = __uint_as_float((unsigned)sexp << 23);
+        if (q == 0) rowinv[row] = __uint_as_float((unsigned)(254 - sexp - 15) << 23);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = v[ks][e] * rscale;
+                const _Float16 hi = (_Float16)xs;
+                ah[ks][e] = hi;
+                am[ks][e] = (_Float16)(xs - (float)hi);
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (KP > NP) {
+        constexpr int PADV = (KP - NP) / 8;
+        for (int i = tid; i < NBUF * 2 * BD * PADV; i += NTH) {
+            const int rowi = i / PADV, pc = i % PADV;
+            _Float16* dst = zt + (size_t)rowi * RS + NP + 8 * pc;
+            *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    auto lstore = [&](const float4 (&rg)[4], int buf) {
+        const float x[4][4] = {{rg[0].x, rg[1].x, rg[2].x, rg[3].x}, {rg[0].y, rg[1].y, rg[2].y, rg[3].y},
+                               {rg[0].z, rg[1].z, rg[2].z, rg[3].z}, {rg[0].w, rg[1].w, rg[2].w, rg[3].w}};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f16x4 h, m;
+            split2h(make_float4(x[t][0], x[t][1], x[t][2], x[t][3]), DKT_F16_SCALE, h, m);
+            _Float16* dst = zt + (size_t)buf * 2 * PLANE + (16 * t + d4) * RS + 4 * jg;
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + PLANE) = m;
+        }
+    };
+    auto compute_store = [&](int buf, int d0) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const _Float16* base = zt + (size_t)buf * 2 * PLANE + r16 * RS + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const _Float16* p = base + 16 * t * RS + 32 * ks;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p);
+                const f16x8 bm = *reinterpret_cast<const f16x8*>(p + PLANE);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[t], 0, 0, 0);
+            }
+        }
+        const int d = d0 + 4 * r16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = wave * 16 + 4 * q + reg;
+            const float u = rowinv[row];
+            if (row < N && d < D)
+                *reinterpret_cast<float4*>(dZb + (size_t)row * D + d) =
+                    make_float4(acc[0][reg] * u, acc[1][reg] * u, acc[2][reg] * u, acc[3][reg] * u);
+        }
+    };
+    auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
+        const int buf = (NBUF == 2) ? (sl & 1) : 0;
+        if constexpr (PF == 2) {
+            gload(rfar, (sl + 2) * BD);
+        } else {
+            if (sl + 1 < nslab) gload(rnear, (sl + 1) * BD);
+        }
+        compute_store(buf, sl * BD);
+        if constexpr (NBUF == 1) __syncthreads();
+        if constexpr (PF == 2) {
+            lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        } else {
+            if (sl + 1 < nslab) lstore(rnear, (NBUF == 2) ? (buf ^ 1) : 0);
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    lstore(r0, 0);
+    __syncthreads();
+    if constexpr (PF == 2) {
+        for (int sl = 0; sl < nslab; sl += 2) {
+            stage(r1, r0, sl);
+            stage(r0, r1, sl + 1);
+        }
+    } else {
+        for (int sl = 0; sl < nslab; ++sl) stage(r0, r1, sl);
+    }
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
 template <int NT>
-void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, hipStream_t st) {
+void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit, hipStream_t st) {
     if (bk == 3) {
-        const int v = env_int("DKT_GRAM_SPLIT_VAR", 11);      // <LDS buffers><prefetch depth>
-        if (v == 21) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 611) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 612) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 12) hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else hipLaunchKernelGGL((gram_sym_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        // <LDS buffers><prefetch depth> of the bf16 split; 2xxx = scaled-f16 split (unit-norm rows only):
+        // 2223 = 2 stage buffers, prefetch depth 2, 3 workgroups per CU
+        const int v = unit ? env_int("DKT_GRAM_UNIT_VAR", 2223) : env_int("DKT_GRAM_SPLIT_VAR", 11);
+        if (v == 21) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 611) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 612) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 12) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 211) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 212) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 2611) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 26113) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 26114) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 4>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 26122) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 2223) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 2213) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 2115) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2, 5>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
     } else if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
     else hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
 }
 
 template <int NT>
-void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, hipStream_t st) {
+void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, bool unit, hipStream_t st) {
     if (bd == 3) {
-        const int v = env_int("DKT_GRAM_BWD_SPLIT_VAR", 11);  // <LDS buffers><prefetch depth>
+        // <LDS buffers><prefetch depth> of the bf16 split; 2xx = scaled-f16 split (unit-norm rows of Z only)
+        const int v = unit ? env_int("DKT_GRAM_BWD_UNIT_VAR", 222) : env_int("DKT_GRAM_BWD_SPLIT_VAR", 11);
+        if (v == 222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 221) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 212) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 211) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if constexpr (NT <= 7) {                              // one stage buffer must also hold the N x N staging copy of W
             if (v == 11) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
             if (v == 12) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
@@ -597,30 +790,30 @@ void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, 
 }  // namespace
 
 // Returns true when the episode-resident kernel was launched.
-bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, hipStream_t st) {
+bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st) {
     if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
     if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
     // DKT_GRAM_SPLIT=1 (default): 3-way bf16 split on the bf16 MFMA pipe; 0: exact-fp32 MFMA (BK from DKT_GRAM_EP_BK)
     const int bk = env_int("DKT_GRAM_SPLIT", 1) ? 3 : env_int("DKT_GRAM_EP_BK", 64);
     switch ((N + 15) / 16) {
-        case 5: launch_sym<5>(Z, E, B, N, D, bk, st); return true;
-        case 6: launch_sym<6>(Z, E, B, N, D, bk, st); return true;
-        case 7: launch_sym<7>(Z, E, B, N, D, bk, st); return true;
-        case 8: launch_sym<8>(Z, E, B, N, D, bk, st); return true;
+        case 5: launch_sym<5>(Z, E, B, N, D, bk, unit, st); return true;
+        case 6: launch_sym<6>(Z, E, B, N, D, bk, unit, st); return true;
+        case 7: launch_sym<7>(Z, E, B, N, D, bk, unit, st); return true;
+        case 8: launch_sym<8>(Z, E, B, N, D, bk, unit, st); return true;
         default: return false;
     }
 }
 
-bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
+bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st) {
     if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
     if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
     // the split kernel pays a per-episode setup (A-fragment split, LDS zero fill): it wins from ~16 slabs of 64 features
     const int bd = (env_int("DKT_GRAM_SPLIT", 1) && D >= env_int("DKT_GRAM_BWD_SPLIT_MIND", 1024)) ? 3 : env_int("DKT_GRAM_EP_BD", 32);
     switch ((N + 15) / 16) {
-        case 5: launch_bwd<5>(W, Z, dZ, B, N, D, sc, bd, st); return true;
-        case 6: launch_bwd<6>(W, Z, dZ, B, N, D, sc, bd, st); return true;
-        case 7: launch_bwd<7>(W, Z, dZ, B, N, D, sc, bd, st); return true;
-        case 8: launch_bwd<8>(W, Z, dZ, B, N, D, sc, bd, st); return true;
+        case 5: launch_bwd<5>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
+        case 6: launch_bwd<6>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
+        case 7: launch_bwd<7>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
+        case 8: launch_bwd<8>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
         default: return false;
     }
 }

@@ -197,7 +197,8 @@ class DKT(MetaTemplate):
         sv, mean, noise = self._hypers()
         cw = torch.full((c,), -1.0 / (c * n), device=zb.device, dtype=torch.float32)
         if self.kernel_type in LINEAR_KINDS:
-            obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zb, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+            obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zb, y, sv, mean, noise, cw, self.jitter0, self.max_tries,
+                                                                     unit_rows=bool(self.normalize))
         else:
             e = ops.base_matrix(zb, self.kernel_type, self.model.lengthscale, self.model.offset)
             obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)

@@ -22,6 +22,8 @@ from . import _lib
 KERNEL_LINEAR = 0
 KERNEL_RBF = 1
 KERNEL_SQDIST = 2
+KERNEL_LINEAR_UNIT = 3      # linear + the promise |a| <= 1 element-wise (rows went through F.normalize)
+GRAM_UNIT_ROWS = 1          # the same promise for the rows of Z in gram_bwd
 MLL_WANT_GRAD = 1
 MLL_WANT_CHOL = 2
 MLL_FORCE_GENERIC = 4
@@ -110,7 +112,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
         n = bm.shape[1]
     else:
         n = m
-    if kind != KERNEL_LINEAR:
+    if kind not in (KERNEL_LINEAR, KERNEL_LINEAR_UNIT):
         lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
     e = torch.empty((b_, m, n), device=a.device, dtype=torch.float32)
     lib = _lib.load()
@@ -172,8 +174,9 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
 
 
-def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dZ[b] = ep_scale[b] * (W[b] + W[b]^T) Z[b]."""
+def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] = None, unit_rows: bool = False) -> torch.Tensor:
+    """dZ[b] = ep_scale[b] * (W[b] + W[b]^T) Z[b].  unit_rows: the caller guarantees |z| <= 1 element-wise (rows that went
+    through F.normalize), which lets the kernel use the scaled 2-way f16 split (DKT_GRAM_UNIT_ROWS)."""
     w = _req(w, "w", 3)
     z = _req(z, "z", 3)
     b_, n, d = z.shape
@@ -186,7 +189,7 @@ def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] 
     dz = torch.empty_like(z)
     lib = _lib.load()
     with _timed("dkt_gram_bwd_f32"):
-        st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale), _stream())
+        st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale), GRAM_UNIT_ROWS if unit_rows else 0, _stream())
     _lib.check(st, "dkt_gram_bwd_f32")
     return dz
 
@@ -439,12 +442,13 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
        backward: dZ = g_b (W + W^T) Z (dkt_gram_bwd_f32, upstream grad folded in as ep_scale)."""
 
     @staticmethod
-    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries):
-        e = gram(z, None, KERNEL_LINEAR)
+    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows=False):
+        e = gram(z, None, KERNEL_LINEAR_UNIT if unit_rows else KERNEL_LINEAR)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
         obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
         ctx.save_for_backward(z, out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
+        ctx.unit_rows = bool(unit_rows)
         ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e)
         return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e
 
@@ -452,12 +456,12 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
     def backward(ctx, gobj, *_unused):
         z, w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        dz = gram_bwd(w, z, gobj) if ctx.needs_input_grad[0] else None
+        dz = gram_bwd(w, z, gobj, unit_rows=ctx.unit_rows) if ctx.needs_input_grad[0] else None
         gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
         gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
         gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
         gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
-        return dz, None, gsv, gmean, gnoise, None, None, None
+        return dz, None, gsv, gmean, gnoise, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -588,6 +592,8 @@ def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float =
     return out if full else out[:8]
 
 
-def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):
-    """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E)."""
-    return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries)
+def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3, unit_rows: bool = False):
+    """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E).
+    unit_rows=True: z went through F.normalize (cossim / bncossim), |z| <= 1 element-wise -- the Gram kernels may then use
+    the scaled 2-way f16 split (same fp32-level accuracy, less staging work)."""
+    return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows)

@@ -41,6 +41,13 @@ extern "C" {
 #define DKT_KERNEL_LINEAR 0 /* linear / cossim / bncossim : E = A B^T                       */
 #define DKT_KERNEL_RBF 1    /* rbf : E = exp(-0.5 |a-b|^2 / l^2), centred norm expansion    */
 #define DKT_KERNEL_SQDIST 2 /* U = |a-b|^2 / l^2 (clamped >= 0): building block of matern   */
+#define DKT_KERNEL_LINEAR_UNIT 3 /* LINEAR + the caller's promise |a_ik| <= 1 for every element (cossim / bncossim:
+                                    the features went through F.normalize, methods/DKT.py:141-142).  Same result to fp32
+                                    accuracy; lets the episode-resident kernel use the scaled 2-way f16 split.  An element
+                                    beyond 1.999 overflows to inf / NaN in that episode's output (loud, not silent). */
+
+/* gram_bwd flags */
+#define DKT_GRAM_UNIT_ROWS 1u /* the same promise for the rows of Z in dkt_gram_bwd_f32 (W is unrestricted) */
 
 /* mll flags */
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
@@ -57,7 +64,8 @@ int dkt_device_cu_count(void);
  * dkt_gram_f32 -- base kernel matrix of one or many episodes.
  *   E[b] = k(A[b], Bm[b])  with A:[B,M,D], Bm:[B,N,D] -> E:[B,M,N].
  *   Bm == NULL: symmetric Gram of A with itself (M == N, only lower tiles computed, mirrored).
- *   kind = DKT_KERNEL_LINEAR | DKT_KERNEL_RBF | DKT_KERNEL_SQDIST; `lengthscale` (device, 1 float) unused by LINEAR.
+ *   kind = DKT_KERNEL_LINEAR | DKT_KERNEL_LINEAR_UNIT | DKT_KERNEL_RBF | DKT_KERNEL_SQDIST; `lengthscale` (device, 1 float)
+ *   unused by the linear kinds.
  * Replaces: ExactGPLayer.forward -> covar_module(x) (methods/DKT.py:375-378,
  *   methods/DKT_regression.py:126-129), i.e. GPyTorch LinearKernel / RBFKernel evaluation,
  *   evaluated once per episode instead of once per class model (DKT.py:148-149,161).
@@ -100,11 +108,11 @@ int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv,
 /*
  * dkt_gram_bwd_f32 -- backward of the linear Gram: dZ[b] = scale_b * (W[b] + W[b]^T) Z[b].
  *   W:[B,N,N]  Z:[B,N,D]  dZ:[B,N,D];  ep_scale: [B] device per-episode factor (upstream
- *   gradient of the episode objective) or NULL (= 1).
+ *   gradient of the episode objective) or NULL (= 1).  flags: 0 or DKT_GRAM_UNIT_ROWS.
  * Replaces: autograd through matmul(Z, Z^T) in loss.backward() (methods/DKT.py:163).
  */
 int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
-                     const float* ep_scale, void* stream);
+                     const float* ep_scale, unsigned flags, void* stream);
 
 /*
  * dkt_rbf_bwd_f32 -- chain rule of the RBF base kernel.  With Ws = 0.5 (W + W^T) and

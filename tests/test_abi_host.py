@@ -35,7 +35,7 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
 def test_argument_errors_do_not_launch(lib):
     # NULL pointers / bad sizes are rejected on the host before any launch
     assert lib.dkt_gram_f32(None, None, None, 1, 4, 4, 4, 0, None, None) == -1
-    assert lib.dkt_gram_bwd_f32(None, None, None, 1, 4, 4, None, None) == -1
+    assert lib.dkt_gram_bwd_f32(None, None, None, 1, 4, 4, None, 0, None) == -1
     assert lib.dkt_predict_f32(None, None, None, None, None, None, 1, 1, 1, 1, None) == -1
 
 

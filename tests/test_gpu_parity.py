@@ -126,6 +126,94 @@ def test_gram_bwd_split_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
     assert torch.equal(ops.gram_bwd(w, z, None), ref)
 
 
+# ---- unit-norm rows (DKT_KERNEL_LINEAR_UNIT / DKT_GRAM_UNIT_ROWS): the scaled 2-way f16 split ----
+def _unit_rows(b, n, d, seed, cuda, kind):
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    z = torch.randn(b, n, d, generator=g, device=cuda)
+    if kind == "heavy":          # a few dominant features per row, many tiny ones (exercises the f16 subnormal range of m)
+        z = z * torch.exp(3.0 * torch.randn(b, n, d, generator=g, device=cuda))
+    z = torch.nn.functional.normalize(z, dim=2)
+    if kind == "onehot":         # rows with a single +-1 entry, exact zeros elsewhere, mixed with ordinary rows
+        z[:, ::3] = 0.0
+        idx = torch.randint(0, d, (b, (n + 2) // 3), generator=g, device=cuda)
+        z[:, ::3].scatter_(2, idx.unsqueeze(2), -1.0)
+    return z.contiguous()
+
+
+@pytest.mark.parametrize("b,n,d", EP_SHAPES)
+@pytest.mark.parametrize("kind", ["plain", "heavy", "onehot"])
+def test_gram_unit_rows_f16_split(cuda, b, n, d, kind):
+    z = _unit_rows(b, n, d, n * 13 + d, cuda, kind)
+    e = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+    ref = torch.einsum("bnd,bmd->bnm", z.double(), z.double())
+    mag = torch.einsum("bnd,bmd->bnm", z.double().abs(), z.double().abs())
+    tol = max(1e-6, 6.0 * np.sqrt(d) * 2.0 ** -24)
+    # relative to sum_k |a_k||b_k| like the fp32 kernels, plus the absolute floor of the f16 range: the low piece of an element
+    # below 2^-18 is flushed, at most 2^-30 |b_k| per product
+    excess = ((e.double() - ref).abs() - tol * mag).max().item()
+    assert excess < 2.0 ** -30 * np.sqrt(d), (excess, tol)
+    assert (e.double() - ref).abs().max().item() < 1.5e-6                  # |E - E64| on cosine similarities
+    assert torch.equal(e, e.transpose(1, 2)) and torch.equal(e, ops.gram(z, None, ops.KERNEL_LINEAR_UNIT))
+    # same answer (to fp32 accuracy) as the range-agnostic bf16 split and as the generic tile kernel below the B threshold
+    assert (e - ops.gram(z)).abs().max().item() < 1.5e-6
+    # (below the B threshold the promise is simply unused: sequential fp32 MFMA chain, a few 1e-7 further from float64)
+    assert (ops.gram(z[:2].contiguous(), None, ops.KERNEL_LINEAR_UNIT) - e[:2]).abs().max().item() < 4e-6
+
+
+@pytest.mark.parametrize("var", ["211", "212", "2611", "26113", "26122", "2223", "2213"])
+def test_gram_unit_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
+    z = _unit_rows(64, 105, 1632, 3, cuda, "plain")
+    monkeypatch.setenv("DKT_GRAM_UNIT_VAR", "2223")
+    ref = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+    monkeypatch.setenv("DKT_GRAM_UNIT_VAR", var)
+    assert torch.equal(ops.gram(z, None, ops.KERNEL_LINEAR_UNIT), ref)
+
+
+def test_gram_unit_rows_promise_violation_is_loud(cuda):
+    z = _unit_rows(64, 105, 256, 9, cuda, "plain")
+    z[5, 17, 33] = 2.5                                   # |z| > 1.999: overflows the scaled f16 piece
+    e = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+    assert not torch.isfinite(e[5, 17]).all(), "a violated unit-row promise must poison the episode, not pass silently"
+    assert torch.isfinite(e[4]).all() and torch.isfinite(e[6]).all()
+
+
+@pytest.mark.parametrize("b,n,d", EP_SHAPES)
+@pytest.mark.parametrize("kind", ["plain", "heavy"])
+def test_gram_bwd_unit_rows_f16_split(cuda, b, n, d, kind, monkeypatch):
+    monkeypatch.setenv("DKT_GRAM_BWD_SPLIT_MIND", "32")              # force the split kernel also at small D
+    z = _unit_rows(b, n, d, n * 17 + d, cuda, kind)
+    g = torch.Generator(device=cuda).manual_seed(n + d)
+    # gradient-like W: per-row AND per-entry dynamic range, one all-zero row, one tiny row
+    w = torch.randn(b, n, n, generator=g, device=cuda) * torch.exp(2.0 * torch.randn(b, n, 1, generator=g, device=cuda)) \
+        * torch.exp(1.5 * torch.randn(b, n, n, generator=g, device=cuda))
+    sc = torch.rand(b, generator=g, device=cuda) + 0.5
+    dz = ops.gram_bwd(w, z, sc, unit_rows=True)
+    ws = (w + w.transpose(1, 2)).double() * sc.double().view(-1, 1, 1)
+    ref = ws @ z.double()
+    mag = ws.abs() @ z.double().abs()
+    # 2e-6 relative to sum_j |W'_ij||z_jd| like the fp32 kernels + the f16 range floor (entries below 2^-17 of their row's
+    # maximum / features below 2^-18 lose their low piece: <= 2^-29 rowmax per term)
+    rowmax = ws.abs().amax(2, keepdim=True)
+    excess = ((dz.double() - ref).abs() - 2e-6 * mag - 2.0 ** -29 * np.sqrt(n) * rowmax).max().item()
+    assert excess < 0, excess
+    assert torch.equal(dz, ops.gram_bwd(w, z, sc, unit_rows=True)), "deterministic"
+    w0 = torch.zeros_like(w)
+    w0[:, 3, 7] = 1e-30
+    dz0 = ops.gram_bwd(w0, z, None, unit_rows=True)      # all-zero rows and a denormal-scale row: finite, exact zeros elsewhere
+    assert torch.isfinite(dz0).all() and (dz0[:, 0] == 0).all()
+    assert (dz0[:, 3].double() - 1e-30 * z[:, 7].double()).abs().max().item() < 1e-36
+
+
+@pytest.mark.parametrize("var", ["222", "221", "212", "211"])
+def test_gram_bwd_unit_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
+    z = _unit_rows(64, 105, 1088, 5, cuda, "plain")
+    w = torch.randn(64, 105, 105, device=cuda, generator=torch.Generator(device=cuda).manual_seed(6))
+    monkeypatch.setenv("DKT_GRAM_BWD_UNIT_VAR", "222")
+    ref = ops.gram_bwd(w, z, None, unit_rows=True)
+    monkeypatch.setenv("DKT_GRAM_BWD_UNIT_VAR", var)
+    assert torch.equal(ops.gram_bwd(w, z, None, unit_rows=True), ref)
+
+
 @pytest.mark.parametrize("n,d,ls,shift", [(19, 2916, 30.0, 0.4), (5, 2916, 20.0, 0.4), (105, 64, 1.3, 0.0), (70, 33, 0.9, 5.0)])
 def test_gram_rbf(cuda, n, d, ls, shift):
     rng = np.random.default_rng(n + d)
@@ -545,6 +633,10 @@ def test_gram_kernels_full_occupancy_are_race_free(cuda):
     assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2])
     dz = [ops.gram_bwd(w, z, sc) for _ in range(3)]
     assert torch.equal(dz[0], dz[1]) and torch.equal(dz[0], dz[2])
+    eu = [ops.gram(z, None, ops.KERNEL_LINEAR_UNIT) for _ in range(3)]           # the scaled-f16 kernels (unit-norm rows)
+    assert torch.equal(eu[0], eu[1]) and torch.equal(eu[0], eu[2])
+    du = [ops.gram_bwd(w, z, sc, unit_rows=True) for _ in range(3)]
+    assert torch.equal(du[0], du[1]) and torch.equal(du[0], du[2])
     st = ops.bn_stats(x, gamma, beta)
     eb = [ops.gram_bn(x, st["a"], st["s"]) for _ in range(3)]
     assert torch.equal(eb[0][0], eb[1][0]) and torch.equal(eb[0][0], eb[2][0]) and torch.equal(eb[0][1], eb[2][1])
@@ -556,6 +648,8 @@ def test_gram_kernels_full_occupancy_are_race_free(cuda):
         assert (e[0][i].double() - zi @ zi.T).abs().max().item() < 2e-6
         a = (w[i] + w[i].T).double() * sc[i].double()
         assert float((dz[0][i].double() - a @ zi).norm() / (a @ zi).norm()) < 1e-5
+        assert (eu[0][i].double() - zi @ zi.T).abs().max().item() < 2e-6
+        assert float((du[0][i].double() - a @ zi).norm() / (a @ zi).norm()) < 1e-5
         # fused front end against float64 autograd of bn_out(train) -> normalize -> <W, E>
         xi = x[i].double().detach().requires_grad_(True)
         g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)

@@ -11,7 +11,7 @@ import sys
 src = sys.argv[1]
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 out = sys.argv[3] if len(sys.argv) > 3 else "pmc_traffic.json"
-names = {"gram_sym_ep_bf16x3_kernel": "dkt_gram_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
+names = {"gram_sym_ep_split_kernel": "dkt_gram_f32", "gram_sym_ep_bf16x3_kernel": "dkt_gram_f32", "gram_bwd_ep_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
          "gram_bwd_kernel": "dkt_gram_bwd_f32", "mll_reg_kernel": "dkt_mll_f32", "mll_generic_kernel": "dkt_mll_f32",
          "mll_wave_kernel": "dkt_mll_f32", "mll_blk_kernel": "dkt_mll_f32"}
 vals = {}
