@@ -94,3 +94,32 @@ def test_ece_loss_on_known_distribution():
     t = ece.calibrate(z, y)
     nll = torch.nn.CrossEntropyLoss()
     assert nll(z * t, y) < nll(z, y) and 0.0 < t.item() < 1.0
+
+
+def test_cli_flags_and_checkpoint_helpers_match_reference_fixture(tmp_path):
+    """tests/golden/cli_reference.json was produced by the REFERENCE's io_utils.py / configs.py (make_cli_golden.py): every
+    flag of the four drivers exists here with the same default, except the two documented deviations (no datasets and only
+    the DKT method exist in this build), and the checkpoint-file helpers pick the same files."""
+    import json
+    from dkt_amd import configs
+    from dkt_amd.io_utils import model_dict
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_reference.json")))
+    deviations = {"dataset": "synthetic", "method": "DKT"}
+    for script, fn in (("train", parse_args), ("test", parse_args), ("train_regression", parse_args_regression),
+                       ("test_regression", parse_args_regression)):
+        mine = vars(fn(script, []))
+        for flag, default in ref["flags"][script].items():
+            assert flag in mine, (script, flag)
+            assert mine[flag] == deviations.get(flag, default), (script, flag, mine[flag], default)
+    assert configs.kernel_type == ref["configs"]["kernel_type"] and configs.save_dir == ref["configs"]["save_dir"]
+    assert set(ref["model_dict_keys"]) - set(model_dict) <= {"ResNet50", "ResNet101"}      # bottleneck ResNets: not used by DKT configs
+    d = str(tmp_path)
+    h = ref["checkpoint_helpers"]
+    assert get_resume_file(d) is h["empty_resume"] and get_best_file(d) is h["empty_best"]
+    for e in (0, 50, 7):
+        open(os.path.join(d, "%d.tar" % e), "w").close()
+    assert os.path.basename(get_resume_file(d)) == h["resume"] and os.path.basename(get_best_file(d)) == h["best_without_best_model"]
+    open(os.path.join(d, "best_model.tar"), "w").close()
+    assert os.path.basename(get_best_file(d)) == h["best_with_best_model"]
+    assert os.path.basename(get_resume_file(d)) == h["resume_with_best_model"]
+    assert os.path.basename(get_assigned_file(d, 12)) == h["assigned_12"]
