@@ -35,6 +35,9 @@ CONFIGS = {   # name -> (n_way, n_support, n_query, D, description)
     "cfg1": (5, 5, 16, 64, "Omniglot 5-way 5-shot, Conv4S features"),
     "cfg2": (5, 5, 16, 1600, "CUB 5-way 5-shot, Conv4 features (headline)"),
     "cfg3": (5, 1, 16, 512, "miniImagenet 5-way 1-shot, ResNet10 features"),
+    # 20-way: N = 420 is what train_loop builds (20 x (5 + 16)); BASELINE.json quotes a 320 x 320 Gram
+    "cfg4": (20, 5, 16, 512, "miniImagenet 20-way 5-shot, ResNet18 features (N = 420: blocked large-N MLL path)"),
+    "cfg4_n320": (20, 1, 15, 512, "20-way, N = 320 (the Gram size BASELINE.json quotes)"),
 }
 
 
@@ -79,7 +82,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=8192, help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192})")
+    ap.add_argument("--episodes", type=int, default=None,
+                    help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192}); default 8192, 1024 for the 20-way shapes")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-test-time", action="store_true",
@@ -104,7 +108,7 @@ def main():
 
     c, s, q, d, desc = CONFIGS[args.config]
     n = c * (s + q)
-    b = args.episodes
+    b = args.episodes or (8192 if n <= 128 else 1024)
     z = synthetic_batch(b, n, d, 1234 + rank, dev).requires_grad_(True)
     raw_s, mean = perturbed_hypers(c, 99, dev)
     raw_s.requires_grad_(True)

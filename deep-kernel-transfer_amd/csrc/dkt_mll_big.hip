@@ -25,14 +25,15 @@ struct GemmOp {
 
 constexpr int GLD = 24;         // LDS row stride (floats) of a [64][16] tile: 6 sixteen-byte units -> conflict-free b128 fragment reads
 
-// One 64 x 16 operand tile into LDS as T[row][k].  `TR` = the operand's memory has the tile ROW index as the fast index
-// (op = transpose): the thread then loads 4 consecutive rows of one k and scatters them; otherwise 4 consecutive k of one row.
-// vec: 16-byte loads are legal (leading dimension, base and offsets multiples of 4 floats).
+// One 64 x 16 operand tile: global -> register (tile_load) and register -> LDS as T[row][k] (tile_store), so that the loads of
+// the NEXT K slice are in flight while the current one is multiplied.  `TR` = the operand's memory has the tile ROW index as the
+// fast index (op = transpose): the thread then loads 4 consecutive rows of one k and scatters them; otherwise 4 consecutive k
+// of one row.  vec: 16-byte loads are legal (leading dimension, base and offsets multiples of 4 floats).
 template <bool TR>
-__device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P, int ld, int r0, int nrows, int k0, int K, int tid, bool vec) {
+__device__ __forceinline__ float4 tile_load(const float* __restrict__ P, int ld, int r0, int nrows, int k0, int K, int tid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!TR) {
         const int r = tid >> 2, k = 4 * (tid & 3);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r0 + r < nrows) {
             const float* p = P + (size_t)(r0 + r) * ld + k0 + k;
             if (vec && k0 + k + 3 < K) v = *reinterpret_cast<const float4*>(p);
@@ -43,10 +44,8 @@ __device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P
                 if (k0 + k + 3 < K) v.w = p[3];
             }
         }
-        *reinterpret_cast<float4*>(T + r * GLD + k) = v;
     } else {
         const int k = tid >> 4, r = 4 * (tid & 15);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k0 + k < K) {
             const float* p = P + (size_t)(k0 + k) * ld + r0 + r;
             if (vec && r0 + r + 3 < nrows) v = *reinterpret_cast<const float4*>(p);
@@ -57,6 +56,17 @@ __device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P
                 if (r0 + r + 3 < nrows) v.w = p[3];
             }
         }
+    }
+    return v;
+}
+
+template <bool TR>
+__device__ __forceinline__ void tile_store(float* T, const float4& v, int tid) {
+    if (!TR) {
+        const int r = tid >> 2, k = 4 * (tid & 3);
+        *reinterpret_cast<float4*>(T + r * GLD + k) = v;
+    } else {
+        const int k = tid >> 4, r = 4 * (tid & 15);
         T[(r + 0) * GLD + k] = v.x;
         T[(r + 1) * GLD + k] = v.y;
         T[(r + 2) * GLD + k] = v.z;
@@ -66,7 +76,7 @@ __device__ __forceinline__ void stage_tile(float* T, const float* __restrict__ P
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
-    __shared__ __attribute__((aligned(16))) float As[64 * GLD], Bs[64 * GLD];
+    __shared__ __attribute__((aligned(16))) float As[2][64 * GLD], Bs[2][64 * GLD];
     const int bz = blockIdx.z;
     const float* A = g.A + (size_t)bz * g.sA;
     const float* B = g.B + (size_t)bz * g.sB;
@@ -76,18 +86,30 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmOp g) {
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        // op(A)[m][k] is A[m][k] (rows = m, fast index k) or A[k][m] (TA: fast index m);  op(B)^T[n][k] is B[n][k] (TB) or B[k][n]
-        stage_tile<TA>(As, A, g.lda, m0, g.M, k0, g.K, tid, g.vecA);
-        stage_tile<!TB>(Bs, B, g.ldb, n0, g.N, k0, g.K, tid, g.vecB);
-        __syncthreads();
+    // op(A)[m][k] is A[m][k] (rows = m, fast index k) or A[k][m] (TA: fast index m);  op(B)^T[n][k] is B[n][k] (TB) or B[k][n]
+    float4 ra = tile_load<TA>(A, g.lda, m0, g.M, 0, g.K, tid, g.vecA);
+    float4 rb = tile_load<!TB>(B, g.ldb, n0, g.N, 0, g.K, tid, g.vecB);
+    tile_store<TA>(As[0], ra, tid);
+    tile_store<!TB>(Bs[0], rb, tid);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += 16, buf ^= 1) {
+        const bool more = k0 + 16 < g.K;
+        if (more) {                                     // next slice: loads fly during this slice's MFMAs
+            ra = tile_load<TA>(A, g.lda, m0, g.M, k0 + 16, g.K, tid, g.vecA);
+            rb = tile_load<!TB>(B, g.ldb, n0, g.N, k0 + 16, g.K, tid, g.vecB);
+        }
         // lane group q holds k = 4q .. 4q+3 of the 16-wide slice (one b128 read); the t-th MFMA contracts k = {t, 4+t, 8+t, 12+t}
-        const f32x4 a = *reinterpret_cast<const f32x4*>(As + (16 * wave + r16) * GLD + 4 * q);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(As[buf] + (16 * wave + r16) * GLD + 4 * q);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const f32x4 bfr = *reinterpret_cast<const f32x4*>(Bs + (16 * ct + r16) * GLD + 4 * q);
+            const f32x4 bfr = *reinterpret_cast<const f32x4*>(Bs[buf] + (16 * ct + r16) * GLD + 4 * q);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bfr[t], acc[ct], 0, 0, 0);
+        }
+        if (more) {                                     // the other buffer was last read before the previous barrier
+            tile_store<TA>(As[buf ^ 1], ra, tid);
+            tile_store<!TB>(Bs[buf ^ 1], rb, tid);
         }
         __syncthreads();
     }
