@@ -46,3 +46,58 @@ extern "C" int dkt_diag_stream_f32(const float* Z, float* out, int B, int N, int
     else hipLaunchKernelGGL(stream_linear_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- co-residency probes (tools/coresident_probe.py): one instruction class per mode, spun for `iters` rounds ----
+// Used to find out which activity of a neighbouring kernel perturbs the rank-2 MLL sweep.
+typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dg_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void spin_kernel(float* out, int iters, int mode) {
+    __shared__ __attribute__((aligned(16))) float lds[12288];        // 48 KB, like a Gram stage buffer
+    const int tid = threadIdx.x;
+    float x = 1.0f + tid * 1e-3f, y = 0.5f + tid * 1e-4f, accs = 0.f;
+    dg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 12288; i += 256) lds[i] = x;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if (mode == 0) {                 // fp32 -> bf16 conversions (v_cvt_pk_bf16_f32) + shifts / subtracts
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const __bf16 h = (__bf16)x;
+                x = (x - (float)h) * 1.0009765625f + y;
+                accs += (float)h;
+            }
+        } else if (mode == 1) {          // bf16 MFMA only
+            dg_bf16x8 a, b;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(x + e); b[e] = (__bf16)(y - e); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        } else if (mode == 2) {          // LDS traffic: b64 writes + b128 reads
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int o = ((tid * 4 + 1024 * k + 16 * it) % 12284) & ~3;
+                *reinterpret_cast<float2*>(lds + o) = make_float2(x, y);
+                const float4 v = *reinterpret_cast<const float4*>(lds + ((o + 2048) % 12284 & ~3));
+                x = v.x * 0.5f + 0.25f;
+                y = v.w * 0.5f + 0.125f;
+            }
+            __syncthreads();
+        } else if (mode == 3) {          // fp32 -> f16 conversions (v_cvt_pk_f16_f32, v_cvt_f32_f16) + packed fp32 ops
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const _Float16 h = (_Float16)(x * 4096.f);
+                x = (x * 4096.f - (float)h) + y;
+                accs += (float)h;
+            }
+        } else {                         // plain fp32 VALU
+#pragma unroll
+            for (int k = 0; k < 32; ++k) x = __builtin_fmaf(x, 0.999f, y);
+        }
+    }
+    out[blockIdx.x * 256 + tid] = x + y + accs + acc[0] + acc[1] + acc[2] + acc[3] + lds[tid];
+}
+
+extern "C" int dkt_diag_spin(float* out, int nblocks, int iters, int mode, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, iters, mode);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

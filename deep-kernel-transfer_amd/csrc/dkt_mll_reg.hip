@@ -93,7 +93,7 @@ __device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     float cj[NT];
     // row factor -(column / d); the column factor stays raw (product = L_pk L_jk)
 #pragma unroll
-    for (int m = 0; m < NP2; ++m) cp2[m] = cur.cp2[m] * nrd;
+    for (int m = 0; m < NP2; ++m) { cp2[m][0] = cur.cp2[m][0] * nrd; cp2[m][1] = cur.cp2[m][1] * nrd; }    // scalar on purpose, see sweep_pair
 #pragma unroll
     for (int ji = KQ; ji < NT; ++ji) cj[ji] = cur.cj[ji];
     const float cpK = (ty == kr) ? nrd : cp2[KQ >> 1][KQ & 1];        // row k itself seeds U_kj = -L_jk / d
@@ -175,12 +175,17 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     const float g0 = e * nrd0;                                         // -e / d0
     const float d1 = __builtin_fmaf(g0, e, d1raw);
     const float nrd1 = -__builtin_amdgcn_rcpf(d1);
-    const f32x2 ev = {e, e};
+    // The row factors are formed with SCALAR v_mul / v_fma, not with the packed forms: with a split Gram kernel co-resident on
+    // the CU (separate stream), the packed versions of exactly these operations were observed to round single 16-lane passes
+    // differently from run to run (tools/corun_check.py); the scalar forms are bitwise stable and cost 0.3 %.
 #pragma unroll
-    for (int m = 0; m < NP2; ++m) F0[m] *= nrd0;
+    for (int m = 0; m < NP2; ++m) { F0[m][0] *= nrd0; F0[m][1] *= nrd0; }
     F0[KQ >> 1][KQ & 1] = (ty == kr) ? nrd0 : F0[KQ >> 1][KQ & 1];     // row k seeds U_kj
 #pragma unroll
-    for (int m = 0; m < NP2; ++m) F1[m] = __builtin_elementwise_fma(F0[m], ev, F1[m]) * nrd1;      // x1' (-1/d1)
+    for (int m = 0; m < NP2; ++m) {                                    // x1' (-1/d1)
+        F1[m][0] = __builtin_fmaf(F0[m][0], e, F1[m][0]) * nrd1;
+        F1[m][1] = __builtin_fmaf(F0[m][1], e, F1[m][1]) * nrd1;
+    }
     F1[KQ >> 1][KQ & 1] = (ty == kr + 1) ? nrd1 : F1[KQ >> 1][KQ & 1]; // row k+1 seeds U_{k+1,j}
 #pragma unroll
     for (int ji = KQ; ji < NT; ++ji) y1[ji] = __builtin_fmaf(y0[ji], g0, y1[ji]);                  // y1'

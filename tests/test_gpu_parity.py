@@ -617,6 +617,32 @@ def test_full_size_properties_cfg2(cuda):
     assert float((z3.grad - 2.5 * z.grad).norm() / (2.5 * z.grad).norm()) < 1e-4
 
 
+def test_mll_bitwise_stable_next_to_split_gram_kernels(cuda):
+    """dkt_mll_f32 on one stream while split Gram kernels run on another (co-resident workgroups on the same CUs): the result
+    must be bitwise the single-stream result.  Regression test for the packed row-factor forms."""
+    b, n, d, c = 8192, 105, 1600, 5
+    g = torch.Generator(device=cuda).manual_seed(21)
+    z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda), dim=2).contiguous()
+    y = dev_t(O.one_vs_rest_targets(c, n // c), cuda)
+    sv = torch.full((c,), 0.69, device=cuda) + 0.01 * torch.arange(c, device=cuda)
+    mean, noise = torch.zeros(c, device=cuda), torch.full((c,), 0.1, device=cuda)
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    e = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+    torch.cuda.synchronize()
+    ref = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(4):
+        with torch.cuda.stream(s2):
+            for _ in range(3):
+                ops.gram(z, None, ops.KERNEL_LINEAR if rep % 2 else ops.KERNEL_LINEAR_UNIT)
+        with torch.cuda.stream(s1):
+            a = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw)
+        torch.cuda.synchronize()
+        for k in ("logp", "alpha", "w", "dsv", "dmean"):
+            assert torch.equal(a[k], ref[k]), (rep, k, int((a[k] != ref[k]).sum()))
+
+
 def test_gram_kernels_full_occupancy_are_race_free(cuda):
     """2048 episodes of the headline shape: every LDS stage buffer hand-off of the streaming kernels under full occupancy.
     Bitwise repeatable, and sampled episodes equal to float64."""
