@@ -37,12 +37,38 @@ __global__ __launch_bounds__(256) void stream_linear_kernel(const float* __restr
     if (acc == 123.456f) out[b] = acc;
 }
 
+// Read + write ceiling of the Gram-backward pattern: per 64-feature slab every row's 256-byte segment is read and a 256-byte
+// segment of the output row written (no arithmetic, no LDS); `out` must hold B*N*D floats for modes 3 / 4.
+__global__ __launch_bounds__(448) void copy_slab_kernel(const float* __restrict__ Z, float* __restrict__ out, int N, int D) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* Ob = out + (size_t)b * N * D;
+    const int nslab = D / 64;
+    for (int sl = 0; sl < nslab; ++sl) {
+        for (int idx = tid; idx < N * 16; idx += 448) {
+            const int row = idx >> 4, c4 = idx & 15;
+            const size_t o = (size_t)row * D + sl * 64 + 4 * c4;
+            *reinterpret_cast<float4*>(Ob + o) = *reinterpret_cast<const float4*>(Zb + o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_linear_kernel(const float* __restrict__ Z, float* __restrict__ out, int N, int D) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float4* Zb = reinterpret_cast<const float4*>(Z + (size_t)b * N * D);
+    float4* Ob = reinterpret_cast<float4*>(out + (size_t)b * N * D);
+    const int n4 = N * D / 4;
+    for (int i = tid; i < n4; i += 256) Ob[i] = Zb[i];
+}
+
 }  // namespace
 
 extern "C" int dkt_diag_stream_f32(const float* Z, float* out, int B, int N, int D, int mode, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL((stream_slab_kernel<128>), dim3(B), dim3(256), 0, st, Z, out, N, D);
     else if (mode == 2) hipLaunchKernelGGL((stream_slab_kernel<256>), dim3(B), dim3(256), 0, st, Z, out, N, D);
+    else if (mode == 3) hipLaunchKernelGGL(copy_slab_kernel, dim3(B), dim3(448), 0, st, Z, out, N, D);
+    else if (mode == 4) hipLaunchKernelGGL(copy_linear_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
     else hipLaunchKernelGGL(stream_linear_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

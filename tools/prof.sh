@@ -6,7 +6,8 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-test-time ${BENCH_ARGS:-}"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
+# kernel trace of bench.py's DEFAULT step counts (the per-kernel averages are compared with the bench line's live HIP-event times)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --no-cpu-baseline --no-test-time ${BENCH_ARGS:-} > $OUT/stats.log 2>&1
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py $ARGS > $OUT/pmc_$tag.log 2>&1
