@@ -180,7 +180,7 @@ def test_gram_unit_rows_promise_violation_is_loud(cuda):
 @pytest.mark.parametrize("b,n,d", EP_SHAPES)
 @pytest.mark.parametrize("kind", ["plain", "heavy"])
 def test_gram_bwd_unit_rows_f16_split(cuda, b, n, d, kind, monkeypatch):
-    monkeypatch.setenv("DKT_GRAM_BWD_SPLIT_MIND", "32")              # force the split kernel also at small D
+    monkeypatch.setenv("DKT_GRAM_BWD_UNIT_MIND", "32")               # force the split kernel also at D < 64
     z = _unit_rows(b, n, d, n * 17 + d, cuda, kind)
     g = torch.Generator(device=cuda).manual_seed(n + d)
     # gradient-like W: per-row AND per-entry dynamic range, one all-zero row, one tiny row
