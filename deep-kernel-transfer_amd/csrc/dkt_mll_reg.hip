@@ -143,9 +143,9 @@ __device__ __forceinline__ void sweep_step(f32x2 (&A2)[(NT + 1) / 2][NT], const 
 // applies pivot k to its entries of column k+1 itself (x1' = x1 + F0 e with e = A[k+1][k]; the second pivot
 // d1 = A[k+1][k+1] - e^2 / d0 is a uniform scalar), then does ONE rank-2 update.  The serial chain
 // barrier -> LDS round trip -> rcp -> update of block column KQ -> publish is paid once per two pivots.
-//   row factors   F0[p] = x0[p] (-1/d0)  (seed -1/d0 at p = k),     F1[p] = x1'[p] (-1/d1)  (seed -1/d1 at p = k+1)
-//   column factors y0[j] (j > k),   y1'[j] = y1[j] + y0[j] (-e/d0)  (j > k+1)
-//   A[p][j] += M0(p,j) F0[p] y0[j] + M1(p,j) F1[p] y1'[j],   Mq(p,j) = (p <= k+q) or (p >= j)
+//   row factors   F0[p] = x0[p]  (seed 1 at p = k),     F1[p] = x1'[p] = x1[p] + F0[p] (-e/d0)  (seed 1 at p = k+1)
+//   column factors y0s[j] = y0[j] (-1/d0) (j > k),   y1s[j] = (y1[j] + y0[j] (-e/d0)) (-1/d1)  (j > k+1)
+//   A[p][j] += M0(p,j) F0[p] y0s[j] + M1(p,j) F1[p] y1s[j],   Mq(p,j) = (p <= k+q) or (p >= j)
 template <int NT, int KQ, int PAR>
 __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const RegCtx<NT>& c, const int kr, const int kend,
                                            const bool lower_eq) {
@@ -175,20 +175,22 @@ __device__ __forceinline__ void sweep_pair(f32x2 (&A2)[(NT + 1) / 2][NT], const 
     const float g0 = e * nrd0;                                         // -e / d0
     const float d1 = __builtin_fmaf(g0, e, d1raw);
     const float nrd1 = -__builtin_amdgcn_rcpf(d1);
-    // The row factors are formed with SCALAR v_mul / v_fma, not with the packed forms: with a split Gram kernel co-resident on
-    // the CU (separate stream), the packed versions of exactly these operations were observed to round single 16-lane passes
-    // differently from run to run (tools/corun_check.py); the scalar forms are bitwise stable and cost 0.3 %.
+    // The row factors stay RAW -- x0 and x1' = x1 + x0 (-e/d0) -- and the pivot reciprocals are folded into the COLUMN factors,
+    // of which only the NT - KQ block columns from the pivot block on exist:  y0s = y0 (-1/d0),  y1s = (y1 + y0 (-e/d0)) (-1/d1).
+    // (Scalar v_fma on purpose: with a split Gram kernel co-resident on the CU, the packed forms of the row-factor operations
+    // were observed to round single 16-lane passes differently from run to run -- tools/corun_check.py)
+    F0[KQ >> 1][KQ & 1] = (ty == kr) ? 1.f : F0[KQ >> 1][KQ & 1];       // row k seeds U_kj = -L_jk / d0
 #pragma unroll
-    for (int m = 0; m < NP2; ++m) { F0[m][0] *= nrd0; F0[m][1] *= nrd0; }
-    F0[KQ >> 1][KQ & 1] = (ty == kr) ? nrd0 : F0[KQ >> 1][KQ & 1];     // row k seeds U_kj
-#pragma unroll
-    for (int m = 0; m < NP2; ++m) {                                    // x1' (-1/d1)
-        F1[m][0] = __builtin_fmaf(F0[m][0], e, F1[m][0]) * nrd1;
-        F1[m][1] = __builtin_fmaf(F0[m][1], e, F1[m][1]) * nrd1;
+    for (int m = 0; m < NP2; ++m) {
+        F1[m][0] = __builtin_fmaf(F0[m][0], g0, F1[m][0]);
+        F1[m][1] = __builtin_fmaf(F0[m][1], g0, F1[m][1]);
     }
-    F1[KQ >> 1][KQ & 1] = (ty == kr + 1) ? nrd1 : F1[KQ >> 1][KQ & 1]; // row k+1 seeds U_{k+1,j}
+    F1[KQ >> 1][KQ & 1] = (ty == kr + 1) ? 1.f : F1[KQ >> 1][KQ & 1];   // row k+1 seeds U_{k+1,j}
 #pragma unroll
-    for (int ji = KQ; ji < NT; ++ji) y1[ji] = __builtin_fmaf(y0[ji], g0, y1[ji]);                  // y1'
+    for (int ji = KQ; ji < NT; ++ji) {
+        y1[ji] = __builtin_fmaf(y0[ji], g0, y1[ji]) * nrd1;
+        y0[ji] *= nrd0;
+    }
     y0[KQ] = (tx > kr) ? y0[KQ] : 0.f;                                 // pivot k updates columns j > k
     y1[KQ] = (tx > kr + 1) ? y1[KQ] : 0.f;                             // pivot k+1 updates columns j > k+1
     y0[NT - 1] = c.col_ok ? y0[NT - 1] : 0.f;                          // padding columns j >= N
