@@ -980,6 +980,30 @@ def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
     assert len(used) == 2
 
 
+def test_dkt_20way_train_and_test_use_the_blocked_large_n_path(cuda, capsys):
+    """cfg4 shape through the drop-in class: 20-way 5-shot, 16 queries -> N = 420 in train_loop (blocked MLL path, unfused
+    front end), 100 support / 300 query at test time; the loss of one episode against the float64 restatement."""
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=20, n_support=5).to(cuda)
+    m.train()
+    m.train_loop(0, _Loader(2, 20, 21, 28, 0), None)
+    assert "Epoch [0] [0/2]" in capsys.readouterr().out
+    assert torch.isfinite(m._last["loss"]) and 0.0 <= m._last["acc_query"].item() <= 100.0
+    x = _Loader(1, 20, 21, 28, 3).x[0]
+    z = m._embed(x.view(420, 3, 28, 28).to(cuda))
+    y = m._targets(20, 21, cuda)
+    loss, aux = m._episode_loss(z, y)
+    hyp = O.GPHypers(m.model.outputscale.detach().cpu().numpy().astype(np.float64),
+                     m.model.mean.detach().cpu().numpy().astype(np.float64), np.full(20, 0.1))
+    ref = O.train_episode(z.detach().cpu().numpy().astype(np.float64), 20, hyp)
+    assert abs(loss.item() - ref["loss"]) < MLL_RTOL * abs(ref["loss"])
+    assert int(aux["info"].abs().max()) == 0
+    m.eval()
+    m.n_query = 15
+    top1, count, _ = m.correct(_Loader(1, 20, 20, 28, 4).x[0])
+    assert count == 300 and 0 <= top1 <= 300
+
+
 def test_dkt_regression_surface(cuda):
     torch.manual_seed(0)
     bb = dkt_amd.backbone.Conv3()
