@@ -1,3 +1,5 @@
+"""dkt_mll_f32 on one stream while bf16-split Gram kernels run on another: number of episodes whose alpha differs from the
+single-stream result (0 expected).  DKT_AMD_LIB selects a variant library.  Measurement tooling."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
