@@ -298,7 +298,13 @@ class DKT(MetaTemplate):
                 self.writer.add_scalar('loss', loss, self.iteration)
 
             # evaluation on support / query with eval-mode features, conditioning on the (stale)
-            # train-mode features and the post-step hyper-parameters (DKT.py:170-192)
+            # train-mode features and the post-step hyper-parameters (DKT.py:170-192).  Its only consumers are the TensorBoard
+            # writer and the log line, and it has no side effect (eval-mode BatchNorm), so it runs only when one of them will
+            # read it (the reference runs it -- with 2C blocking read-backs -- on every iteration)
+            need_eval = self.writer is not None or i % print_freq == 0 or i == len(train_loader) - 1
+            if not need_eval:
+                self._last = dict(loss=loss.detach(), acc_support=None, acc_query=None, info=aux["info"])
+                continue
             with torch.no_grad():
                 self.model.eval()
                 self.likelihood.eval()
