@@ -161,7 +161,7 @@ class DKT(MetaTemplate):
         return (self.kernel_type in ("bncossim", "cossim") and n <= 128 and d % 4 == 0
                 and os.environ.get("DKT_FUSED_FRONTEND", "1") != "0")
 
-    def _episode_loss_from_trunk(self, x_feat, y):
+    def _episode_loss_from_trunk(self, x_feat, y, want_z=True):
         """Training loss of ONE episode from the trunk output x_feat:[N,D]; bn_out runs in train mode (batch statistics of
         the episode, running estimates updated exactly as nn.BatchNorm1d does) inside the fused kernels.
         Returns (loss, aux, z_train) with z_train the normalised train-mode features (detached) the in-loop evaluation
@@ -185,7 +185,9 @@ class DKT(MetaTemplate):
                 bn.running_mean.mul_(1.0 - mom).add_(bmean[0], alpha=mom)
                 bn.running_var.mul_(1.0 - mom).add_(bvar[0], alpha=mom)
                 bn.num_batches_tracked += 1
-            z_train = (xb[0].detach() * a.reshape(-1, xb.shape[2])[0] + s.reshape(-1, xb.shape[2])[0]) * rnorm[0].unsqueeze(1)
+            z_train = None
+            if want_z:
+                z_train = (xb[0].detach() * a.reshape(-1, xb.shape[2])[0] + s.reshape(-1, xb.shape[2])[0]) * rnorm[0].unsqueeze(1)
         aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
         return obj.mean(), aux, z_train
 
@@ -278,15 +280,17 @@ class DKT(MetaTemplate):
 
             # hyper-parameter means for the log line, read BEFORE the step (DKT.py:145-157); kept on
             # the device, converted to Python floats only when printed
-            with torch.no_grad():
-                log_outputscale = self.model.outputscale.mean()
-                log_noise = self.model.noise.mean()
-                ls = self.model.lengthscale
-                log_lengthscale = ls.mean() if ls is not None else torch.zeros((), device=dev)
+            need_eval = self.writer is not None or i % print_freq == 0 or i == len(train_loader) - 1
+            if i % print_freq == 0:
+                with torch.no_grad():
+                    log_outputscale = self.model.outputscale.mean()
+                    log_noise = self.model.noise.mean()
+                    ls = self.model.lengthscale
+                    log_lengthscale = ls.mean() if ls is not None else torch.zeros((), device=dev)
 
             optimizer.zero_grad()
             if fused:
-                loss, aux, z_train = self._episode_loss_from_trunk(x_feat, y_targets)
+                loss, aux, z_train = self._episode_loss_from_trunk(x_feat, y_targets, want_z=need_eval)
             else:
                 loss, aux = self._episode_loss(z_train, y_targets)
             loss.backward()
@@ -301,7 +305,6 @@ class DKT(MetaTemplate):
             # train-mode features and the post-step hyper-parameters (DKT.py:170-192).  Its only consumers are the TensorBoard
             # writer and the log line, and it has no side effect (eval-mode BatchNorm), so it runs only when one of them will
             # read it (the reference runs it -- with 2C blocking read-backs -- on every iteration)
-            need_eval = self.writer is not None or i % print_freq == 0 or i == len(train_loader) - 1
             if not need_eval:
                 self._last = dict(loss=loss.detach(), acc_support=None, acc_query=None, info=aux["info"])
                 continue
