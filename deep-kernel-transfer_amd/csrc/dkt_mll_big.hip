@@ -339,14 +339,17 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
         for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
             hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, b0, C, N, nb);
             if (hipMemsetAsync(info_m, 0, nmat * sizeof(int32_t), st) != hipSuccess) return DKT_ERR_LAUNCH;
-            // ---- blocked Cholesky with explicit inverses of the diagonal blocks ----
+            // ---- blocked Cholesky, LEFT-looking, with explicit inverses of the diagonal blocks.  Per block column j three
+            //      launches: (a) all row blocks i >= j at once:  A_ij -= sum_{k<j} L_ik L_jk^T  -- the blocks k < j are contiguous
+            //      columns, so this is ONE GEMM with M = N - off(j), K = off(j) (one pass over the result instead of j);
+            //      (b) the diagonal block: L_jj and U_jj = L_jj^-T by the register sweep;  (c) the panel below it, all row
+            //      blocks at once:  L_ij = A_ij U_jj.
             for (int j = 0; j < nbk; ++j) {
+                if (j > 0)
+                    gemm(st, nmat, false, true, N - off(j), sz(j), off(j), -1.f, blk(Lm, j, 0), N, nn, blk(Lm, j, 0), N, nn, 1.f, blk(Kw, j, j), N, nn);
                 dkt_chol_inv_block_launch(blk(Kw, j, j), N, nn, blk(Lm, j, j), N, nn, blk(Vm, j, j), N, nn, sz(j), off(j), info_m, nmat, st);
-                for (int i = j + 1; i < nbk; ++i)          // L_ij = A_ij U_jj
-                    gemm(st, nmat, false, false, sz(i), sz(j), sz(j), 1.f, blk(Kw, i, j), N, nn, blk(Vm, j, j), N, nn, 0.f, blk(Lm, i, j), N, nn);
-                for (int i = j + 1; i < nbk; ++i)          // A_ii' -= L_ij L_i'j^T  (lower block triangle)
-                    for (int i2 = j + 1; i2 <= i; ++i2)
-                        gemm(st, nmat, false, true, sz(i), sz(i2), sz(j), -1.f, blk(Lm, i, j), N, nn, blk(Lm, i2, j), N, nn, 1.f, blk(Kw, i, i2), N, nn);
+                if (j + 1 < nbk)
+                    gemm(st, nmat, false, false, N - off(j + 1), sz(j), sz(j), 1.f, blk(Kw, j + 1, j), N, nn, blk(Vm, j, j), N, nn, 0.f, blk(Lm, j + 1, j), N, nn);
             }
             if (attempt == a.max_tries) break;
             if (hipMemsetAsync(nfail, 0, sizeof(int), st) != hipSuccess) return DKT_ERR_LAUNCH;
@@ -359,8 +362,10 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
         // ---- V = L^-T, upper block triangular: V_jj = U_jj (already in Vm), V_ij = -U_ii sum_{k=i+1..j} L_ki^T V_kj ----
         for (int j = 1; j < nbk; ++j) {
             for (int i = j - 1; i >= 0; --i) {
-                for (int k = i + 1; k <= j; ++k)
-                    gemm(st, nmat, true, false, sz(i), sz(j), sz(k), 1.f, blk(Lm, k, i), N, nn, blk(Vm, k, j), N, nn, (k == i + 1) ? 0.f : 1.f, blk(Kinv, i, j), N, nn);
+                // the row blocks k = i+1 .. j are contiguous in memory: ONE GEMM over the long K instead of a launch (and a
+                // read-modify-write of the result) per k
+                gemm(st, nmat, true, false, sz(i), sz(j), off(j) + sz(j) - off(i + 1), 1.f, blk(Lm, i + 1, i), N, nn, blk(Vm, i + 1, j), N, nn, 0.f,
+                     blk(Kinv, i, j), N, nn);
                 gemm(st, nmat, false, false, sz(i), sz(j), sz(i), -1.f, blk(Vm, i, i), N, nn, blk(Kinv, i, j), N, nn, 0.f, blk(Vm, i, j), N, nn);
             }
         }
@@ -370,11 +375,10 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
         hipLaunchKernelGGL(big_finish_kernel, dim3(nmat), dim3(256), 0, st, a, Lm, Vm, wv, al, jit, info_m, b0);
         if (a.flags & DKT_MLL_WANT_CHOL) hipLaunchKernelGGL(big_chol_out_kernel, dim3(32, nmat), dim3(256), 0, st, a, Lm, info_m, b0);
         if (want_grad) {
-            // ---- K^-1 = V V^T, lower block triangle: (i, j), i >= j: sum_{k >= i} V_ik V_jk^T ----
+            // ---- K^-1 = V V^T, lower block triangle: row block i against the row blocks j <= i, all at once; the column blocks
+            //      k >= i are contiguous: one GEMM per i with N = off(i) + sz(i) columns and K = N - off(i) ----
             for (int i = 0; i < nbk; ++i)
-                for (int j = 0; j <= i; ++j)
-                    for (int k = i; k < nbk; ++k)
-                        gemm(st, nmat, false, true, sz(i), sz(j), sz(k), 1.f, blk(Vm, i, k), N, nn, blk(Vm, j, k), N, nn, (k == i) ? 0.f : 1.f, blk(Kinv, i, j), N, nn);
+                gemm(st, nmat, false, true, sz(i), off(i) + sz(i), N - off(i), 1.f, blk(Vm, i, i), N, nn, blk(Vm, 0, i), N, nn, 0.f, blk(Kinv, i, 0), N, nn);
             hipLaunchKernelGGL(big_w_kernel, dim3(32, bcnt), dim3(256), 0, st, a, Kinv, al, info_m, b0, nb);
         }
     }
