@@ -289,11 +289,10 @@ __global__ __launch_bounds__(256) void big_chol_out_kernel(MllArgs a, const floa
 inline int big_nb(int N) {
     static const int forced = [] { const char* v = getenv("DKT_BIG_NB"); return v ? atoi(v) : 0; }();
     if (forced >= 16 && forced <= 108) return forced & ~3;
-    // 64 x 64 GEMM tiles: when N is (almost) a multiple of 64, blocks of 64 waste nothing (N = 320: 2.9 ms against 3.3 ms with
-    // 4 blocks of 80; N = 190: -5 %); otherwise the fewest blocks of <= 108 rows win (N = 420: 4 x 105 beats 7 blocks of 64)
-    if (((N + 63) / 64) * 64 - N <= 8) return 64;
-    const int nbk = (N + 107) / 108;
-    return (((N + nbk - 1) / nbk) + 3) & ~3;
+    // blocks of 64 rows = the GEMM tile: no padded MFMA work, and with the merged left-looking launches the extra block columns
+    // cost little (N = 420: 7 blocks of 64 beat 4 blocks of 105 by 5 %; N = 320: 5 exact blocks)
+    (void)N;
+    return 64;
 }
 constexpr int BIG_CHUNK = 128;          // episodes per chunk of the workspace
 
