@@ -579,7 +579,8 @@ def test_predict_variance_vs_oracle(cuda):
 # ----------------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json cfg2 at bench batch): no oracle pass over 1024 episodes needed
 # ----------------------------------------------------------------------------------------------
-def test_full_size_properties_cfg2(cuda):
+@pytest.mark.parametrize("unit", [False, True], ids=["bf16_split", "unit_rows_f16_split"])
+def test_full_size_properties_cfg2(cuda, unit):
     b, n, d, c = 256, 105, 1600, 5
     gen = torch.Generator(device="cpu").manual_seed(1234)
     zr = torch.randn(b, n, d, generator=gen)
@@ -589,7 +590,7 @@ def test_full_size_properties_cfg2(cuda):
     hyp = O.perturbed_hypers(c, 7)
     sv, mean, noise = dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda)
     cw = torch.full((c,), -1.0 / (c * n), device=cuda)
-    obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw)
+    obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=unit)
     obj.sum().backward()
     assert int(info.abs().max().item()) == 0 and torch.isfinite(logp).all()
     assert torch.allclose(torch.diagonal(e, dim1=1, dim2=2), torch.ones(b, n, device=cuda), atol=2e-6)
@@ -600,7 +601,7 @@ def test_full_size_properties_cfg2(cuda):
     assert resid.abs().max().item() < 2e-4
     # determinism: a second launch is bitwise identical (no atomics anywhere)
     z2 = z.detach().clone().requires_grad_(True)
-    obj2, logp2, *_ = ops.episode_loss_linear(z2, y, sv, mean, noise, cw)
+    obj2, logp2, *_ = ops.episode_loss_linear(z2, y, sv, mean, noise, cw, unit_rows=unit)
     obj2.sum().backward()
     assert torch.equal(logp, logp2) and torch.equal(z.grad, z2.grad)
     # spot-check three episodes against the oracle at full size
@@ -610,7 +611,7 @@ def test_full_size_properties_cfg2(cuda):
         assert rel_l2(z.grad[i].cpu().numpy(), ref["dz"]) < GRAD_RTOL
     # linearity of the backward in the upstream gradient
     z3 = z.detach().clone().requires_grad_(True)
-    obj3, *_ = ops.episode_loss_linear(z3, y, sv, mean, noise, cw)
+    obj3, *_ = ops.episode_loss_linear(z3, y, sv, mean, noise, cw, unit_rows=unit)
     (2.5 * obj3.sum()).backward()
     # (the scale is folded into the MFMA A operand, so the two results differ by fp32 rounding amplified by the
     # cancellation between the alpha alpha^T and K^-1 parts of W: compare in relative L2)
