@@ -15,10 +15,14 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
-SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_blk.hip", "dkt_mll_wave.hip", "dkt_predict.hip", "dkt_spectral.hip",
-           "dkt_frontend.hip", "dkt_diag.hip"]     # dkt_diag: measurement-only kernels, outside the ABI header
+SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_predict.hip",
+           "dkt_spectral.hip", "dkt_frontend.hip"]
+# measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
+DIAG_SOURCES = ["dkt_diag.hip"]
+DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
 HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"),
            os.path.join(CSRC, "dkt_split.h"), os.path.join(INCLUDE, "dkt_abi.h")]
+OBJ_DIR = os.path.join(_HERE, "build")
 
 _c_p = ctypes.c_void_p
 _c_i = ctypes.c_int
@@ -55,14 +59,64 @@ def _lib_path() -> str:
     return os.environ.get("DKT_AMD_LIB") or LIB_PATH
 
 
+def _flags() -> list:
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", INCLUDE, "-I", CSRC] + \
+        os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def _digest(src: str) -> str:
+    """Content hash of a source, every header and the flags: the object cache key (mtimes do not survive a checkout)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [src] + HEADERS:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()[:20]
+
+
+def _stamp(sources, replace=None) -> str:
+    return ";".join(_digest((replace or {}).get(s, os.path.join(CSRC, s))) for s in sources)
+
+
 def needs_build() -> bool:
     if os.environ.get("DKT_AMD_LIB"):
         return False
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(LIB_PATH + ".stamp"):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(LIB_PATH + ".stamp") as fh:
+        return fh.read() != _stamp(SOURCES)
+
+
+def _compile_link(sources, target, replace=None, verbose=False) -> str:
+    """One hipcc -c per source (in parallel, objects cached by content hash under build/), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+
+    def one(name):
+        src = (replace or {}).get(name, os.path.join(CSRC, name))
+        obj = os.path.join(OBJ_DIR, "%s.%s.o" % (os.path.basename(src), _digest(src)))
+        if not os.path.exists(obj):
+            cmd = [hipcc] + _flags() + ["-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s%s" % (name, res.stdout, res.stderr))
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(one, sources))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(target + ".tmp", target)
+    with open(target + ".stamp", "w") as fh:
+        fh.write(_stamp(sources, replace))
+    return target
 
 
 def build(force: bool = False, verbose: bool = False, out: str = None, replace: dict = None) -> str:
@@ -70,18 +124,20 @@ def build(force: bool = False, verbose: bool = False, out: str = None, replace: 
     Cross-compiles without a GPU.  `out` / `replace` ({source name: other path}) build a variant library for A/B runs."""
     if out is None and not force and not needs_build():
         return LIB_PATH
-    target = out or LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [(replace or {}).get(s, os.path.join(CSRC, s)) for s in SOURCES]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           "-I", INCLUDE, "-I", CSRC] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split() + srcs + ["-o", target + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(target + ".tmp", target)
-    return target
+    if force and os.path.isdir(OBJ_DIR):
+        for f in os.listdir(OBJ_DIR):
+            if f.endswith(".o"):
+                os.remove(os.path.join(OBJ_DIR, f))
+    return _compile_link(SOURCES, out or LIB_PATH, replace, verbose)
+
+
+def build_diag(verbose: bool = False) -> str:
+    """The measurement-only kernels (tools/, tests): libdkt_diag.so, never loaded by the product path."""
+    if os.path.exists(DIAG_LIB_PATH) and os.path.exists(DIAG_LIB_PATH + ".stamp"):
+        with open(DIAG_LIB_PATH + ".stamp") as fh:
+            if fh.read() == _stamp(DIAG_SOURCES):
+                return DIAG_LIB_PATH
+    return _compile_link(DIAG_SOURCES, DIAG_LIB_PATH, None, verbose)
 
 
 def load() -> ctypes.CDLL:
@@ -105,6 +161,11 @@ def load() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def load_diag() -> ctypes.CDLL:
+    """dlopen the measurement-only library (tools / tests); builds it on first use."""
+    return ctypes.CDLL(build_diag())
 
 
 STATUS = {0: "DKT_OK", -1: "DKT_ERR_BAD_ARG", -2: "DKT_ERR_TOO_LARGE", -3: "DKT_ERR_WORKSPACE", -4: "DKT_ERR_LAUNCH"}

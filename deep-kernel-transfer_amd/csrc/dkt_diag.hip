@@ -127,3 +127,35 @@ extern "C" int dkt_diag_spin(float* out, int nblocks, int iters, int mode, void*
     hipLaunchKernelGGL(spin_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, iters, mode);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- lane primitives the MFMA marginal-likelihood kernel relies on (tests/test_gpu_parity.py::test_lane_primitives) ----
+// One wave.  in: [4][64] an accumulator-layout tile X (register q, lane l) and [4][64] a tile Y.
+// out[0:64]    = DPP row_newbcast:3 of X register 0
+// out[64:320]  = the four registers v_permlane32_swap / v_permlane16_swap spread X register 1 into
+// out[320:576] = X^T Y through four v_mfma_f32_16x16x4_f32 with X's registers as A and Y's as B operands (accumulator layout)
+// out[576:640] = v_fmac_f32_dpp acc += row_newbcast:5(acc) * t  with acc = X register 2, t = Y register 0
+__global__ __launch_bounds__(64) void lane_primitives_kernel(const float* in, float* out) {
+    const int l = threadIdx.x;
+    float x[4], y[4];
+    for (int q = 0; q < 4; ++q) { x[q] = in[q * 64 + l]; y[q] = in[256 + q * 64 + l]; }
+    out[l] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[0]), 0x150 + 3, 0xf, 0xf, false));
+    const unsigned u = __float_as_uint(x[1]);
+    auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    auto lo = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+    out[64 + l] = __uint_as_float(lo[0]);
+    out[128 + l] = __uint_as_float(lo[1]);
+    out[192 + l] = __uint_as_float(hi[0]);
+    out[256 + l] = __uint_as_float(hi[1]);
+    dg_f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[q], c, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) out[320 + q * 64 + l] = c[q];
+    float acc = x[2];
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y[0]));
+    out[576 + l] = acc;
+}
+
+extern "C" int dkt_diag_lane_primitives(const float* in, float* out, void* stream) {
+    hipLaunchKernelGGL(lane_primitives_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -1,4 +1,4 @@
-// Shared between dkt_mll.hip (generic LDS/global path) and dkt_mll_reg.hip (register-resident path).
+// Shared between dkt_mll.hip (dispatch + generic LDS/global path), dkt_mll_mfma.hip, dkt_mll_reg.hip and dkt_mll_big.hip.
 #pragma once
 #include "dkt_common.h"
 #include "../../include/dkt_abi.h"
@@ -29,12 +29,10 @@ struct MllArgs {
 
 constexpr float DKT_HALF_LOG_2PI = 0.91893853320467274178f;
 
-// Register-resident path: handles N + 1 <= 128.  Returns false when N is out of range.
+// Wave-per-class-matrix MFMA path (dkt_mll_mfma.hip): the default for N + 1 <= 128.  Returns false when N is out of range.
+bool dkt_mll_mfma_launch(const MllArgs& a, hipStream_t st);
+// Register-resident sweep (dkt_mll_reg.hip; the round-1 default, kept as the DKT_MLL_FORCE_REG validation twin): N + 1 <= 128.
 bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st);
-// Blocked path (panel sweep + MFMA trailing updates): N + 1 <= 128.
-bool dkt_mll_blk_launch(const MllArgs& a, hipStream_t st);
-// Wave-per-episode path (no barriers): N + 1 in (104, 112].  Returns false when N is out of range / disabled.
-bool dkt_mll_wave_launch(const MllArgs& a, hipStream_t st);
 
 // Batched factorisation + inversion of nb x nb diagonal blocks (nb <= 127) with the register-resident sweep (dkt_mll_reg.hip).
 void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int ldl, long sL, float* U, int ldu, long sU, int nb,

@@ -53,6 +53,7 @@ extern "C" {
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
 #define DKT_MLL_WANT_CHOL 2u /* also write the Cholesky factors L[B,C,N,N]                  */
 #define DKT_MLL_FORCE_GENERIC 4u /* validation aid: take the generic LDS/global path for any N  */
+#define DKT_MLL_FORCE_REG 8u     /* validation aid: the register-sweep kernel instead of the MFMA wave-per-matrix kernel (N <= 127) */
 
 int dkt_abi_version(void);
 

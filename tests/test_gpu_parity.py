@@ -248,17 +248,18 @@ def _episode_case(c, per, d, seed, corr=0, b=2):
                                           # block-column boundaries of the two-pivots-per-barrier sweep (even / odd tails)
                                           (1, 3, 8, 0), (1, 31, 16, 0), (1, 32, 16, 0), (1, 33, 16, 0), (2, 32, 16, 0), (1, 65, 16, 0),
                                           (2, 48, 16, 0), (1, 97, 16, 0), (1, 113, 16, 0), (1, 126, 16, 0)])
-@pytest.mark.parametrize("force_generic", [False, True])
-def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, force_generic):
-    """force_generic=False: register-resident kernel for N <= 126, generic LDS/global kernel above;
-    force_generic=True: the generic kernel for every N."""
+@pytest.mark.parametrize("path", ["default", "reg", "generic"])
+def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, path):
+    """default: the wave-per-matrix MFMA kernel for N <= 127, the blocked / generic kernels above;
+    reg: the register-sweep twin (DKT_MLL_FORCE_REG);  generic: the generic LDS / global kernel for every N."""
+    force_generic, force_reg = path == "generic", path == "reg"
     z, hyp, n = _episode_case(c, per, d, 17 + n_hash(c, per, d), corr)
     y = O.one_vs_rest_targets(c, per)
     sv = hyp.outputscale
     cw = np.full(c, -1.0 / (c * n))
     e_dev = ops.gram(dev_t(z, cuda))
     out = ops.mll(e_dev, dev_t(y, cuda), dev_t(sv, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda),
-                  want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda), force_generic=force_generic)
+                  want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda), force_generic=force_generic, force_reg=force_reg)
     torch.cuda.synchronize()
     assert int(out["info"].abs().max().item()) == 0
     assert float(out["jitter"].abs().max().item()) == 0.0
@@ -311,19 +312,45 @@ def test_mll_full_occupancy_is_race_free(cuda, c, per):
     assert ((runs[0]["w"] - gen["w"]).flatten(1).norm(dim=1) / gen["w"].flatten(1).norm(dim=1)).max().item() < 1e-4
 
 
-@pytest.mark.parametrize("c,per,d,corr", [(5, 21, 64, 0), (5, 21, 1600, 5), (1, 104, 32, 0), (3, 37, 24, 0)])
-def test_mll_wave_per_episode_kernel(cuda, c, per, d, corr, monkeypatch):
-    """The barrier-free wave-per-episode kernel (off by default) stays parity-green for its
-    N range (104 <= N <= 111): it must reproduce the register kernel's outputs to rounding."""
+def test_lane_primitives(cuda):
+    """The hardware idioms the MFMA marginal-likelihood kernel is built on (csrc/dkt_mll_mfma.hip): DPP row_newbcast, the
+    v_permlane32/16_swap row spread, X^T Y straight from accumulator registers, and the DPP-fused FMA of the sweep."""
+    import ctypes
+    import dkt_amd
+    lib = dkt_amd._lib.load_diag()
+    lib.dkt_diag_lane_primitives.restype = ctypes.c_int
+    lib.dkt_diag_lane_primitives.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+    xt, yt = rng.standard_normal((16, 16)).astype(np.float32), rng.standard_normal((16, 16)).astype(np.float32)
+    lane = np.arange(64)
+    g, c = lane >> 4, lane & 15
+    acc = lambda t: np.stack([t[4 * g + q, c] for q in range(4)])          # accumulator layout [4][64]
+    inp = np.concatenate([acc(xt).ravel(), acc(yt).ravel()]).astype(np.float32)
+    out = torch.zeros(640, device=cuda)
+    assert lib.dkt_diag_lane_primitives(dev_t(inp, cuda).data_ptr(), out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    x, y = acc(xt), acc(yt)
+    np.testing.assert_array_equal(o[:64], x[0][(lane & ~15) | 3])
+    for k in range(4):                                                     # rows 1, 5, 9, 13 of X in every row group
+        np.testing.assert_array_equal(o[64 + 64 * k:128 + 64 * k], xt[4 * k + 1, c])
+    np.testing.assert_allclose(o[320:576].reshape(4, 64), acc(xt.T.astype(np.float64) @ yt.astype(np.float64)), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o[576:640], x[2] + x[2][(lane & ~15) | 5] * y[0], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,per,d,corr", [(5, 21, 64, 0), (5, 21, 1600, 5), (1, 104, 32, 0), (3, 37, 24, 0), (20, 5, 64, 0), (7, 9, 32, 0),
+                                          (6, 4, 16, 0), (2, 8, 16, 0)])
+def test_mll_mfma_kernel_against_register_twin(cuda, c, per, d, corr):
+    """The default wave-per-matrix MFMA kernel and the register-sweep twin are different algorithms (upper blocked
+    factorisation on the matrix pipe vs a right-looking sweep on the VALU): every output must agree to rounding, with and
+    without the gradient / Cholesky outputs (different template instantiations), C > 5 running the classes in rounds."""
     z, hyp, n = _episode_case(c, per, d, 5 + n_hash(c, per, d), corr, b=3)
     y = dev_t(O.one_vs_rest_targets(c, per), cuda)
     cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
     e = ops.gram(dev_t(z, cuda))
     args = (e, y, dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda))
-    monkeypatch.setenv("DKT_MLL_WAVE", "1")
     a = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=cw)
-    monkeypatch.setenv("DKT_MLL_WAVE", "0")
-    r = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=cw)
+    r = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=cw, force_reg=True)
     torch.cuda.synchronize()
     for i in range(3):
         res = O.mll_terms(O.gram_linear(z[i]), O.one_vs_rest_targets(c, per), hyp.outputscale, hyp.mean, hyp.noise)
@@ -331,6 +358,13 @@ def test_mll_wave_per_episode_kernel(cuda, c, per, d, corr, monkeypatch):
     for key in ("logp", "alpha", "chol", "w", "dsv", "dmean", "dnoise"):
         assert rel_l2(a[key].cpu().numpy(), r[key].cpu().numpy()) < 1e-4, key
     assert int(a["info"].abs().max().item()) == 0
+    g = ops.mll(*args, want_grad=True, cls_weight=cw)
+    f = ops.mll(*args)
+    ch = ops.mll(*args, want_chol=True)
+    for key in ("logp", "alpha"):                       # the four template instantiations agree to rounding
+        for other in (g, f, ch):
+            assert rel_l2(a[key].cpu().numpy(), other[key].cpu().numpy()) < 2e-6, key
+    assert rel_l2(a["w"].cpu().numpy(), g["w"].cpu().numpy()) < 2e-6 and rel_l2(a["chol"].cpu().numpy(), ch["chol"].cpu().numpy()) < 2e-6
 
 
 def n_hash(*a):
@@ -357,8 +391,9 @@ def test_mll_per_episode_targets_and_residual_property(cuda):
         assert np.abs(l @ l.T - k).max() < 1e-5 and np.abs(np.triu(l, 1)).max() == 0.0
 
 
-@pytest.mark.parametrize("force_generic", [False, True])
-def test_jitter_retry_and_failure_info(cuda, force_generic):
+@pytest.mark.parametrize("path", ["default", "reg", "generic"])
+def test_jitter_retry_and_failure_info(cuda, path):
+    force_generic, force_reg = path == "generic", path == "reg"
     rng = np.random.default_rng(0)
     q, _ = np.linalg.qr(rng.standard_normal((8, 8)))
     y = np.ones((1, 8))
@@ -367,7 +402,7 @@ def test_jitter_retry_and_failure_info(cuda, force_generic):
         e = q @ np.diag([min_eig, 0.3, 0.5, 0.7, 1.0, 1.2, 1.5, 2.0]) @ q.T
         e = 0.5 * (e + e.T)
         o = ops.mll(dev_t(e[None], cuda), dev_t(y, cuda), dev_t([1.0], cuda), dev_t([0.0], cuda), dev_t([0.1], cuda),
-                    want_grad=True, force_generic=force_generic)
+                    want_grad=True, force_generic=force_generic, force_reg=force_reg)
         return e, o
 
     # K = E + 0.1 I has smallest eigenvalue -5e-5: plain, 1e-6, 1e-5 fail; total jitter 1e-4 succeeds

@@ -23,7 +23,7 @@ e = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
 torch.cuda.synchronize()
 ref = ops.mll(e, y, sv, mean, noise)
 torch.cuda.synchronize()
-lib = dkt_amd._lib.load()
+lib = dkt_amd._lib.load_diag()
 lib.dkt_diag_spin.restype = ctypes.c_int
 lib.dkt_diag_spin.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 scratch = torch.empty(4096 * 256, device=dev)

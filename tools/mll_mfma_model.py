@@ -1,0 +1,169 @@
+"""Lane-level numpy model of the wave-per-matrix MFMA marginal-likelihood kernel (csrc/dkt_mll_mfma.hip).
+
+Design aid, not product code: it executes the kernel's algorithm with the exact register layouts of gfx950
+(v_mfma_f32_16x16x4_f32 operand / accumulator lane maps, DPP row_newbcast, the replicated column layout of the
+diagonal-tile sweep) so that the index logic can be checked on a CPU against numpy's Cholesky / inverse before
+any GPU time is spent.  Run:  python tools/mll_mfma_model.py
+"""
+import numpy as np
+
+L = np.arange(64)
+G, Cc = L >> 4, L & 15           # row group, position in the row
+
+
+def mfma(a, b, c):
+    """D = C + A B with A[i][k] in lane (k*16+i), B[k][j] in lane (k*16+j), D[4g+r][j] in lane (g*16+j) reg r."""
+    A = np.zeros((16, 4)); Bm = np.zeros((4, 16))
+    A[Cc, G] = a
+    Bm[G, Cc] = b
+    D = A @ Bm
+    out = c.copy()
+    for r in range(4):
+        out[r] += D[4 * G + r, Cc]
+    return out
+
+
+def tile_to_acc(T):
+    """16x16 matrix -> accumulator layout [4][64]."""
+    return np.stack([T[4 * G + r, Cc] for r in range(4)])
+
+
+def acc_to_tile(x):
+    T = np.zeros((16, 16))
+    for r in range(4):
+        T[4 * G + r, Cc] = x[r]
+    return T
+
+
+def xty(X, Y, C=None):
+    """C + X^T Y on accumulator-layout tiles: register r of X is the A operand, register r of Y the B operand."""
+    out = np.zeros((4, 64)) if C is None else C
+    for r in range(4):
+        out = mfma(X[r], Y[r], out)
+    return out
+
+
+def bcast(x, p):
+    """DPP row_newbcast:p"""
+    return x[(L & ~15) | p]
+
+
+def to_columns(S):
+    """accumulator layout -> replicated column layout a[i][lane] = T[i][lane & 15] (permlane32/16 swaps on the GPU)."""
+    T = acc_to_tile(S)
+    return np.stack([T[i, Cc] for i in range(16)])
+
+
+def sweep(S):
+    """Diagonal tile: S = -(Schur complement) in accumulator layout -> M = R^-T (acc layout), dv (lane c: raw pivot d_c).
+    ONE register per row: lanes c > p of row i hold the (negated) Schur part, lanes c <= p the rows of L^-1 being built.
+    A non-positive pivot is replaced by 1 (augmented row, failed matrices); the padding pivots are 1 by construction."""
+    x = to_columns(S)
+    dv = np.ones(64)
+    for p in range(16):
+        dneg = bcast(x[p], p)               # = -d
+        eq = Cc == p
+        dv = np.where(eq, -dneg, dv)
+        dneg = np.where(dneg < 0, dneg, -1.0)
+        rs = 1.0 / np.sqrt(-dneg)
+        rs2 = rs * rs
+        t = np.where(eq, rs2 - 1.0, x[p] * rs2)
+        x[p] = np.where(eq, rs, x[p] * rs)
+        for i in range(p + 1, 16):
+            x[i] = x[i] + bcast(x[i], p) * t
+    M = np.zeros((4, 64))
+    for r in range(4):
+        v = np.choose(G, [x[r], x[4 + r], x[8 + r], x[12 + r]])
+        M[r] = np.where(Cc <= 4 * G + r, v, 0.0)
+    return M, dv, x
+
+
+def run(N, K, rvec):
+    """Full algorithm on the (N+1)-augmented, padded matrix.  Returns logdet, quad, alpha, K^-1 - alpha alpha^T (N x N)."""
+    NT = (N + 1 + 15) // 16
+    NP = 16 * NT
+    pN = N - 16 * (NT - 1)
+    Sfull = np.zeros((NP, NP))
+    Sfull[:N, :N] = -K
+    Sfull[:N, N] = -rvec
+    Sfull[N, :N] = -rvec
+    for p in range(N + 1, NP):
+        Sfull[p, p] = -1.0
+    tile = lambda i, j: tile_to_acc(Sfull[16 * i:16 * i + 16, 16 * j:16 * j + 16])
+    T = {(i, j): tile(i, j) for i in range(NT) for j in range(i, NT)}
+    negI = tile_to_acc(-np.eye(16))
+    Md = {}
+    logdet = 0.0
+    quad = None
+    # ---- phase 1: K' = R^T R, tiles hold S = -(Schur) until they become R ----
+    for k in range(NT):
+        last = k == NT - 1
+        M, dv, _ = sweep(T[(k, k)])
+        Md[k] = M
+        valid = (16 * k + Cc) < N
+        logdet += np.sum(np.log(dv[:16])[valid[:16]])
+        if last:
+            quad = -dv[pN]                       # the augmented pivot met S[N][N] = +|w|^2
+        nV = xty(M, negI)                        # M^T (-I) = -V_kk
+        for j in range(k + 1, NT):
+            T[(k, j)] = xty(nV, T[(k, j)])       # R_kj = (-V_kk)^T S_kj
+        for i in range(k + 1, NT):
+            for j in range(i, NT):
+                T[(i, j)] = xty(T[(k, i)], T[(k, j)], T[(i, j)])     # S_ij += R_ki^T R_kj
+    # ---- phase 2: M = R^-T, M_ji (j > i) overwrites slot (i, j) ----
+    for j in range(1, NT):
+        nV = xty(Md[j], negI)
+        for i in range(j):
+            Q = xty(T[(i, j)], Md[i])            # k = i term: R_ij^T M_ii
+            for k in range(i + 1, j):
+                Q = xty(T[(k, j)], T[(i, k)], Q)  # R_kj^T M_ki   (M_ki sits in slot (i, k))
+            T[(i, j)] = xty(nV, Q)               # M_ji = -V_jj^T Q
+    # alpha = -(row N of M)
+    alpha = np.zeros(NP)
+    for i in range(NT - 1):
+        t = acc_to_tile(T[(i, NT - 1)])          # M_{NT-1, i}: rows = block NT-1, cols = block i
+        alpha[16 * i:16 * i + 16] = -t[pN, :]
+    alpha[16 * (NT - 1):] = -acc_to_tile(Md[NT - 1])[pN, :]
+    alpha = alpha[:N]
+    # ---- phase 3: P''_ij = sum_{k >= j} Mflip_ki^T M_kj, in place, result in slot (i, j), diagonal in Md ----
+    sg = np.stack([np.where(4 * G + r == pN, -1.0, 1.0) for r in range(4)])
+    Mt = lambda k, i: Md[k] if k == i else T[(i, k)]
+    for j in range(NT):
+        for i in list(range(j)) + [j]:
+            acc = None
+            for k in range(j, NT):
+                A = Mt(k, i)
+                if k == NT - 1:
+                    A = A * sg
+                acc = xty(A, Mt(k, j), acc)
+            if i == j:
+                Md[j] = acc
+            else:
+                T[(i, j)] = acc
+    P = np.zeros((NP, NP))
+    for j in range(NT):
+        P[16 * j:16 * j + 16, 16 * j:16 * j + 16] = acc_to_tile(Md[j])
+        for i in range(j):
+            P[16 * i:16 * i + 16, 16 * j:16 * j + 16] = acc_to_tile(T[(i, j)])
+            P[16 * j:16 * j + 16, 16 * i:16 * i + 16] = acc_to_tile(T[(i, j)]).T
+    return logdet, quad, alpha, P[:N, :N]
+
+
+def main():
+    rng = np.random.default_rng(0)
+    for N in (5, 15, 16, 19, 25, 31, 85, 105, 111, 112, 127):
+        Z = rng.standard_normal((N, 40))
+        Z /= np.linalg.norm(Z, axis=1, keepdims=True)
+        K = 0.7 * Z @ Z.T + 0.1 * np.eye(N)
+        r = rng.standard_normal(N)
+        logdet, quad, alpha, P = run(N, K, r)
+        Ki = np.linalg.inv(K)
+        a_ref = Ki @ r
+        err = [abs(logdet - np.linalg.slogdet(K)[1]), abs(quad - r @ a_ref), np.abs(alpha - a_ref).max(),
+               np.abs(P - (Ki - np.outer(a_ref, a_ref))).max()]
+        print("N=%3d  logdet %.2e  quad %.2e  alpha %.2e  P %.2e" % (N, *err))
+        assert max(err) < 1e-9
+
+
+if __name__ == "__main__":
+    main()

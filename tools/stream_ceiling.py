@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dkt_amd  # noqa: E402
 
-lib = dkt_amd._lib.load()
+lib = dkt_amd._lib.load_diag()
 fn = lib.dkt_diag_stream_f32
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
