@@ -159,3 +159,160 @@ extern "C" int dkt_diag_lane_primitives(const float* in, float* out, void* strea
     hipLaunchKernelGGL(lane_primitives_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- issue-rate microbenchmarks of the instruction forms the MFMA marginal-likelihood sweep uses (tools/ubench_valu.py) ----
+// One wave per workgroup; out[block * 8 + v] = s_memtime ticks per instruction of variant v.
+#define DG_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <bool BIGREG>
+__global__ __launch_bounds__(768) void valu_ubench_kernel(float* out, int iters) {
+    if constexpr (BIGREG) asm volatile("v_mov_b32 v167, 0" ::: "v167");           // 168 VGPRs: three waves fill a SIMD's register file
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = 1.0f + threadIdx.x * 1e-3f + i;
+    float t = 1e-6f;
+    unsigned long long t0, t1;
+    float res[8];
+    // 0: plain v_fmac_f32
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[0] = (float)(t1 - t0) / (16.f * iters);
+    // 1: v_fmac_f32_dpp row_newbcast
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(t));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[1] = (float)(t1 - t0) / (16.f * iters);
+    // 2: v_fmac_f32_dpp quad_perm (classic DPP)
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(t));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[2] = (float)(t1 - t0) / (16.f * iters);
+    // 3: v_readlane_b32 + v_fmac_f32 with the SGPR operand (2 instructions per update)
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_readlane_b32 s40, %0, 3\n\tv_fmac_f32 %0, s40, %1" : "+v"(a[k]) : "v"(t) : "s40");
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[3] = (float)(t1 - t0) / (32.f * iters);
+    // 4: v_mov_b32_dpp row_newbcast
+    float b[16];
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(b[k]) : "v"(a[k]));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[4] = (float)(t1 - t0) / (16.f * iters);
+    // 5: v_rsq_f32
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_rsq_f32 %0, %1" : "=v"(b[k]) : "v"(a[k]));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[5] = (float)(t1 - t0) / (16.f * iters);
+    // 6: dependent chain of plain v_fmac_f32 (latency)
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[0]) : "v"(t));
+        DG_REP16(DG_X)
+#undef DG_X
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[6] = (float)(t1 - t0) / (16.f * iters);
+    // 7: v_mfma_f32_16x16x4_f32, four independent accumulators
+    dg_f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], a[3], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], a[5], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[6], a[7], c3, 0, 0, 0);
+        }
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    res[7] = (float)(t1 - t0) / (16.f * iters);
+    float s = c0[0] + c1[1] + c2[2] + c3[3];
+    for (int i = 0; i < 16; ++i) s += a[i] + b[i];
+    if ((threadIdx.x & 63) == 0)
+        for (int v = 0; v < 8; ++v) out[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + v] = res[v];
+    if (s == 123.456f) out[0] = s;
+}
+
+extern "C" int dkt_diag_valu_ubench(float* out, int nblocks, int waves_per_block, int iters, void* stream) {
+    if (iters < 0) hipLaunchKernelGGL(valu_ubench_kernel<true>, dim3(nblocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, out, -iters);
+    else hipLaunchKernelGGL(valu_ubench_kernel<false>, dim3(nblocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, out, iters);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---- the diagonal-tile sweep of dkt_mll_mfma.hip in isolation, at 1 .. 3 waves per SIMD (tools/ubench_valu.py) ----
+// MODE 0: v_fmac_f32_dpp (fused);  MODE 1: v_mov_b32_dpp + v_fmac_f32;  MODE 2: fused, no s_nop between the pieces
+template <int MODE, int P, int I>
+__device__ __forceinline__ void dg_rows(float (&x)[16], const float t) {
+    if constexpr (I < 16) {
+        if constexpr (MODE == 1) {
+            float m;
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(x[I]), "n"(P));
+            x[I] = __builtin_fmaf(m, t, x[I]);
+        } else if constexpr (MODE == 0) {
+            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x[I]) : "v"(t), "n"(P));
+        } else {
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x[I]) : "v"(t), "n"(P));
+        }
+        dg_rows<MODE, P, I + 1>(x, t);
+    }
+}
+template <int MODE, int P>
+__device__ __forceinline__ void dg_sweep(float (&x)[16], float& dv, const int c) {
+    if constexpr (P < 16) {
+        float xp;
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(xp) : "v"(x[P]), "n"(P));
+        const float d = 1.0f - xp;
+        const bool eq = c == P;
+        dv = eq ? d : dv;
+        const float rs = __builtin_amdgcn_rsqf(d);
+        const float t = x[P] * (rs * rs);
+        x[P] = eq ? rs : x[P] * rs;
+        dg_rows<MODE, P, P + 1>(x, t);
+        dg_sweep<MODE, P + 1>(x, dv, c);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(768) void sweep_ubench_kernel(float* out, int iters) {
+    float x[16], dv = 0.f;
+    for (int i = 0; i < 16; ++i) x[i] = ((threadIdx.x & 15) == i) ? 0.5f : 0.01f * (i + 1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        dg_sweep<MODE, 0>(x, dv, threadIdx.x & 15);
+        for (int i = 0; i < 16; ++i) x[i] = x[i] * 1e-3f + (((threadIdx.x & 15) == i) ? 0.5f : 0.01f);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = dv;
+    for (int i = 0; i < 16; ++i) s += x[i];
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (float)(t1 - t0) / iters;
+    if (s == 123.456f) out[0] = s;
+}
+extern "C" int dkt_diag_sweep_ubench(float* out, int nblocks, int waves_per_block, int iters, int mode, void* stream) {
+    const dim3 g(nblocks), b(64 * waves_per_block);
+    if (mode == 0) hipLaunchKernelGGL(sweep_ubench_kernel<0>, g, b, 0, (hipStream_t)stream, out, iters);
+    else if (mode == 1) hipLaunchKernelGGL(sweep_ubench_kernel<1>, g, b, 0, (hipStream_t)stream, out, iters);
+    else hipLaunchKernelGGL(sweep_ubench_kernel<2>, g, b, 0, (hipStream_t)stream, out, iters);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -93,58 +93,24 @@ struct Lane {
 // Row p is final afterwards: scaled by 1/sqrt(d) it is row p of M = R^-T for c <= p (and of -R for c > p).
 // A non-positive pivot is replaced by 1: the augmented pivot (whose raw value is the quadratic form), and the pivots of a
 // matrix that fails (reported through dv, outputs poisoned by the caller).  Padding pivots are 1 by construction.
-// x[i] += row_newbcast_P(x[i]) * t for i = P+1 .. 15 as ONE asm block of v_fmac_f32_dpp (hipcc does not fuse the DPP move into the
-// FMA: it emits v_mov 0 / s_nop / v_mov_dpp / v_fmac per update).  The leading s_nop 1 covers the "VALU write -> DPP read: 2 wait
-// states" hazard for whatever the compiler placed just before the block; inside it every instruction reads a register written
-// at least one pivot earlier.
+// x[i] += row_newbcast_P(x[i]) * t for rows i = I0 .. I0 + CNT - 1 as ONE asm block of v_fmac_f32_dpp (hipcc does not fuse the DPP
+// move into the FMA: it emits v_mov 0 / s_nop / v_mov_dpp / v_fmac per update).  The leading s_nop 1 covers the "VALU write -> DPP
+// read: 2 wait states" hazard for whatever the compiler placed just before the block; inside it every instruction reads a register
+// written at least one pivot earlier.
 #define DKT_FMD(k) "v_fmac_f32_dpp %" #k ", %" #k ", %[t] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
-template <int P>
-__device__ __forceinline__ void sweep_rows(float (&x)[16], const float t) {
-    if constexpr (P == 0)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9) DKT_FMD(10) DKT_FMD(11) DKT_FMD(12) DKT_FMD(13) DKT_FMD(14)
-                     : "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 1)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9) DKT_FMD(10) DKT_FMD(11) DKT_FMD(12) DKT_FMD(13)
-                     : "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 2)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9) DKT_FMD(10) DKT_FMD(11) DKT_FMD(12)
-                     : "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 3)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9) DKT_FMD(10) DKT_FMD(11)
-                     : "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 4)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9) DKT_FMD(10)
-                     : "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 5)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8) DKT_FMD(9)
-                     : "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 6)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7) DKT_FMD(8)
-                     : "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 7)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6) DKT_FMD(7)
-                     : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 8)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5) DKT_FMD(6)
-                     : "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 9)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) DKT_FMD(5)
-                     : "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 10)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4)
-                     : "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 11)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3)
-                     : "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 12)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2)
-                     : "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 13)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1)
-                     : "+v"(x[14]), "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
-    else if constexpr (P == 14)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0)
-                     : "+v"(x[15]) : [t] "v"(t), [p] "n"(P));
+template <int P, int I0, int CNT>
+__device__ __forceinline__ void sweep_rows_piece(float (&x)[16], const float t) {
+    static_assert(CNT >= 0 && CNT <= 5 && I0 + CNT <= 16, "piece");
+    if constexpr (CNT == 1)
+        asm volatile("s_nop 1\n\t" DKT_FMD(0) : "+v"(x[I0 + 0]) : [t] "v"(t), [p] "n"(P));
+    else if constexpr (CNT == 2)
+        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]) : [t] "v"(t), [p] "n"(P));
+    else if constexpr (CNT == 3)
+        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]) : [t] "v"(t), [p] "n"(P));
+    else if constexpr (CNT == 4)
+        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]) : [t] "v"(t), [p] "n"(P));
+    else if constexpr (CNT == 5)
+        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]), "+v"(x[I0 + 4]) : [t] "v"(t), [p] "n"(P));
 }
 #undef DKT_FMD
 
@@ -155,38 +121,40 @@ __device__ __forceinline__ float pivot_bcast(const float xp) {
     return d;
 }
 
-template <int P>
-__device__ __forceinline__ void sweep_pivot(float (&x)[16], float& dv, const Lane& ln) {
-    float dneg = pivot_bcast<P>(x[P]);                    // -d_P, uniform
+// One pivot: x holds -A.  t = x[P] / d is the update factor of the row (Schur lanes c > P and L^-1 lanes c < P alike); at lane P itself
+// the multiplier column turns into a column of L^-1, x[i] <- x[i] / d = x[i] (1 + t) with t = (1 - d) / d -- no cancellation because
+// the caller scales the matrix by a power of 4 so that every pivot is <= 1.
+// No guard on d: a non-positive pivot turns the matrix into inf / NaN -- it is reported through dv and the caller poisons the
+// outputs anyway -- except the augmented pivot of the last tile (LAST: local index pn, forced to 1; padding pivots are 1 already).
+template <int P, bool LAST>
+__device__ __forceinline__ float sweep_pivot_head(float (&x)[16], float& dv, const Lane& ln, const int pn) {
+    float d = -pivot_bcast<P>(x[P]);                      // d_P, uniform
     const bool eq = ln.c == P;
-    dv = eq ? -dneg : dv;
-    dneg = (dneg < 0.f) ? dneg : -1.0f;
-    const float rs = __builtin_amdgcn_rsqf(-dneg);        // 1 / sqrt(d)
+    dv = eq ? d : dv;
+    if constexpr (LAST) d = (P == pn) ? 1.0f : d;
+    const float rs = __builtin_amdgcn_rsqf(d);            // 1 / sqrt(d)
     const float rs2 = rs * rs;
-    const float t = eq ? (rs2 - 1.0f) : x[P] * rs2;
+    const float t = (eq ? 1.0f - d : x[P]) * rs2;
     x[P] = eq ? rs : x[P] * rs;
-    sweep_rows<P>(x, t);
+    return t;
 }
 
-template <int P>
-__device__ __forceinline__ void sweep_from(float (&x)[16], float& dv, const Lane& ln) {
-    if constexpr (P < 16) {
-        sweep_pivot<P>(x, dv, ln);
-        sweep_from<P + 1>(x, dv, ln);
-    }
-}
-
-// Diagonal tile S (accumulator layout, = -(Schur complement), symmetric) -> M = R^-T (accumulator layout).
-// dv: lane c receives the raw pivot d_c;  x (out): the swept rows (CHOL: -R above the diagonal).
-__device__ __forceinline__ f32x4 sweep_tile(const f32x4 S, float& dv, float (&x)[16], const Lane& ln) {
+// accumulator layout -> replicated column layout
+__device__ __forceinline__ void sweep_begin(const f32x4 S, float (&x)[16], float& dv) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) spread_rows(S[q], x[q], x[4 + q], x[8 + q], x[12 + q]);
     dv = 1.0f;
-    sweep_from<0>(x, dv, ln);
+}
+
+// swept rows -> M = R^-T in the accumulator layout
+__device__ __forceinline__ f32x4 sweep_end(const float (&x)[16], const Lane& ln) {
     f32x4 M;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float v = ln.g0 ? x[q] : (ln.g1 ? x[4 + q] : (ln.g2 ? x[8 + q] : x[12 + q]));
+        // (opaque copies: hipcc otherwise turns the select chain into an indexed load of x[4 g + q] from a scratch copy of x)
+        float r0 = x[q], r1 = x[4 + q], r2 = x[8 + q], r3 = x[12 + q];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        const float v = ln.g0 ? r0 : (ln.g1 ? r1 : (ln.g2 ? r2 : r3));
         M[q] = (ln.c <= 4 * ln.g + q) ? v : 0.f;
     }
     return M;
@@ -206,7 +174,10 @@ struct FormCtx {
     const f32x4* es;         // LDS: the episode's E tiles (raw, accumulator layout), shared by the waves of the episode
     const f32x4* ys;         // LDS: this wave's targets y_c, 16-byte groups
     int pN, c16, g4, lane;
-    float nsv, dg, mc;       // -sv, -(noise + jitter), mean
+    float nsv, dg, mc, rsc;  // -sv / kappa, -(noise + jitter) / kappa, mean, 1 / sqrt(kappa)
+#ifdef DKT_MFMA_CLOCKS
+    unsigned long long* clk2;
+#endif
 };
 
 // Tile (I, J), I <= J, of S = -K' in the accumulator layout, from the staged E tile.  The last block column carries the augmented
@@ -227,14 +198,14 @@ __device__ __forceinline__ f32x4 form_tile(const FormCtx& f) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool rok = (I < NT - 1) || (g4 + q < pN);
-            s[q] = (c16 == pN) ? (rok ? f.mc - yv[q] : 0.f) : s[q];
+            s[q] = (c16 == pN) ? (rok ? (f.mc - yv[q]) * f.rsc : 0.f) : s[q];
         }
         if constexpr (I == NT - 1) {
             const float yc = reinterpret_cast<const float*>(f.ys)[16 * I + c16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = s[q];
-                v = (g4 + q == pN) ? ((c16 < pN) ? f.mc - yc : 0.f) : v;       // mirror row of the augmented column; pivot N = 0
+                v = (g4 + q == pN) ? ((c16 < pN) ? (f.mc - yc) * f.rsc : 0.f) : v;   // mirror row of the augmented column; pivot N = 0
                 v = (g4 + q > pN) ? ((g4 + q == c16) ? -1.0f : 0.f) : v;        // padding: identity
                 s[q] = v;
             }
@@ -251,13 +222,145 @@ __device__ __forceinline__ void form_row0(Tiles<NT>& T, const FormCtx& f) {     
     }
 }
 
-// trailing update of block step 0 with the freshly formed tile as the C operand: S_ij = form(i, j) + R_0i^T R_0j
-template <int NT, int I, int J>
-__device__ __forceinline__ void form_trailing0(Tiles<NT>& T, const FormCtx& f) {
-    if constexpr (I < NT) {
-        T.t[I][J] = xty(T.t[0][I], T.t[0][J], form_tile<NT, I, J>(f));
-        if constexpr (J + 1 < NT) form_trailing0<NT, I, J + 1>(T, f);
-        else form_trailing0<NT, I + 1, I + 1>(T, f);
+// tile row 1 of block step 0's trailing update, the freshly formed tiles as C operands: S_1j = form(1, j) + R_01^T R_0j
+template <int NT, int J>
+__device__ __forceinline__ void form_trailing_row1(Tiles<NT>& T, const FormCtx& f) {
+    if constexpr (J < NT) {
+        T.t[1][J] = xty(T.t[0][1], T.t[0][J], form_tile<NT, 1, J>(f));
+        form_trailing_row1<NT, J + 1>(T, f);
+    }
+}
+
+// two independent X^T Y chains advanced alternately: the dependent-accumulate latency of one hides behind the other
+__device__ __forceinline__ void xty2(const f32x4 xa, const f32x4 ya, f32x4& ca, const f32x4 xb, const f32x4 yb, f32x4& cb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ca = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q], ya[q], ca, 0, 0, 0);
+        cb = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[q], yb[q], cb, 0, 0, 0);
+    }
+}
+
+// Trailing updates of block step K that are NOT needed by the next sweep (tile rows i >= K + 2), u = 0 .. n_pending - 1 in (i, j) order.
+template <int NT, int K> constexpr int n_pending() { return (K >= 0 && NT - K - 2 > 0) ? (NT - K - 2) * (NT - K - 1) / 2 : 0; }
+template <int NT, int K> constexpr int pend_i(int u) { int i = K + 2; while (u >= NT - i) { u -= NT - i; ++i; } return i; }
+template <int NT, int K> constexpr int pend_j(int u) { int i = K + 2; while (u >= NT - i) { u -= NT - i; ++i; } return i + u; }
+
+// The pending updates as a stream of single MFMAs, S = 0 .. n_pend_mfma - 1, ordered so that neighbours belong to different tiles
+// (two tile updates advance alternately: the dependent-accumulate latency of one hides behind the other).
+template <int NT, int K> constexpr int n_pend_mfma() { return 8 * ((n_pending<NT, K>() + 1) / 2); }
+
+template <int NT, int K, int S0, int S1>
+__device__ __forceinline__ void pend_mfma(Tiles<NT>& T, const FormCtx& f) {
+    if constexpr (S0 < S1) {
+        constexpr int u = 2 * (S0 / 8) + (S0 & 1), q = (S0 % 8) >> 1;
+        if constexpr (u < n_pending<NT, K>()) {
+            constexpr int i = pend_i<NT, K>(u), j = pend_j<NT, K>(u);
+            if constexpr (K == 0 && q == 0) T.t[i][j] = form_tile<NT, i, j>(f);              // block step 0 consumes E as it goes
+            T.t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.t[K][i][q], T.t[K][j][q], T.t[i][j], 0, 0, 0);
+        }
+        pend_mfma<NT, K, S0 + 1, S1>(T, f);
+    }
+}
+
+// Slots of the sweep into which the pending MFMAs are dealt: one after every pivot's scalar chain and one after every piece of
+// <= 5 row updates, i.e. about one MFMA (32 cycles of the matrix pipe) per 5-6 VALU instructions (~32 cycles of issue from one wave).
+constexpr int slots_of_pivot(int p) { return 1 + (15 - p + 4) / 5; }
+constexpr int slots_before(int p) { int n = 0; for (int i = 0; i < p; ++i) n += slots_of_pivot(i); return n; }
+constexpr int SWEEP_SLOTS = slots_before(16);
+
+template <int NT, int K, int SLOT>
+__device__ __forceinline__ void run_slot(Tiles<NT>& T, const FormCtx& f) {
+    constexpr int NM = n_pend_mfma<NT, K>();
+    if constexpr (NM > 0) {
+        pend_mfma<NT, K, SLOT * NM / SWEEP_SLOTS, (SLOT + 1) * NM / SWEEP_SLOTS>(T, f);
+        __builtin_amdgcn_sched_barrier(0);                    // pin the MFMA between the VALU pieces
+    }
+}
+
+template <int NT, int K, int P, int I0, int SLOT>
+__device__ __forceinline__ void sweep_rows_slots(Tiles<NT>& T, const FormCtx& f, float (&x)[16], const float t) {
+    if constexpr (I0 < 16) {
+        constexpr int CNT = (16 - I0) < 5 ? (16 - I0) : 5;
+        sweep_rows_piece<P, I0, CNT>(x, t);
+        run_slot<NT, K, SLOT>(T, f);
+        sweep_rows_slots<NT, K, P, I0 + CNT, SLOT + 1>(T, f, x, t);
+    }
+}
+
+// The sweep of diagonal tile K + 1 with block step K's remaining trailing updates dealt over it: their MFMAs run on the matrix
+// pipe underneath the sweep's VALU work of the same wave (K = -1: the very first tile, nothing pending).
+template <int NT, int K, int P, bool LAST>
+__device__ __forceinline__ void sweep_interleaved(Tiles<NT>& T, const FormCtx& f, float (&x)[16], float& dv, const Lane& ln, const int pn) {
+    if constexpr (P < 16) {
+        const float t = sweep_pivot_head<P, LAST>(x, dv, ln, pn);
+#ifdef DKT_MFMA_CLOCKS
+        if constexpr (K == -1) { __builtin_amdgcn_sched_barrier(0); f.clk2[P] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+        run_slot<NT, K, slots_before(P)>(T, f);
+        sweep_rows_slots<NT, K, P, P + 1, slots_before(P) + 1>(T, f, x, t);
+        sweep_interleaved<NT, K, P + 1, LAST>(T, f, x, dv, ln, pn);
+    }
+}
+
+template <bool CHOL>
+struct P1Ctx {
+    f32x4* myst;
+    float* Lmat;             // CHOL: this matrix' L[N, N]
+    float lsc;               // CHOL: sqrt(kappa), L = L_s sqrt(kappa)
+    f32x4 negI;
+    int lane, c16, pN, N;
+    int fail_at;
+    float lsum, quad;
+#ifdef DKT_MFMA_CLOCKS
+    unsigned long long* clk;
+#endif
+};
+
+// Block step K of the factorisation; x / dv hold the swept diagonal tile K on entry.
+template <int NT, int K, bool CHOL>
+__device__ __forceinline__ void phase1_step(Tiles<NT>& T, const FormCtx& f, P1Ctx<CHOL>& c, float (&x)[16], float& dv, const Lane& ln) {
+    if constexpr (K < NT) {
+#ifdef DKT_MFMA_CLOCKS
+        __builtin_amdgcn_sched_barrier(0);
+        c.clk[13 + 2 * K] = __builtin_amdgcn_s_memtime();          // sweep K done
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const f32x4 M = sweep_end(x, ln);
+        const bool valid = (K < NT - 1) || (c.c16 < c.pN);
+        const unsigned long long badm = __ballot(valid && !(dv > 0.f)) & 0xffffull;
+        const int first = (int)__builtin_ctzll(badm | 0x10000ull);
+        c.fail_at = (c.fail_at == 0 && badm != 0) ? 16 * K + first + 1 : c.fail_at;
+        c.lsum += (valid && ln.g0) ? __builtin_amdgcn_logf(dv) : 0.f;              // log2
+        if constexpr (K == NT - 1) c.quad = -__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), c.pN));
+        c.myst[K * 64 + c.lane] = M;
+        if constexpr (CHOL) {
+            // L[16K + c][16K + i] = R_KK[i][c] = -x[i] (i < c), 1 / M_KK[c][c] on the diagonal, zero above it
+            if (ln.g0 && valid) {
+                float* Lrow = c.Lmat + (size_t)(16 * K + c.c16) * c.N + 16 * K;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (16 * K + i < c.N) Lrow[i] = (i < c.c16) ? -x[i] * c.lsc : ((i == c.c16) ? c.lsc / x[i] : 0.f);
+            }
+        }
+        if constexpr (K + 1 < NT) {
+            const f32x4 nV = xty0(M, c.negI);                                        // M^T (-I) = -V_KK
+#pragma unroll
+            for (int j = K + 1; j < NT; ++j) T.t[K][j] = xty0(nV, T.t[K][j]);        // panel: R_Kj
+            // tile row K + 1 first: the next sweep and the next panel need it
+            if constexpr (K == 0) form_trailing_row1<NT, 1>(T, f);
+            else {
+#pragma unroll
+                for (int j = K + 1; j < NT; ++j) T.t[K + 1][j] = xty(T.t[K][K + 1], T.t[K][j], T.t[K + 1][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef DKT_MFMA_CLOCKS
+            c.clk[14 + 2 * K] = __builtin_amdgcn_s_memtime();      // panel + tile row K + 1 issued
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            sweep_begin(T.t[K + 1][K + 1], x, dv);
+            sweep_interleaved<NT, K, 0, K + 1 == NT - 1>(T, f, x, dv, ln, c.pN);
+            phase1_step<NT, K + 1, CHOL>(T, f, c, x, dv, ln);
+        }
     }
 }
 
@@ -325,7 +428,8 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
     const int nrounds = (C + wpg - 1) / wpg;
 
 #ifdef DKT_MFMA_CLOCKS
-    unsigned long long clk[12] = {};
+    unsigned long long clk[32] = {};
+    unsigned long long clk2[16] = {};
 #endif
     DKT_CLK(0);
     for (int round = 0; round < nrounds; ++round) {
@@ -359,68 +463,56 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
             const size_t bc = (size_t)b * C + c;
             FormCtx f;
             f.es = stage; f.ys = myys;
-            f.pN = pN; f.c16 = c16; f.g4 = g4; f.lane = lane; f.nsv = -svc; f.mc = mc;
+#ifdef DKT_MFMA_CLOCKS
+            f.clk2 = clk2;
+#endif
+            f.pN = pN; f.c16 = c16; f.g4 = g4; f.lane = lane; f.mc = mc;
+            // Scale by kappa = 4^m >= max_i K_ii (exact in fp32): every pivot of K / kappa is <= 1, which the sweep's update at the
+            // pivot lane relies on.  With r / 2^m in the augmented column, w and the quadratic form are unchanged;
+            // alpha = alpha_s / 2^m, K^-1 - alpha alpha^T = (.)_s / kappa, log det K = log det K_s + N log kappa.
+            float emax = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 e = stage[tidx(j, j) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) emax = fmaxf(emax, (g4 + q == c16) ? e[q] : 0.f);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) emax = fmaxf(emax, __shfl_xor(emax, o, DKT_WAVE));
             int fail_at = 0;
             float jit = 0.f, lsum = 0.f, quad = 0.f;
+            int msc = 0;
             for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
                 jit = 0.f;
                 if (attempt > 0) {
                     jit = a.jitter0;
                     for (int i = 1; i < attempt; ++i) jit *= 10.f;
                 }
-                f.dg = -(nzc + jit);
-                fail_at = 0;
-                lsum = 0.f;
+                int ex;
+                (void)frexpf(fmaf(svc, emax, nzc + jit), &ex);                 // max K_ii = f 2^ex, 0.5 <= f < 1
+                msc = max(0, (ex + 1) >> 1);
+                const float ikap = ldexpf(1.0f, -2 * msc);                      // 1 / kappa
+                f.nsv = -svc * ikap;
+                f.dg = -(nzc + jit) * ikap;
+                f.rsc = ldexpf(1.0f, -msc);
                 form_row0<NT, 0, 0>(T, f);
-                // ---- phase 1: factorisation (block step 0 consumes the rest of E as it is read) ----
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
+                // ---- phase 1: factorisation.  The sweep of tile k + 1 runs ahead, interleaved with step k's remaining updates ----
+                P1Ctx<CHOL> pc;
+                pc.myst = myst; pc.Lmat = CHOL ? a.L + bc * N * N : nullptr; pc.lsc = ldexpf(1.0f, msc); pc.negI = negI;
+                pc.lane = lane; pc.c16 = c16; pc.pN = pN; pc.N = N;
+                pc.fail_at = 0; pc.lsum = 0.f; pc.quad = 0.f;
+#ifdef DKT_MFMA_CLOCKS
+                pc.clk = clk;
+                clk[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, bits 0..31
+                clk[12] = __builtin_amdgcn_s_memtime();
+#endif
+                {
                     float dv, x[16];
-                    __builtin_amdgcn_sched_barrier(0);       // keep block step k-1's updates above and step k's loads / MFMAs below the sweep
-#ifdef DKT_MFMA_CLOCKS
-                    const unsigned long long tsw0 = __builtin_amdgcn_s_memtime();
-#endif
-                    const f32x4 M = sweep_tile(T.t[k][k], dv, x, ln);
-                    __builtin_amdgcn_sched_barrier(0);
-#ifdef DKT_MFMA_CLOCKS
-                    {
-                        const unsigned long long tsw1 = __builtin_amdgcn_s_memtime();
-                        clk[9] += tsw1 - tsw0;                      // all sweeps
-                        if (k == 0) clk[10] = tsw1 - tsw0;
-                        if (k == NT - 1) clk[11] = tsw1 - tsw0;
-                    }
-#endif
-                    const bool valid = (k < NT - 1) || (c16 < pN);
-                    const unsigned long long badm = __ballot(valid && !(dv > 0.f)) & 0xffffull;
-                    const int first = (int)__builtin_ctzll(badm | 0x10000ull);
-                    fail_at = (fail_at == 0 && badm != 0) ? 16 * k + first + 1 : fail_at;
-                    lsum += (valid && ln.g0) ? __builtin_amdgcn_logf(dv) : 0.f;          // log2
-                    if (k == NT - 1) quad = -__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), pN));
-                    myst[k * 64 + lane] = M;
-                    if constexpr (CHOL) {
-                        // L[16k + c][16k + i] = R_kk[i][c] = -x[i] (i < c), 1 / M_kk[c][c] on the diagonal, zero above it
-                        if (ln.g0 && valid) {
-                            float* Lrow = a.L + bc * N * N + (size_t)(16 * k + c16) * N + 16 * k;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i)
-                                if (16 * k + i < N) Lrow[i] = (i < c16) ? -x[i] : ((i == c16) ? 1.0f / x[i] : 0.f);
-                        }
-                    }
-                    if (k + 1 < NT) {
-                        const f32x4 nV = xty0(M, negI);                                  // M^T (-I) = -V_kk
-#pragma unroll
-                        for (int j = k + 1; j < NT; ++j) T.t[k][j] = xty0(nV, T.t[k][j]);
-                        if (k == 0) {
-                            form_trailing0<NT, 1, 1>(T, f);
-                        } else {
-#pragma unroll
-                            for (int i = k + 1; i < NT; ++i) {
-#pragma unroll
-                                for (int j = i; j < NT; ++j) T.t[i][j] = xty(T.t[k][i], T.t[k][j], T.t[i][j]);
-                            }
-                        }
-                    }
+                    sweep_begin(T.t[0][0], x, dv);
+                    sweep_interleaved<NT, -1, 0, NT == 1>(T, f, x, dv, ln, pN);
+                    phase1_step<NT, 0, CHOL>(T, f, pc, x, dv, ln);
                 }
+                fail_at = pc.fail_at; lsum = pc.lsum; quad = pc.quad;
                 if (fail_at == 0) break;
             }
             DKT_CLK(2);
@@ -432,7 +524,7 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                     const bool row_ok = (j < NT - 1) || (c16 < pN);
 #pragma unroll
                     for (int k = 0; k < j; ++k) {
-                        bstore4(Lr, T.t[k][j], row_ok ? ((16 * j + c16) * N + 16 * k + g4) * 4 : OOB, 0);
+                        bstore4(Lr, T.t[k][j] * ldexpf(1.0f, msc), row_ok ? ((16 * j + c16) * N + 16 * k + g4) * 4 : OOB, 0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const bool ok = (j < NT - 1) || (g4 + q < pN);
@@ -441,17 +533,29 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                     }
                 }
             }
-            // ---- phase 2: M = R^-T; M_ji (j > i) overwrites slot (i, j) ----
+            // ---- phase 2: M = R^-T; M_ji (j > i) overwrites slot (i, j); two rows i at a time (independent MFMA chains) ----
 #pragma unroll
             for (int j = 1; j < NT; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4 nV = xty0(myst[j * 64 + lane], negI);
 #pragma unroll
-                for (int i = 0; i < j; ++i) {
-                    f32x4 Q = xty0(T.t[i][j], myst[i * 64 + lane]);
+                for (int i = 0; i < j; i += 2) {
+                    if (i + 1 < j) {
+                        f32x4 QA = xty0(T.t[i][j], myst[i * 64 + lane]);                 // k = i
+                        f32x4 QB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = i + 1; k < j; ++k) Q = xty(T.t[k][j], T.t[i][k], Q);
-                    T.t[i][j] = xty0(nV, Q);
+                        for (int k = i + 1; k < j; ++k)
+                            xty2(T.t[k][j], T.t[i][k], QA, T.t[k][j], (k == i + 1) ? myst[k * 64 + lane] : T.t[i + 1][k], QB);
+                        f32x4 RA = {0.f, 0.f, 0.f, 0.f}, RB = {0.f, 0.f, 0.f, 0.f};
+                        xty2(nV, QA, RA, nV, QB, RB);
+                        T.t[i][j] = RA;
+                        T.t[i + 1][j] = RB;
+                    } else {
+                        f32x4 Q = xty0(T.t[i][j], myst[i * 64 + lane]);
+#pragma unroll
+                        for (int k = i + 1; k < j; ++k) Q = xty(T.t[k][j], T.t[i][k], Q);
+                        T.t[i][j] = xty0(nV, Q);
+                    }
                 }
             }
             DKT_CLK(3);
@@ -464,7 +568,7 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const f32x4 m = (i < NT - 1) ? T.t[i][NT - 1] : myst[(NT - 1) * 64 + lane];
-                    const float v = -(qn == 0 ? m[0] : qn == 1 ? m[1] : qn == 2 ? m[2] : m[3]);
+                    const float v = -(qn == 0 ? m[0] : qn == 1 ? m[1] : qn == 2 ? m[2] : m[3]) * f.rsc;
                     const bool ok = arow && ((i < NT - 1) || (c16 < pN));
                     bstore1(ar, (fail_at != 0) ? qnan : v, ok ? (16 * i + c16) * 4 : OOB, 0);
                     asum += ok ? v : 0.f;
@@ -480,32 +584,45 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     __builtin_amdgcn_sched_barrier(0);
+                    // i = 0 .. j-1 in pairs, then the diagonal (whose LDS slot the others still read) last
 #pragma unroll
-                    for (int i = 0; i <= j; ++i) {           // i = 0 .. j-1, then the diagonal (which the others still read) last
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i <= j; i += 2) {
+                        const bool pair = i + 1 <= j;
+                        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int k = j; k < NT; ++k) {
-                            f32x4 A = (k == i) ? myst[k * 64 + lane] : T.t[i][k];
                             const f32x4 Bm = (k == j) ? myst[k * 64 + lane] : T.t[j][k];
-                            if (k == NT - 1) A = A * sgn;
-                            acc = xty(A, Bm, acc);
-                        }
-                        if (i < j) {
-                            T.t[i][j] = acc;
-                        } else {
-                            // diagonal tile: M_jj is dead now, P''_jj takes its place in LDS; trace over the real rows
-                            myst[j * 64 + lane] = acc;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const bool ok = (g4 + q == c16) && ((j < NT - 1) || (c16 < pN));
-                                trpp += ok ? acc[q] : 0.f;
+                            f32x4 A0 = (k == i) ? myst[k * 64 + lane] : T.t[i][k];
+                            if (k == NT - 1) A0 = A0 * sgn;
+                            if (pair) {
+                                f32x4 A1 = (k == i + 1) ? myst[k * 64 + lane] : T.t[i + 1][k];
+                                if (k == NT - 1) A1 = A1 * sgn;
+                                xty2(A0, Bm, accA, A1, Bm, accB);
+                            } else {
+                                accA = xty(A0, Bm, accA);
                             }
                         }
+                        auto put = [&](const f32x4 acc, const int ii) {
+                            if (ii < j) {
+                                T.t[ii][j] = acc;
+                            } else {
+                                // diagonal tile: M_jj is dead now, P''_jj takes its place in LDS; trace over the real rows
+                                myst[j * 64 + lane] = acc;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const bool ok = (g4 + q == c16) && ((j < NT - 1) || (c16 < pN));
+                                    trpp += ok ? acc[q] : 0.f;
+                                }
+                            }
+                        };
+                        put(accA, i);
+                        if (pair) put(accB, i + 1);
                     }
                 }
             }
             DKT_CLK(5);
-            lsum = wave_allsum(lsum);
+            lsum = wave_allsum(lsum) + (float)(2 * msc * N);            // log2 det K = log2 det K_s + N log2 kappa
+            trpp *= ldexpf(1.0f, -2 * msc);
             asum = wave_allsum(asum);
             trpp = wave_allsum(trpp);
             if (lane == 0) {
@@ -527,7 +644,7 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                 }
             }
             const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
-            coef = (fail_at == 0) ? -0.5f * cw * svc : qnan;         // W_c = coef P''   (a failed class poisons W[b])
+            coef = (fail_at == 0) ? -0.5f * cw * svc * ldexpf(1.0f, -2 * msc) : qnan;   // W_c = coef P''_s   (a failed class poisons W[b])
         }
         DKT_CLK(6);
         if constexpr (GRAD) {
@@ -627,8 +744,9 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
 #ifdef DKT_MFMA_CLOCKS
     DKT_CLK(8);
     if (ln.lane == 0 && a.ws) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + ((size_t)blockIdx.x * (MFMA_MAX_WPG * EPW) + wall) * 12;
-        for (int i = 0; i < 12; ++i) o[i] = clk[i];
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + ((size_t)blockIdx.x * (MFMA_MAX_WPG * EPW) + wall) * 48;
+        for (int i = 0; i < 32; ++i) o[i] = clk[i];
+        for (int i = 0; i < 16; ++i) o[32 + i] = clk2[i];
     }
 #endif
 }

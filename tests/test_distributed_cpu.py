@@ -90,3 +90,20 @@ def test_shard_episodes_partitions():
         parts = [list(dkt_amd.distributed.shard_episodes(n, r, w)) for r in range(w)]
         assert sum(parts, []) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_bench_spawns_its_own_ranks_and_reduces_the_config_sized_bucket():
+    """`bench.py --gpus 2` without a launcher spawns one process per rank itself; the step's one collective carries the
+    config's backbone + bn_out bucket plus the 2C hyper-parameter gradients (cfg2: 116 288 + 10 floats).  CPU / gloo selftest
+    of that plumbing -- the kernels themselves need the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-collective"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"selftest": True, "n_gpus": 2, "bucket_floats": 116288 + 10, "valid": True}

@@ -367,6 +367,44 @@ def test_mll_mfma_kernel_against_register_twin(cuda, c, per, d, corr):
     assert rel_l2(a["w"].cpu().numpy(), g["w"].cpu().numpy()) < 2e-6 and rel_l2(a["chol"].cpu().numpy(), ch["chol"].cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("scale", [1.0, 90.0, 3e-3, 4100.0])
+def test_mll_large_and_small_magnitude_base_matrices(cuda, scale):
+    """Polynomial / un-normalised linear kernels hand the marginal-likelihood kernel base matrices whose diagonal is far from 1
+    (DKT.py:352-365).  The MFMA kernel factors K / 4^m with every pivot <= 1 (exact power-of-two scaling): log-likelihood,
+    alpha, the Cholesky factor and all gradients must stay at fp32 accuracy for any magnitude.  At scale 4100 the condition
+    number (~4e6) is beyond what an fp32 factorisation resolves to 1e-4 (the register-sweep twin measures 5e-3 on the gradient
+    scalars there, this kernel 7e-2: both form the inverse factor explicitly): only finiteness and a 1e-2 bound on the
+    log-likelihood are required."""
+    c, per, d = 5, 12, 24
+    z, hyp, n = _episode_case(c, per, d, 91, 3, b=2)
+    y = O.one_vs_rest_targets(c, per)
+    cw = np.full(c, -1.0 / (c * n))
+    e64 = np.stack([scale * (O.gram_linear(z[i]) + 0.3) for i in range(2)])
+    args = (dev_t(e64, cuda), dev_t(y, cuda), dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda))
+    out = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda))
+    twin = ops.mll(*args, want_grad=True, want_chol=True, cls_weight=dev_t(cw, cuda), force_reg=True)
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().max().item()) == 0
+    hard = scale > 1000.0
+    for i in range(2):
+        e = e64[i].astype(np.float32).astype(np.float64)
+        res = O.mll_terms(e, y, hyp.outputscale, hyp.mean, hyp.noise)
+        w_ref, _, _, _ = O.mll_grads(e, res, hyp.outputscale, hyp.noise, cw)
+        _, dsv1, dmean1, dnoise1 = O.mll_grads(e, res, hyp.outputscale, hyp.noise, np.ones(c))
+        errs = {}
+        for name, o in (("mfma", out), ("reg", twin)):
+            errs[name] = dict(logp=np.abs((o["logp"][i].cpu().numpy() - res.logp) / res.logp).max(),
+                              alpha=rel_l2(o["alpha"][i].cpu().numpy(), res.alpha), chol=rel_l2(o["chol"][i].cpu().numpy(), res.chol),
+                              w=rel_l2(o["w"][i].cpu().numpy(), w_ref), dsv=rel_l2(o["dsv"][i].cpu().numpy(), dsv1),
+                              dmean=rel_l2(o["dmean"][i].cpu().numpy(), dmean1), dnoise=rel_l2(o["dnoise"][i].cpu().numpy(), dnoise1))
+        tol = dict(logp=MLL_RTOL, alpha=5e-4, chol=5e-5, w=GRAD_RTOL, dsv=GRAD_RTOL, dmean=GRAD_RTOL, dnoise=GRAD_RTOL)
+        if hard:
+            assert errs["mfma"]["logp"] < 1e-2 and all(np.isfinite(v) for v in errs["mfma"].values()), errs
+            continue
+        for k, t in tol.items():
+            assert errs["mfma"][k] < t, (k, errs["mfma"][k], errs["reg"][k])
+
+
 def n_hash(*a):
     return int(sum((i + 1) * v for i, v in enumerate(a)))
 

@@ -54,20 +54,23 @@ def to_columns(S):
     return np.stack([T[i, Cc] for i in range(16)])
 
 
-def sweep(S):
+def sweep(S, pn=None):
     """Diagonal tile: S = -(Schur complement) in accumulator layout -> M = R^-T (acc layout), dv (lane c: raw pivot d_c).
-    ONE register per row: lanes c > p of row i hold the (negated) Schur part, lanes c <= p the rows of L^-1 being built.
-    A non-positive pivot is replaced by 1 (augmented row, failed matrices); the padding pivots are 1 by construction."""
+    ONE register per row: lanes c > p of row i hold the (negated) Schur part, lanes c <= p the rows of L^-1 being built;
+    both obey x[i] += bcast_p(x[i]) * t with t = x[p] / d, except lane p itself, where the multiplier column turns into a column
+    of L^-1: t = 1 / d - 1 = (1 - d) / d (no cancellation: the caller scales the matrix so that every pivot is <= 1).
+    pn (last tile only): local index of the augmented pivot, which is forced to 1; the padding pivots are 1 by construction."""
     x = to_columns(S)
     dv = np.ones(64)
     for p in range(16):
-        dneg = bcast(x[p], p)               # = -d
+        d = -bcast(x[p], p)
         eq = Cc == p
-        dv = np.where(eq, -dneg, dv)
-        dneg = np.where(dneg < 0, dneg, -1.0)
-        rs = 1.0 / np.sqrt(-dneg)
+        dv = np.where(eq, d, dv)
+        if pn is not None and p == pn:
+            d = np.ones(64)
+        rs = 1.0 / np.sqrt(d)
         rs2 = rs * rs
-        t = np.where(eq, rs2 - 1.0, x[p] * rs2)
+        t = np.where(eq, (1.0 - d) * rs2, x[p] * rs2)
         x[p] = np.where(eq, rs, x[p] * rs)
         for i in range(p + 1, 16):
             x[i] = x[i] + bcast(x[i], p) * t
@@ -83,10 +86,14 @@ def run(N, K, rvec):
     NT = (N + 1 + 15) // 16
     NP = 16 * NT
     pN = N - 16 * (NT - 1)
+    # power-of-4 scaling: pivots <= 1 (K / kappa, r / sqrt(kappa): w, the quadratic form and the signs are unchanged)
+    e = int(np.frexp(np.diag(K).max())[1])
+    m = max(0, (e + 1) // 2)
+    kappa = 4.0 ** m
     Sfull = np.zeros((NP, NP))
-    Sfull[:N, :N] = -K
-    Sfull[:N, N] = -rvec
-    Sfull[N, :N] = -rvec
+    Sfull[:N, :N] = -K / kappa
+    Sfull[:N, N] = -rvec / 2.0 ** m
+    Sfull[N, :N] = -rvec / 2.0 ** m
     for p in range(N + 1, NP):
         Sfull[p, p] = -1.0
     tile = lambda i, j: tile_to_acc(Sfull[16 * i:16 * i + 16, 16 * j:16 * j + 16])
@@ -98,7 +105,7 @@ def run(N, K, rvec):
     # ---- phase 1: K' = R^T R, tiles hold S = -(Schur) until they become R ----
     for k in range(NT):
         last = k == NT - 1
-        M, dv, _ = sweep(T[(k, k)])
+        M, dv, _ = sweep(T[(k, k)], pN if last else None)
         Md[k] = M
         valid = (16 * k + Cc) < N
         logdet += np.sum(np.log(dv[:16])[valid[:16]])
@@ -146,7 +153,7 @@ def run(N, K, rvec):
         for i in range(j):
             P[16 * i:16 * i + 16, 16 * j:16 * j + 16] = acc_to_tile(T[(i, j)])
             P[16 * j:16 * j + 16, 16 * i:16 * i + 16] = acc_to_tile(T[(i, j)]).T
-    return logdet, quad, alpha, P[:N, :N]
+    return logdet + N * np.log(kappa), quad, alpha / 2.0 ** m, P[:N, :N] / kappa
 
 
 def main():
@@ -154,7 +161,7 @@ def main():
     for N in (5, 15, 16, 19, 25, 31, 85, 105, 111, 112, 127):
         Z = rng.standard_normal((N, 40))
         Z /= np.linalg.norm(Z, axis=1, keepdims=True)
-        K = 0.7 * Z @ Z.T + 0.1 * np.eye(N)
+        K = (0.7 * Z @ Z.T + 0.1 * np.eye(N)) * (37.0 if N % 2 else 1.0)
         r = rng.standard_normal(N)
         logdet, quad, alpha, P = run(N, K, r)
         Ki = np.linalg.inv(K)

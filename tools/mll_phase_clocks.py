@@ -19,18 +19,20 @@ from dkt_amd import ops  # noqa: E402
 
 lib = dkt_amd._lib.load()
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-c, n, d = 5, 105, 64
+c = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+n, d = (105 // c) * c if c > 1 else 105, 64
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=dev), dim=2).contiguous()
 e = ops.gram(z)
-cls = torch.arange(c, device=dev).repeat_interleave(n // c)
+cls = torch.arange(c, device=dev).repeat_interleave(n // c)[:n]
 y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
 sv = torch.full((c,), 0.7, device=dev) + 0.02 * torch.arange(c, device=dev)
 mean, noise = torch.zeros(c, device=dev), torch.full((c,), 0.1, device=dev)
 cw = torch.full((c,), -1.0 / (c * n), device=dev)
 nwg = (b + 1) // 2
-ws = torch.zeros(nwg * 10 * 12, dtype=torch.int64, device=dev)
+ws = torch.zeros(nwg * 10 * 48, dtype=torch.int64, device=dev)
+wpg = c if c <= 5 else 5
 outs = dict(logp=torch.empty(b, c, device=dev), alpha=torch.empty(b, c, n, device=dev), jit=torch.empty(b, c, device=dev),
             info=torch.empty(b, c, dtype=torch.int32, device=dev), w=torch.empty(b, n, n, device=dev), dsv=torch.empty(b, c, device=dev),
             dmean=torch.empty(b, c, device=dev), dnoise=torch.empty(b, c, device=dev))
@@ -41,16 +43,31 @@ for it in range(3):
                          ws.numel() * 8, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0
 torch.cuda.synchronize()
-t = ws.cpu().numpy().reshape(nwg, 10, 12).astype(np.float64)
+raw = ws.cpu().numpy().reshape(nwg, 10, 48)[:, :2 * wpg, :]
+t = raw.astype(np.float64)
 names = ["start->row0 issued", "phase 1 (factorisation)", "phase 2 (inverse)", "alpha", "phase 3 (M^T M)", "reductions + scalars",
          "LDS accumulate (turns + barriers)", "store W"]
 dt = np.diff(t[:, :, :9], axis=2)
+print("C = %d, N = %d" % (c, n))
 print("waves %d; mean / p10 / p90 shader clocks per phase (s_memtime ticks = 100 MHz constant clock? see total)" % (nwg * 10))
 for i, nm in enumerate(names):
     v = dt[:, :, i].ravel()
     print("%-36s mean %9.0f   p10 %9.0f   p90 %9.0f" % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 90)))
-for i, nm in ((9, "  of phase 1: all 7 sweeps"), (10, "  first sweep (waits for E)"), (11, "  last sweep")):
-    v = t[:, :, i].ravel()
-    print("%-36s mean %9.0f   p10 %9.0f   p90 %9.0f" % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 90)))
+# phase 1 in detail, grouped by how many waves of the workgroup share the wave's SIMD (HW_ID bits 5:4)
+simd = (raw[:, :, 9] >> 4) & 3
+nt = (n + 1 + 15) // 16
+share = np.zeros_like(simd)
+for wg in range(nwg):
+    cnt = np.bincount(simd[wg], minlength=4)
+    share[wg] = cnt[simd[wg]]
+for sh in sorted(set(share.ravel().tolist())):
+    m = share == sh
+    sw = [(t[:, :, 13] - t[:, :, 12])[m].mean()] + [(t[:, :, 13 + 2 * k] - t[:, :, 12 + 2 * k])[m].mean() for k in range(1, nt)]
+    bu = [(t[:, :, 14 + 2 * k] - t[:, :, 13 + 2 * k])[m].mean() for k in range(nt - 1)]
+    print("waves sharing their SIMD with %d of the workgroup: %d   phase 1 mean %.0f" % (sh, m.sum(), (t[:, :, 2] - t[:, :, 1])[m].mean()))
+    print("   sweeps (k = 0 plain; k >= 1 interleaved with step k-1's updates): " + " ".join("%.0f" % v for v in sw))
+    print("   panel + next tile row bursts:                                     " + " ".join("%.0f" % v for v in bu))
+    pv = [(t[:, :, 32] - t[:, :, 12])[m].mean()] + [(t[:, :, 32 + q] - t[:, :, 31 + q])[m].mean() for q in range(1, 16)]
+    print("   sweep 0 by pivot (first: P1 start -> pivot 0's head done):         " + " ".join("%.0f" % v for v in pv))
 tot = (t[:, :, 8] - t[:, :, 0]).ravel()
 print("%-36s mean %9.0f   p10 %9.0f   p90 %9.0f" % ("wave total", tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
