@@ -420,9 +420,6 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
     f32x4* const stage = stage_all[epl];
     f32x4* const myst = mst[wall];
     f32x4* const myys = yst[wall];
-    Lane ln;
-    ln.lane = tid & 63; ln.g = ln.lane >> 4; ln.c = ln.lane & 15;
-    ln.g0 = ln.g == 0; ln.g1 = ln.g == 1; ln.g2 = ln.g == 2;
     const int C = a.C;
     const float qnan = __int_as_float(0x7fc00000);
     const int nrounds = (C + wpg - 1) / wpg;
@@ -435,8 +432,11 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
     for (int round = 0; round < nrounds; ++round) {
         // lane coordinates and sizes made opaque per round: keeps the compiler from hoisting (and then spilling) every mask and
         // address of the round body into the kernel prologue
-        int c16 = ln.c, g4 = 4 * ln.g, lane = ln.lane, N = a.N;
+        int c16 = tid & 15, g4 = (tid >> 2) & 12, lane = tid & 63, N = a.N;
         DKT_OPAQUE_V(c16); DKT_OPAQUE_V(g4); DKT_OPAQUE_V(lane); DKT_OPAQUE_S(N);
+        Lane ln;
+        ln.lane = lane; ln.g = g4 >> 2; ln.c = c16;
+        ln.g0 = ln.g == 0; ln.g1 = ln.g == 1; ln.g2 = ln.g == 2;
         const int pN = N - 16 * (NT - 1);                        // local index of the augmented row / column in the last tile
         const int c = round * wpg + w;
         const bool active = ep_ok && c < C;
@@ -534,10 +534,16 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                 }
             }
             // ---- phase 2: M = R^-T; M_ji (j > i) overwrites slot (i, j); two rows i at a time (independent MFMA chains) ----
+            // (lane coordinates opaque again: what the later phases derive from them is recomputed here instead of being kept
+            // alive -- spilled -- across the factorisation)
+            DKT_OPAQUE_V(c16); DKT_OPAQUE_V(g4); DKT_OPAQUE_V(lane);
+            f32x4 negI2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) negI2[q] = (g4 + q == c16) ? -1.0f : 0.0f;
 #pragma unroll
             for (int j = 1; j < NT; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x4 nV = xty0(myst[j * 64 + lane], negI);
+                const f32x4 nV = xty0(myst[j * 64 + lane], negI2);
 #pragma unroll
                 for (int i = 0; i < j; i += 2) {
                     if (i + 1 < j) {
@@ -743,7 +749,7 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
     DKT_CLK(7);
 #ifdef DKT_MFMA_CLOCKS
     DKT_CLK(8);
-    if (ln.lane == 0 && a.ws) {
+    if ((tid & 63) == 0 && a.ws) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + ((size_t)blockIdx.x * (MFMA_MAX_WPG * EPW) + wall) * 48;
         for (int i = 0; i < 32; ++i) o[i] = clk[i];
         for (int i = 0; i < 16; ++i) o[32 + i] = clk2[i];

@@ -73,10 +73,18 @@ class GradBucket:
             self._flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
         return self._flat
 
-    def allreduce_mean(self) -> None:
+    def allreduce_mean(self, flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Average the gradients over the ranks.  `flag` (a 0-dim / 1-element tensor, e.g. max |info| of the step) rides in the
+        same collective and comes back SUMMED over the ranks, so that every rank learns about a failure on any rank in the
+        same step (and raises together instead of leaving the others blocked in the next collective)."""
         if not is_distributed() or not self.params:
-            return
+            return flag
         flat = self._buffer()
+        if flag is not None:
+            if self._flat.numel() != self.numel + 1:
+                self._flat = torch.zeros(self.numel + 1, device=self.params[0].device, dtype=torch.float32)
+                flat = self._flat
+            flat[self.numel] = flag.reshape(-1)[0].to(torch.float32)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -86,6 +94,7 @@ class GradBucket:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        out_flag = flat[self.numel].clone() if flag is not None else None
         flat.div_(dist.get_world_size())
         off = 0
         for p in self.params:
@@ -95,6 +104,7 @@ class GradBucket:
             else:
                 p.grad.copy_(flat[off:off + n].reshape(p.shape))
             off += n
+        return out_flag
 
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
@@ -132,3 +142,23 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+def average_module_buffers(module: torch.nn.Module) -> None:
+    """Mean over ranks of every floating-point buffer (BatchNorm running_mean / running_var), one flat all-reduce; integer
+    buffers (num_batches_tracked) take rank 0's value.  No-op outside torch.distributed."""
+    if not is_distributed():
+        return
+    fl = [b for b in module.buffers() if b.is_floating_point()]
+    if fl:
+        flat = torch.cat([b.detach().reshape(-1).to(torch.float32) for b in fl])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        off = 0
+        for b in fl:
+            n = b.numel()
+            b.data.copy_(flat[off:off + n].reshape(b.shape))
+            off += n
+    for b in module.buffers():
+        if not b.is_floating_point():
+            dist.broadcast(b.data, src=0)

@@ -70,6 +70,25 @@ class _FusableBatchNorm1d(nn.BatchNorm1d):
         return x if self.bypass else super().forward(x)
 
 
+class _MetaBatched:
+    """Groups `nb` consecutive episodes of an episodic loader into one item x:[nb, C, S+Q, ch, H, W] (a short tail is dropped)."""
+
+    def __init__(self, loader, nb):
+        self.loader, self.nb = loader, nb
+
+    def __len__(self):
+        return len(self.loader) // self.nb
+
+    def __iter__(self):
+        xs, ys = [], []
+        for x, y in self.loader:
+            xs.append(x)
+            ys.append(y)
+            if len(xs) == self.nb:
+                yield torch.stack(xs, 0), ys
+                xs, ys = [], []
+
+
 class DKT(MetaTemplate):
     def __init__(self, model_func, n_way, n_support, kernel_type=None):
         super(DKT, self).__init__(model_func, n_way, n_support)
@@ -107,6 +126,24 @@ class DKT(MetaTemplate):
         self.likelihood = _LikelihoodView(self.model)
         self.mll = _MllView(self)
         return self.model, self.likelihood, self.mll
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts this module's own state dict AND one written by the reference's DKT (train.py:61,65: {'epoch', 'state'} with
+        the GPyTorch module tree `model.models.{c}.*`, `likelihood.likelihoods.{c}.*`, `mll.*` next to `feature.*` /
+        `feature_extractor.*`): the backbone tensors load by name, the GP hyper-parameters of every class through
+        ExactGPHypers.load_reference_state_dict."""
+        if not ExactGPHypers.is_reference_state_dict(state_dict):
+            return super().load_state_dict(state_dict, strict=strict)
+        for prefix in ("feature_extractor.", "feature."):
+            fe = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+            if fe:
+                res = self.feature_extractor.load_state_dict(fe, strict=strict)
+                break
+        else:
+            raise RuntimeError("reference state dict without feature_extractor.* / feature.* tensors")
+        if self.model.load_reference_state_dict(state_dict) == 0:
+            raise RuntimeError("reference state dict without model.models.{c}.* hyper-parameters")
+        return res
 
     def set_forward(self, x, is_feature=False):
         pass
@@ -162,11 +199,12 @@ class DKT(MetaTemplate):
                 and os.environ.get("DKT_FUSED_FRONTEND", "1") != "0")
 
     def _episode_loss_from_trunk(self, x_feat, y, want_z=True):
-        """Training loss of ONE episode from the trunk output x_feat:[N,D]; bn_out runs in train mode (batch statistics of
-        the episode, running estimates updated exactly as nn.BatchNorm1d does) inside the fused kernels.
-        Returns (loss, aux, z_train) with z_train the normalised train-mode features (detached) the in-loop evaluation
-        conditions on (DKT.py:170-192)."""
-        xb = x_feat.unsqueeze(0).contiguous()
+        """Training loss of ONE episode from the trunk output x_feat:[N,D] (or the mean over a meta-batch [B,N,D]); bn_out runs
+        in train mode (batch statistics of EACH episode, running estimates updated exactly as nn.BatchNorm1d would after seeing
+        the episodes one by one) inside the fused kernels.
+        Returns (loss, aux, z_train) with z_train the normalised train-mode features (detached) of the first episode, which
+        the in-loop evaluation conditions on (DKT.py:170-192)."""
+        xb = (x_feat if x_feat.dim() == 3 else x_feat.unsqueeze(0)).contiguous()
         n = xb.shape[1]
         c = y.shape[-2]
         sv, mean, noise = self._hypers()
@@ -182,9 +220,15 @@ class DKT(MetaTemplate):
         with torch.no_grad():
             if bn is not None and bn.track_running_stats:
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item() + 1)
-                bn.running_mean.mul_(1.0 - mom).add_(bmean[0], alpha=mom)
-                bn.running_var.mul_(1.0 - mom).add_(bvar[0], alpha=mom)
-                bn.num_batches_tracked += 1
+                nb = xb.shape[0]
+                if nb == 1:
+                    bn.running_mean.mul_(1.0 - mom).add_(bmean[0], alpha=mom)
+                    bn.running_var.mul_(1.0 - mom).add_(bvar[0], alpha=mom)
+                else:       # nb sequential momentum updates in closed form: r <- (1-m)^nb r + m sum_b (1-m)^(nb-1-b) x_b
+                    wts = mom * (1.0 - mom) ** torch.arange(nb - 1, -1, -1, device=xb.device, dtype=torch.float32)
+                    bn.running_mean.mul_((1.0 - mom) ** nb).add_((bmean * wts[:, None]).sum(0))
+                    bn.running_var.mul_((1.0 - mom) ** nb).add_((bvar * wts[:, None]).sum(0))
+                bn.num_batches_tracked += nb
             z_train = None
             if want_z:
                 z_train = (xb[0].detach() * a.reshape(-1, xb.shape[2])[0] + s.reshape(-1, xb.shape[2])[0]) * rnorm[0].unsqueeze(1)
@@ -202,8 +246,17 @@ class DKT(MetaTemplate):
             obj, logp, alpha, info, jit, e = ops.episode_loss_linear(zb, y, sv, mean, noise, cw, self.jitter0, self.max_tries,
                                                                      unit_rows=bool(self.normalize))
         else:
-            e = ops.base_matrix(zb, self.kernel_type, self.model.lengthscale, self.model.offset)
-            obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+            # rbf / matern / polynomial: every class model owns its lengthscale / offset (one ExactGPLayer per class,
+            # DKT.py:63-66), so the base matrix differs per class: one Gram + one single-model MLL launch per class
+            ls, off = self.model.lengthscale, self.model.offset
+            objs, logps, alphas, infos, jits = [], [], [], [], []
+            for k in range(c):
+                e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
+                yk = y[..., k:k + 1, :].contiguous()
+                o, lp, al, inf, jt = ops.mll_objective(e, yk, sv[k:k + 1], mean[k:k + 1], noise[k:k + 1], cw[k:k + 1], self.jitter0, self.max_tries)
+                objs.append(o); logps.append(lp); alphas.append(al); infos.append(inf); jits.append(jt)
+            obj = torch.stack(objs, 0).sum(0)
+            logp, alpha, info, jit = torch.cat(logps, 1), torch.cat(alphas, 1), torch.cat(infos, 1), torch.cat(jits, 1)
         aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
         return obj.mean(), aux
 
@@ -214,11 +267,25 @@ class DKT(MetaTemplate):
         ls = None if ls is None else ls.detach()
         off = None if off is None else off.detach()
         zc = z_cond.detach().unsqueeze(0)
-        if e_cond is None or self.kernel_type not in LINEAR_KINDS:      # E depends on post-step hyper-parameters
-            e_cond = ops.kernel_matrix(zc, None, self.kernel_type, ls, off)
-        out = ops.mll(e_cond, y, sv.detach(), mean.detach(), noise.detach(), jitter0=self.jitter0, max_tries=self.max_tries)
-        ex = ops.kernel_matrix(z_star.detach().unsqueeze(0), zc, self.kernel_type, ls, off)
-        mu, labels = ops.predict(ex, out["alpha"], sv.detach(), mean.detach())
+        zs = z_star.detach().unsqueeze(0)
+        sv, mean, noise = sv.detach(), mean.detach(), noise.detach()
+        if self.kernel_type in LINEAR_KINDS:
+            if e_cond is None:
+                e_cond = ops.kernel_matrix(zc, None, self.kernel_type)
+            out = ops.mll(e_cond, y, sv, mean, noise, jitter0=self.jitter0, max_tries=self.max_tries)
+            mu, labels = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type), out["alpha"], sv, mean)
+            return mu[0], labels[0], out
+        # per-class base matrices (E depends on the class model's own, post-step, lengthscale / offset)
+        mus, outs = [], []
+        for k in range(y.shape[-2]):
+            lk, ok = (None if ls is None else ls[k:k + 1]), (None if off is None else off[k:k + 1])
+            o = ops.mll(ops.kernel_matrix(zc, None, self.kernel_type, lk, ok), y[..., k:k + 1, :].contiguous(), sv[k:k + 1], mean[k:k + 1],
+                        noise[k:k + 1], jitter0=self.jitter0, max_tries=self.max_tries)
+            m, _ = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type, lk, ok), o["alpha"], sv[k:k + 1], mean[k:k + 1], want_labels=False)
+            mus.append(m); outs.append(o)
+        mu = torch.cat(mus, 1)
+        out = {key: torch.cat([o[key] for o in outs], 1) for key in ("logp", "alpha", "jitter", "info")}
+        labels = mu.argmax(1).to(torch.int32)                 # first maximum wins, as np.argmax
         return mu[0], labels[0], out
 
     def _posterior_fused_eval(self, x_support, x_query, y):
@@ -246,11 +313,14 @@ class DKT(MetaTemplate):
         mu, labels = ops.predict(e_all[:, ns:, :ns].contiguous(), out["alpha"], sv.detach(), mean.detach())
         return mu[0], labels[0], out
 
-    def _sync_grads(self):
+    def _sync_grads(self, flag=None):
+        """One all-reduce of the flat gradient bucket; `flag` (max |info| of this rank's step) is summed over the ranks in the
+        same collective.  Returns the (global) flag."""
         if distributed.is_distributed():
             if self._grad_bucket is None:
                 self._grad_bucket = distributed.GradBucket(self.parameters())
-            self._grad_bucket.allreduce_mean()
+            return self._grad_bucket.allreduce_mean(flag)
+        return flag
 
     # ------------------------------------------------------------------ training
     def train_loop(self, epoch, train_loader, optimizer, print_freq=10):
@@ -258,25 +328,44 @@ class DKT(MetaTemplate):
         optimizer = torch.optim.Adam([{'params': self.model.parameters(), 'lr': 1e-4},
                                       {'params': self.feature_extractor.parameters(), 'lr': 1e-3}])
         dev = self.device
+        self._bad_steps = None
+        mb = max(1, int(getattr(self, "meta_batch", 1) or 1))
+        if mb > 1:          # opt-in (train.py --meta_batch B): B episodes per Adam step; 1 = the reference's semantics (DKT.py:160-164)
+            train_loader = _MetaBatched(train_loader, mb)
         for i, (x, _) in enumerate(train_loader):
-            self.n_query = x.size(1) - self.n_support
+            xe = x if x.dim() == 6 else x.unsqueeze(0)            # [B, C, S+Q, ch, H, W]
+            nb = xe.size(0)
+            self.n_query = xe.size(2) - self.n_support
             if self.change_way:
-                self.n_way = x.size(0)
+                self.n_way = xe.size(1)
             self._check_way(self.n_way)
             per = self.n_support + self.n_query
-            x_all = x.contiguous().view(self.n_way * per, *x.size()[2:]).to(dev, non_blocking=True)
+            n_ep = self.n_way * per
+            x_all = xe.contiguous().view(nb * n_ep, *xe.size()[3:]).to(dev, non_blocking=True)
             y_targets = self._targets(self.n_way, per, dev)
 
             self.model.train()
             self.likelihood.train()
             self.feature_extractor.train()
+            # ONE backbone pass over the nb * N images of the step (meta-batch: the backbone's own BatchNorm2d layers then see
+            # all of them as one batch, as any mini-batch training does; bn_out and the GPs stay per episode)
             x_feat = self._trunk_features(x_all)
-            fused = x_feat.dim() == 2 and self._fused_front_end(x_feat.shape[0], x_feat.shape[1])
+            fused = x_feat.dim() == 2 and self._fused_front_end(n_ep, x_feat.shape[1])
             if not fused:                                 # torch bn_out / F.normalize in front of the Gram kernels
                 bn = getattr(self.feature_extractor.trunk, "bn_out", None)
-                z_train = x_feat if bn is None else bn(x_feat)
+                if bn is None:
+                    z_train = x_feat
+                elif nb == 1:
+                    z_train = bn(x_feat)
+                else:                                     # per-episode batch statistics, like the fused path
+                    z_train = torch.cat([bn(x_feat[k * n_ep:(k + 1) * n_ep]) for k in range(nb)], 0)
                 if self.normalize:
                     z_train = F.normalize(z_train, p=2, dim=1)
+                if nb > 1:
+                    z_train = z_train.view(nb, n_ep, -1)
+            elif nb > 1:
+                x_feat = x_feat.view(nb, n_ep, -1)
+            x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
 
             # hyper-parameter means for the log line, read BEFORE the step (DKT.py:145-157); kept on
             # the device, converted to Python floats only when printed
@@ -294,7 +383,11 @@ class DKT(MetaTemplate):
             else:
                 loss, aux = self._episode_loss(z_train, y_targets)
             loss.backward()
-            self._sync_grads()
+            # failure flag of the step (not positive definite after every jitter retry), kept on the device, summed over the
+            # ranks with the gradients and accumulated over the iterations: checked -- on every rank alike -- at the next
+            # print point (GPyTorch raises NotPSDError synchronously; a failed step has poisoned the update with NaN)
+            bad = self._sync_grads(aux["info"].abs().max().float())
+            self._bad_steps = bad if self._bad_steps is None else self._bad_steps + bad
             optimizer.step()
 
             self.iteration = i + (epoch * len(train_loader))
@@ -308,6 +401,9 @@ class DKT(MetaTemplate):
             if not need_eval:
                 self._last = dict(loss=loss.detach(), acc_support=None, acc_query=None, info=aux["info"])
                 continue
+            if nb > 1 and not fused:
+                z_train = z_train[0].detach()
+            e_first = aux["e"][:1]
             with torch.no_grad():
                 self.model.eval()
                 self.likelihood.eval()
@@ -316,7 +412,7 @@ class DKT(MetaTemplate):
                 z_support = z_eval[:, :self.n_support].reshape(self.n_way * self.n_support, -1)
                 z_query = z_eval[:, self.n_support:].reshape(self.n_way * self.n_query, -1)
                 z_star = torch.cat([z_support, z_query], 0)
-                _, labels, _ = self._posterior(z_train, y_targets, z_star, e_cond=aux["e"])
+                _, labels, _ = self._posterior(z_train, y_targets, z_star, e_cond=e_first)
                 cls = torch.arange(self.n_way, device=dev, dtype=torch.int32)
                 ns = self.n_way * self.n_support
                 acc_support = (labels[:ns] == cls.repeat_interleave(self.n_support)).float().mean() * 100.0
@@ -329,7 +425,7 @@ class DKT(MetaTemplate):
             if i % print_freq == 0:
                 if self.writer is not None:
                     self.writer.add_histogram('z_support', z_support, self.iteration)
-                if int(aux["info"].abs().max().item()) != 0:
+                if float(self._bad_steps.item()) != 0.0:
                     raise RuntimeError("DKT: kernel matrix not positive definite after jitter retries "
                                        "(GPyTorch raises NotPSDError here)")
                 print('Epoch [{:d}] [{:d}/{:d}] | Outscale {:f} | Lenghtscale {:f} | Noise {:f} | Loss {:f} | Supp. {:f} | Query {:f}'.format(

@@ -131,6 +131,16 @@ class DKT(nn.Module):
         torch.save({'gp': self.model.state_dict(), 'likelihood': {}, 'net': self.feature_extractor.state_dict()}, checkpoint)
 
     def load_checkpoint(self, checkpoint):
+        """Own checkpoints and the reference's (DKT_regression.py:99-110: 'gp' = ExactGPLayer.state_dict() with GPyTorch's key
+        names, 'likelihood' = GaussianLikelihood.state_dict(), 'net' = the backbone)."""
         ckpt = torch.load(checkpoint, map_location=self.device)
-        self.model.load_state_dict(ckpt['gp'])
+        gp = ckpt['gp']
+        if any(k.startswith(("mean_module.", "covar_module.", "likelihood.noise_covar.")) for k in gp):
+            ref = {"model.models.0." + k: v for k, v in gp.items()}
+            for k, v in (ckpt.get('likelihood') or {}).items():           # 'noise_covar.raw_noise'
+                ref.setdefault("model.models.0.likelihood." + k, v)
+            if self.model.load_reference_state_dict(ref) == 0:
+                raise RuntimeError("reference regression checkpoint without known GP keys")
+        else:
+            self.model.load_state_dict(gp)
         self.feature_extractor.load_state_dict(ckpt['net'])

@@ -5,9 +5,10 @@ Mirrors what the reference builds from GPyTorch objects (reference methods/DKT.p
 methods/DKT_regression.py:25-37, 112-129):
   * ConstantMean            -> `mean_constant` [C], init 0, learned
   * ScaleKernel             -> `raw_outputscale` [C], outputscale = softplus(raw), init raw 0 -> ln 2
-  * LinearKernel.variance   -> `raw_variance` [1]; cossim/bncossim: variance = 1.0 and frozen (DKT.py:366-370)
-  * RBFKernel / MaternKernel(nu=2.5).lengthscale -> `raw_lengthscale` [1], lengthscale = softplus(raw), init ln 2
-  * PolynomialKernel.offset -> `raw_offset` [1] (poli1, poli2), offset = softplus(raw), init ln 2
+  * LinearKernel.variance   -> `raw_variance` [C]; cossim/bncossim: variance = 1.0 and frozen (DKT.py:366-370)
+  * RBFKernel / MaternKernel(nu=2.5).lengthscale -> `raw_lengthscale` [C], lengthscale = softplus(raw), init ln 2
+  * PolynomialKernel.offset -> `raw_offset` [C] (poli1, poli2), offset = softplus(raw), init ln 2
+    (the reference builds one ExactGPLayer per class, DKT.py:63-66: every class model owns its base-kernel parameters)
   * SpectralMixtureKernel(num_mixtures=Q, ard_num_dims=D) (regression only, DKT_regression.py:121-122; NOT wrapped in a
                                ScaleKernel) -> `raw_mixture_weights` [Q], `raw_mixture_means` [Q,1,D],
                                `raw_mixture_scales` [Q,1,D] (GPyTorch's shapes), all softplus(raw), raw init 0
@@ -60,17 +61,17 @@ class ExactGPHypers(nn.Module):
             self.raw_outputscale = nn.Parameter(torch.zeros(n_models))
         if kernel in ("cossim", "bncossim"):
             # variance = 1.0, frozen
-            self.raw_variance = nn.Parameter(torch.full((1,), inv_softplus(1.0)), requires_grad=False)
+            self.raw_variance = nn.Parameter(torch.full((n_models,), inv_softplus(1.0)), requires_grad=False)
         elif kernel == "linear":
-            self.raw_variance = nn.Parameter(torch.zeros(1))
+            self.raw_variance = nn.Parameter(torch.zeros(n_models))
         else:
             self.register_parameter("raw_variance", None)
         if kernel in RBF_KINDS + MATERN_KINDS:
-            self.raw_lengthscale = nn.Parameter(torch.zeros(1))
+            self.raw_lengthscale = nn.Parameter(torch.zeros(n_models))
         else:
             self.register_parameter("raw_lengthscale", None)
         if kernel in POLY_KINDS:          # PolynomialKernel.offset = softplus(raw_offset), init raw 0
-            self.raw_offset = nn.Parameter(torch.zeros(1))
+            self.raw_offset = nn.Parameter(torch.zeros(n_models))
         else:
             self.register_parameter("raw_offset", None)
         if fixed_noise is not None:
@@ -132,31 +133,35 @@ class ExactGPHypers(nn.Module):
         return self.n_models
 
     # ---- reference (GPyTorch IndependentModelList) checkpoint keys ----
+    REFERENCE_KEYS = {                                  # key below `models.{c}.` -> parameter here (element c)
+        "mean_module.constant": "mean_constant",
+        "covar_module.raw_outputscale": "raw_outputscale",
+        "likelihood.noise_covar.raw_noise": "raw_noise",
+        "covar_module.base_kernel.raw_variance": "raw_variance",
+        "covar_module.base_kernel.raw_lengthscale": "raw_lengthscale",
+        "covar_module.base_kernel.raw_offset": "raw_offset",
+    }
+
     def load_reference_state_dict(self, state: dict, prefix: str = "model.") -> int:
         """Copy hyper-parameters out of a reference DKT `state_dict()` (GPyTorch 1.0.1 key names:
         `model.models.{c}.mean_module.constant`, `.covar_module.raw_outputscale`,
-        `.covar_module.base_kernel.raw_variance|raw_lengthscale`, `.likelihood.noise_covar.raw_noise`).
+        `.covar_module.base_kernel.raw_variance|raw_lengthscale|raw_offset`, `.likelihood.noise_covar.raw_noise`), every class.
         Returns the number of tensors consumed.  Key names could not be diffed against GPyTorch here."""
         used = 0
         with torch.no_grad():
             for c in range(self.n_models):
                 base = "%smodels.%d." % (prefix, c)
-                for key, (dst, idx) in {
-                    base + "mean_module.constant": (self.mean_constant, c),
-                    base + "covar_module.raw_outputscale": (self.raw_outputscale, c),
-                    base + "likelihood.noise_covar.raw_noise": (self.raw_noise, c),
-                }.items():
-                    if key in state and dst is not None:
-                        dst[idx] = state[key].reshape(-1)[0].to(dst)
-                        used += 1
-                for key, dst in {
-                    base + "covar_module.base_kernel.raw_variance": self.raw_variance,
-                    base + "covar_module.base_kernel.raw_lengthscale": self.raw_lengthscale,
-                }.items():
-                    if key in state and dst is not None and c == 0:
-                        dst[0] = state[key].reshape(-1)[0].to(dst)
+                for key, name in self.REFERENCE_KEYS.items():
+                    dst = getattr(self, name, None)
+                    if base + key in state and dst is not None:
+                        dst[c] = state[base + key].reshape(-1)[0].to(dst)
                         used += 1
         return used
+
+    @staticmethod
+    def is_reference_state_dict(state: dict) -> bool:
+        """A state dict written by the reference's DKT (GPyTorch module tree) rather than by this module."""
+        return any(k.startswith("model.models.0.") for k in state)
 
 
 class _Attr:
@@ -173,10 +178,10 @@ class _ModelView:
     @property
     def covar_module(self):
         h, c = self._h, self._c
-        ls = h.lengthscale
+        ls, var = h.lengthscale, h.variance
         return _Attr(outputscale=h.outputscale[c],
                      raw_outputscale=None if h.raw_outputscale is None else h.raw_outputscale[c],
-                     base_kernel=_Attr(lengthscale=ls, variance=h.variance))
+                     base_kernel=_Attr(lengthscale=None if ls is None else ls[c:c + 1], variance=None if var is None else var[c:c + 1]))
 
     @property
     def likelihood(self):

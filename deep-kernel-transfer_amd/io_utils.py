@@ -27,6 +27,7 @@ def parse_args(script, argv=None):
     parser.add_argument('--kernel_type', default=None, help='override configs.kernel_type')
     parser.add_argument('--image_size', default=None, type=int, help='override the backbone-dependent image size')
     parser.add_argument('--n_episode', default=None, type=int, help='episodes per epoch (train: 100) / per test run (600)')
+    parser.add_argument('--meta_batch', default=1, type=int, help='[train, this build] episodes per Adam step through the batched hot path (1 = the reference: one step per episode)')
     if script == 'train':
         parser.add_argument('--num_classes', default=200, type=int, help='(baseline only; kept for CLI compatibility)')
         parser.add_argument('--save_freq', default=50, type=int, help='Save frequency')

@@ -87,6 +87,14 @@ def gp_logp(e, y_c, sv, mean, noise, jitter0=None):
     return -0.5 * (quad + logdet + n * LOG_2PI), alpha.squeeze(-1)
 
 
+def _per_model(p, c):
+    """Base-kernel parameter of class model c: every ExactGPLayer owns its parameters (methods/DKT.py:63-66, 352-370); a scalar
+    or one-element tensor is shared."""
+    if p is None or not torch.is_tensor(p) or p.numel() == 1:
+        return p
+    return p.reshape(-1)[c]
+
+
 def classification_loss(z, n_way, outputscale, mean, noise, kernel="bncossim", lengthscale=None,
                         normalize=False, variance=1.0):
     """methods/DKT.py:141-162.  z: [N,D] backbone (incl. bn_out) output; returns (loss, logp[C], alpha[C,N])."""
@@ -96,8 +104,8 @@ def classification_loss(z, n_way, outputscale, mean, noise, kernel="bncossim", l
     y = one_vs_rest_targets(n_way, n // n_way, z.dtype)
     logps, alphas = [], []
     for c in range(n_way):                       # IndependentModelList: a Python loop over models,
-        e = base_matrix(z, None, kernel, lengthscale)   # each re-evaluating its own kernel matrix
-        lp, a = gp_logp(e, y[c], outputscale[c] * variance, mean[c], noise[c])
+        e = base_matrix(z, None, kernel, _per_model(lengthscale, c))   # each evaluating its OWN kernel (own lengthscale / offset)
+        lp, a = gp_logp(e, y[c], outputscale[c] * _per_model(variance, c), mean[c], noise[c])
         logps.append(lp / n)                      # ExactMarginalLogLikelihood: / num_data
         alphas.append(a)
     loss = -(sum(logps) / n_way)                  # SumMarginalLogLikelihood: / len(mlls)
@@ -113,8 +121,11 @@ def regression_loss(z, labels, outputscale, mean, noise, lengthscale, kernel="rb
 
 
 def predict_mean(z_cond, z_star, alpha, outputscale, mean, kernel="bncossim", lengthscale=None, variance=1.0):
-    ex = base_matrix(z_star, z_cond, kernel, lengthscale)
-    return mean[:, None] + (outputscale * variance)[:, None] * (alpha @ ex.T)
+    rows = []
+    for c in range(alpha.shape[0]):
+        ex = base_matrix(z_star, z_cond, kernel, _per_model(lengthscale, c))
+        rows.append(mean[c] + outputscale[c] * _per_model(variance, c) * (ex @ alpha[c]))
+    return torch.stack(rows)
 
 
 # --------------------------------------------------------------------------------------------

@@ -135,9 +135,51 @@ def make_spectral():
     print("wrote regression_spectral_q4: loss", out["loss"])
 
 
+def make_cfg0():
+    """BASELINE.json configs[0] / SURVEY.md 8c: the QMUL regression head (methods/DKT_regression.py:45-97) at its real shape --
+    one GP, RBF kernel, a training task of 19 frames with D = 2916 Conv3 features, and the test-time shape (condition on 5 of
+    them, predict all 19).  Features are regenerated from the seed (19 x 2916 doubles would be 440 KB).  Cross-checked against
+    scikit-learn (log marginal likelihood, predictive mean / std) and scipy at generation time."""
+    from scipy.stats import multivariate_normal
+    seed, n, d = 1907, 19, 2916
+    rng = np.random.default_rng(seed)
+    z = np.abs(rng.standard_normal((n, d))) * 0.35 + 0.05 * rng.standard_normal((1, d))     # ReLU-like Conv3 outputs
+    labels = rng.uniform(-1.0, 1.0, n)
+    hyp = O.GPHypers(np.array([0.9]), np.array([0.07]), np.array([0.3]), lengthscale=11.0)
+    out = O.regression_episode(z, labels, hyp, kernel="rbf")
+    kmat = hyp.outputscale[0] * out["e"] + hyp.noise[0] * np.eye(n)
+    ref_scipy = multivariate_normal.logpdf(labels, mean=np.full(n, hyp.mean[0]), cov=kmat)
+    ref_sk, _ = sklearn_logp("rbf", z, labels - hyp.mean[0], hyp.outputscale[0], hyp.noise[0], hyp.lengthscale)
+    assert abs(ref_scipy - out["logp"][0]) < 1e-8 * abs(ref_scipy) and abs(ref_sk - out["logp"][0]) < 1e-8 * abs(ref_sk)
+    sup = [1, 4, 9, 13, 17]
+    pred = O.regression_predict(z[sup], labels[sup], z, hyp, kernel="rbf")
+    _, gp = sklearn_logp("rbf", z[sup], labels[sup] - hyp.mean[0], hyp.outputscale[0], hyp.noise[0], hyp.lengthscale)
+    mu_sk, sd_sk = gp.predict(z, return_std=True)
+    assert np.abs(mu_sk + hyp.mean[0] - pred["mean"]).max() < 1e-8
+    # sklearn's predictive variance takes the prior diagonal from the full kernel, WhiteKernel included: it is the variance
+    # with the observation noise added -- what likelihood(model(x)).confidence_region() reads in the reference
+    assert np.abs(sd_sk ** 2 - pred["var"]).max() < 1e-9
+    np.savez_compressed(os.path.join(OUT, "cfg0_qmul_regression_rbf.npz"), seed=seed, n=n, d=d, z_checksum=float(z.sum()), z_row0=z[0, :8].copy(),
+                        labels=labels, outputscale=hyp.outputscale, mean=hyp.mean, noise=hyp.noise, lengthscale=hyp.lengthscale,
+                        e_rows=out["e"][:3].copy(), loss=out["loss"], logp=out["logp"], logp_sklearn=ref_sk, logp_scipy=ref_scipy,
+                        alpha=out["alpha"], dsv=out["dsv"], dmean=out["dmean"], dnoise=out["dnoise"], dlengthscale=out["dlengthscale"],
+                        dz_rows=out["dz"][:3].copy(), dz_fro=float(np.linalg.norm(out["dz"])), dz_checksum=float(np.abs(out["dz"]).sum()),
+                        support=np.array(sup), pred_mean=pred["mean"], pred_var=pred["var"])
+    print("wrote cfg0_qmul_regression_rbf: loss", out["loss"], "dlengthscale", out["dlengthscale"])
+
+
+def cfg0_features(seed=1907, n=19, d=2916):
+    """The generator the fixture's z comes from (tests regenerate z from the seed)."""
+    rng = np.random.default_rng(seed)
+    z = np.abs(rng.standard_normal((n, d))) * 0.35 + 0.05 * rng.standard_normal((1, d))
+    return z, rng.uniform(-1.0, 1.0, n)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["spectral"]:
         make_spectral()
+    elif sys.argv[1:] == ["cfg0"]:
+        make_cfg0()
     else:
         main()
         make_spectral()

@@ -107,6 +107,42 @@ def test_reference_checkpoint_key_loader():
     assert abs(h.mean_constant[0].item() - 0.3) < 1e-7 and abs(h.raw_outputscale[1].item() + 0.7) < 1e-7
 
 
+def test_reference_format_checkpoints_load_through_the_drivers_entry_points(tmp_path):
+    """A state dict with the reference's key names (GPyTorch module tree, methods/DKT.py:58-71; every class model owns its
+    base-kernel parameters) loads through DKT.load_state_dict -- what test.py / train.py --resume / test_uncertainty.py call --
+    and the reference's regression checkpoint layout through DKTRegression.load_checkpoint."""
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=3, n_support=2, kernel_type="rbf")
+    own = m.state_dict()
+    state = {("feature." + k[len("feature_extractor."):]): v.clone() + 0.25 for k, v in own.items() if k.startswith("feature_extractor.")}
+    state.update({k: v for k, v in own.items() if k.startswith("feature_extractor.")})     # the reference saves both aliases
+    for c in range(3):
+        b = "model.models.%d." % c
+        state[b + "mean_module.constant"] = torch.tensor([0.1 * (c + 1)])
+        state[b + "covar_module.raw_outputscale"] = torch.tensor(-0.5 * c)
+        state[b + "covar_module.base_kernel.raw_lengthscale"] = torch.tensor([[1.0 + c]])
+        state[b + "likelihood.noise_covar.raw_noise"] = torch.tensor([-2.0])
+        state["likelihood.likelihoods.%d.noise_covar.raw_noise" % c] = torch.tensor([-2.0])
+        state["mll.model.models.%d.mean_module.constant" % c] = torch.tensor([0.1 * (c + 1)])
+    m.load_state_dict(state)
+    assert torch.allclose(m.model.mean_constant, torch.tensor([0.1, 0.2, 0.3]))
+    assert torch.allclose(m.model.raw_outputscale, torch.tensor([0.0, -0.5, -1.0]))
+    assert torch.allclose(m.model.raw_lengthscale, torch.tensor([1.0, 2.0, 3.0]))          # per class, none dropped
+    assert torch.allclose(m.model.raw_noise, torch.full((3,), -2.0))
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"model.models.0.mean_module.constant": torch.zeros(1)})          # no backbone tensors
+    reg = dkt_amd.DKTRegression(dkt_amd.backbone.Conv3(), "rbf")
+    path = str(tmp_path / "ref_regression_ckpt")
+    torch.save({"gp": {"likelihood.noise_covar.raw_noise": torch.tensor([0.4]), "mean_module.constant": torch.tensor([0.7]),
+                       "covar_module.raw_outputscale": torch.tensor(0.2), "covar_module.base_kernel.raw_lengthscale": torch.tensor([[1.5]])},
+                "likelihood": {"noise_covar.raw_noise": torch.tensor([0.4])}, "net": reg.feature_extractor.state_dict()}, path)
+    reg.load_checkpoint(path)
+    assert abs(reg.model.mean_constant.item() - 0.7) < 1e-7 and abs(reg.model.raw_lengthscale.item() - 1.5) < 1e-7
+    assert abs(reg.model.raw_noise.item() - 0.4) < 1e-7 and abs(reg.model.raw_outputscale.item() - 0.2) < 1e-7
+    own_path = str(tmp_path / "own_ckpt")
+    reg.save_checkpoint(own_path)
+    reg.load_checkpoint(own_path)
+
+
 def test_backbone_shapes():
     bb = dkt_amd.backbone
     x = torch.randn(2, 3, 28, 28)

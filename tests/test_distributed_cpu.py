@@ -60,6 +60,19 @@ def _worker(rank, world, port, q):
         accs = [float(e) for e in sh]
         allacc = dkt_amd.distributed.gather_accuracies(accs, device=torch.device("cpu"))
         assert allacc == [float(e) for e in range(601)]
+        # failure flag riding in the gradient collective: summed over the ranks, gradients still averaged
+        for p_ in bucket.params:
+            p_.grad = torch.full_like(p_, float(rank))
+        flag = bucket.allreduce_mean(torch.tensor(3.0 if rank == 1 else 0.0))
+        assert float(flag) == 3.0 and all(torch.allclose(p_.grad, torch.full_like(p_, (world - 1) / 2.0)) for p_ in bucket.params)
+        # BatchNorm running estimates averaged over the ranks before a checkpoint is written
+        bn = torch.nn.BatchNorm1d(4)
+        bn.running_mean.fill_(float(rank))
+        bn.running_var.fill_(1.0 + 2.0 * rank)
+        bn.num_batches_tracked.fill_(10 + rank)
+        dkt_amd.distributed.average_module_buffers(bn)
+        assert torch.allclose(bn.running_mean, torch.full((4,), (world - 1) / 2.0)) and torch.allclose(bn.running_var, torch.full((4,), float(world)))
+        assert int(bn.num_batches_tracked) == 10
         t = dkt_amd.distributed.allreduce_sum_(torch.tensor([1.0 + rank]))
         assert t.item() == sum(1.0 + r for r in range(world))
         q.put((rank, "ok"))

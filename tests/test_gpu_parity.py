@@ -4,6 +4,7 @@ size-independent properties.  Tolerances (north_star): marginal log likelihood 1
 identical predicted labels; gradients rel-L2 1e-3."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -516,7 +517,7 @@ def test_duplicate_rows_rank_deficient_gram(cuda):
 # ----------------------------------------------------------------------------------------------
 # golden vectors through the fused autograd entry point
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "cfg*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "cfg[1-9]*.npz"))))
 def test_golden_training_episode_fused(cuda, path):
     g = np.load(path)
     c, s, q, d = int(g["n_way"]), int(g["n_support"]), int(g["n_query"]), int(g["d"])
@@ -568,6 +569,50 @@ def test_golden_rbf_episode_autograd(cuda):
     assert rel_l2(sv.grad.cpu().numpy(), ref["dsv"]) < GRAD_RTOL
     assert rel_l2(noise.grad.cpu().numpy(), ref["dnoise"]) < GRAD_RTOL
     assert rel_l2(mean.grad.cpu().numpy(), ref["dmean"]) < GRAD_RTOL
+
+
+def test_golden_cfg0_qmul_regression_head(cuda):
+    """BASELINE.json configs[0] at its real shape ((19, 2916, 1 GP, RBF) training task and the 5 -> 19 test shape,
+    methods/DKT_regression.py:45-97) against the committed fixture tests/golden/cfg0_qmul_regression_rbf.npz (float64 oracle,
+    cross-checked against scikit-learn and scipy when it was generated): through the raw ops AND through the DKTRegression head."""
+    sys.path.insert(0, GOLD)
+    from make_golden import cfg0_features
+    g = np.load(os.path.join(GOLD, "cfg0_qmul_regression_rbf.npz"))
+    z, labels = cfg0_features(int(g["seed"]), int(g["n"]), int(g["d"]))
+    assert abs(z.sum() - float(g["z_checksum"])) < 1e-9 * abs(float(g["z_checksum"])) and np.allclose(labels, g["labels"])
+    n = z.shape[0]
+    zt = dev_t(z[None], cuda).requires_grad_(True)
+    ls = dev_t([float(g["lengthscale"])], cuda).requires_grad_(True)
+    sv, mean, noise = (dev_t(g[k], cuda).requires_grad_(True) for k in ("outputscale", "mean", "noise"))
+    cw = torch.full((1,), -1.0 / n, device=cuda)
+    e = ops.base_matrix(zt, "rbf", ls)
+    assert np.abs(e[0, :3].detach().cpu().numpy() - g["e_rows"]).max() < 2e-6
+    obj, logp, alpha, info, jit = ops.mll_objective(e, dev_t(labels[None, None], cuda), sv, mean, noise, cw)
+    obj.mean().backward()
+    assert int(info.abs().max().item()) == 0
+    assert abs(obj.item() - float(g["loss"])) < MLL_RTOL * abs(float(g["loss"]))
+    assert abs(logp.item() - float(g["logp"][0])) < MLL_RTOL * abs(float(g["logp"][0]))
+    assert rel_l2(alpha[0].cpu().numpy(), g["alpha"]) < 5e-4
+    assert rel_l2(zt.grad[0, :3].cpu().numpy(), g["dz_rows"]) < GRAD_RTOL
+    assert abs(float(zt.grad[0].norm()) - float(g["dz_fro"])) < GRAD_RTOL * float(g["dz_fro"])
+    assert abs(ls.grad.item() - float(g["dlengthscale"])) < GRAD_RTOL * abs(float(g["dlengthscale"]))
+    assert rel_l2(sv.grad.cpu().numpy(), g["dsv"]) < GRAD_RTOL             # the fixture's gradients are those of the loss -logp / N
+    assert rel_l2(noise.grad.cpu().numpy(), g["dnoise"]) < GRAD_RTOL
+    assert rel_l2(mean.grad.cpu().numpy(), g["dmean"]) < GRAD_RTOL
+    # the DKTRegression head: same numbers through _loss / predict (the backbone replaced by the fixture's features)
+    m = dkt_amd.DKTRegression(dkt_amd.backbone.Conv3(), "rbf").to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.fill_(dkt_amd.gp.inv_softplus(float(g["outputscale"][0])))
+        m.model.mean_constant.fill_(float(g["mean"][0]))
+        m.model.raw_noise.fill_(dkt_amd.gp.inv_softplus(float(g["noise"][0]) - dkt_amd.gp.NOISE_LOWER_BOUND))
+        m.model.raw_lengthscale.fill_(dkt_amd.gp.inv_softplus(float(g["lengthscale"])))
+    loss, aux = m._loss(dev_t(z, cuda), dev_t(labels, cuda))
+    assert abs(loss.item() - float(g["loss"])) < MLL_RTOL * abs(float(g["loss"]))
+    sup = g["support"].tolist()
+    with torch.no_grad():
+        mu, var = m.predict(dev_t(z[sup], cuda), dev_t(labels[sup], cuda), dev_t(z, cuda), with_variance=True)
+    assert np.abs(mu.cpu().numpy() - g["pred_mean"]).max() < 1e-4
+    assert np.abs(var.cpu().numpy() - g["pred_var"]).max() < 1e-4 * np.abs(g["pred_var"]).max()
 
 
 @pytest.mark.parametrize("b,n,d", [(2, 5, 12), (2, 85, 512), (3, 105, 64), (2, 105, 1600), (1, 130, 36), (1, 420, 512)])
@@ -856,6 +901,69 @@ def test_dkt_train_step_fused_front_end_matches_float64_autograd(cuda, kernel):
         assert int(bn.num_batches_tracked.item()) == int(bnr.num_batches_tracked.item()) == 1
 
 
+@pytest.mark.parametrize("kernel", ["bncossim", "rbf"])
+def test_dkt_meta_batch_step_is_the_mean_of_the_single_episode_losses(cuda, kernel, capsys):
+    """train.py --meta_batch B (opt-in; 1 = the reference's one Adam step per episode, DKT.py:160-164): one backbone pass over the
+    B x N images, bn_out and the C GPs per episode through the batched [B, N, D] hot-path entries.  The step's loss and every
+    gradient must equal the float64 restatement of mean_b loss(episode b), and bn_out's running estimates what nn.BatchNorm1d
+    holds after seeing the B episodes one after the other."""
+    import copy
+    torch.manual_seed(0)
+    nb, n_way, per = 3, 5, 21
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=n_way, n_support=5, kernel_type=kernel).to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
+        m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+        if m.model.raw_lengthscale is not None:
+            m.model.raw_lengthscale.copy_(torch.tensor([8.0, 6.5, 9.0, 7.0, 10.0]))
+    ref = copy.deepcopy(m).cpu().double()
+    x = torch.rand(nb, n_way, per, 3, 28, 28, generator=torch.Generator().manual_seed(1))
+    n = n_way * per
+    x_all = x.view(nb * n, 3, 28, 28)
+    m.train()
+    y = m._targets(n_way, per, cuda)
+    x_feat = m._trunk_features(x_all.to(cuda))
+    if kernel == "bncossim":
+        assert m._fused_front_end(n, x_feat.shape[1])
+        loss, aux, _ = m._episode_loss_from_trunk(x_feat.view(nb, n, -1), y)
+    else:
+        loss, aux = m._episode_loss(x_feat.view(nb, n, -1), y)
+    loss.backward()
+    assert aux["logp"].shape == (nb, n_way) and int(aux["info"].abs().max().item()) == 0
+    ref.train()
+    xr = ref._trunk_features(x_all.double())                       # the backbone's BatchNorm2d layers see all nb * N images
+    bnr = getattr(ref.feature_extractor.trunk, "bn_out", None) if kernel == "bncossim" else None
+    losses = []
+    for b in range(nb):
+        zb = xr[b * n:(b + 1) * n]
+        if bnr is not None:
+            zb = bnr(zb)                                            # per-episode batch statistics, running estimates episode by episode
+        if ref.normalize:
+            zb = torch.nn.functional.normalize(zb, p=2, dim=1)
+        lb, _, _ = T.classification_loss(zb, n_way, ref.model.outputscale, ref.model.mean, ref.model.noise, kernel, ref.model.lengthscale)
+        losses.append(lb)
+    loss_r = torch.stack(losses).mean()
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None, name
+            continue
+        diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+        assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+    if bnr is not None:
+        bn = m.feature_extractor.trunk.bn_out
+        assert rel_l2(bn.running_mean.cpu().numpy(), bnr.running_mean.numpy()) < 1e-5
+        assert rel_l2(bn.running_var.cpu().numpy(), bnr.running_var.numpy()) < 1e-4
+        assert int(bn.num_batches_tracked.item()) == int(bnr.num_batches_tracked.item()) == nb
+    # the driver-facing switch: train_loop with meta_batch = 2 takes len(loader) // 2 Adam steps
+    m.meta_batch = 2
+    before = m.model.raw_outputscale.detach().clone()
+    m.train_loop(0, _Loader(5, n_way, per, 28, 3), None)
+    out = capsys.readouterr().out
+    assert "Epoch [0] [0/2]" in out and not torch.equal(before, m.model.raw_outputscale.detach())
+
+
 # ----------------------------------------------------------------------------------------------
 # BNCosSim front half fused into the Gram build (bn_out + F.normalize + LinearKernel, DKT.py:48,141-142,375-378)
 # ----------------------------------------------------------------------------------------------
@@ -956,12 +1064,14 @@ def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
     with torch.no_grad():
         m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
         m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+        # every class model owns its base-kernel parameters (one ExactGPLayer per class, DKT.py:63-66): distinct values per class
         if m.model.raw_lengthscale is not None:
-            m.model.raw_lengthscale.fill_(8.0)      # un-normalised Conv4S features: distances ~ 8
+            m.model.raw_lengthscale.copy_(torch.tensor([8.0, 6.5, 9.0, 7.0, 10.0]))      # un-normalised Conv4S features: distances ~ 8
         if m.model.raw_offset is not None:
-            m.model.raw_offset.fill_(0.3)
+            m.model.raw_offset.copy_(torch.tensor([0.3, -0.2, 0.6, 0.0, 1.0]))
         if kernel == "linear":
-            m.model.raw_variance.fill_(-0.4)
+            m.model.raw_variance.copy_(torch.tensor([-0.4, 0.1, -0.8, 0.3, 0.0]))
+    assert all(getattr(m.model, nm) is None or getattr(m.model, nm).shape == (5,) for nm in ("raw_lengthscale", "raw_offset", "raw_variance"))
     ref = copy.deepcopy(m).cpu().double()
     x = torch.rand(5, 12, 3, 28, 28, generator=torch.Generator().manual_seed(2))
     x_all = x.view(60, 3, 28, 28)
@@ -984,11 +1094,19 @@ def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
             continue
         diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
         assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
-    # prediction through the same kernel (cross matrix)
+    # prediction through the same kernel (cross matrix, per-class parameters) vs the float64 restatement
     m.eval()
+    ref.eval()
     m.n_query = 7
     logits = m.get_logits(x)
     assert logits.shape == (35, 5) and torch.isfinite(logits).all()
+    with torch.no_grad():
+        zs = ref._embed(x[:, :5].reshape(25, 3, 28, 28).double())
+        zq = ref._embed(x[:, 5:].reshape(35, 3, 28, 28).double())
+        kn = kernel if kernel != "cossim" else "linear"
+        _, _, alpha_s = T.classification_loss(zs, 5, ref.model.outputscale, ref.model.mean, ref.model.noise, kn, extra, variance=var)
+        mu_r = T.predict_mean(zs, zq, alpha_s, ref.model.outputscale, ref.model.mean, kn, extra, variance=var)
+    assert np.abs(logits.t().cpu().numpy() - mu_r.numpy()).max() < 2e-3 * max(1.0, np.abs(mu_r.numpy()).max())
 
 
 def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
@@ -1282,7 +1400,7 @@ def test_drivers_end_to_end(cuda, tmp_path, monkeypatch, capsys):
     assert len(accs) == 2 and all(0.0 <= a <= 100.0 for a in accs)
     line = (tmp_path / "record" / "results.txt").read_text().strip().splitlines()[-1]
     assert "Setting: synthetic-novel-Conv4S-DKT 5shot 5way_train 5way_test" in line and "Test Acc" in line
-    eces = tu.main(common + ["--repeat", "1"])
-    assert len(eces) == 1 and 0.0 <= eces[0] <= 1.0
+    eces, temperature = tu.main(common + ["--repeat", "2"])
+    assert len(eces) == 2 and all(0.0 <= e <= 1.0 for e in eces) and temperature > 0.0
     out = capsys.readouterr().out
     assert "Epoch [0] [0/6]" in out and "Overall Test Acc" in out and "Overall ECE" in out

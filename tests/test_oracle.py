@@ -27,7 +27,7 @@ def _hyp(g):
     return O.GPHypers(g["outputscale"], g["mean"], g["noise"], float(g["lengthscale"]))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "cfg*.npz")) + glob.glob(os.path.join(GOLD, "small*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "cfg[1-9]*.npz")) + glob.glob(os.path.join(GOLD, "small*.npz"))))
 def test_golden_train_vectors(path):
     g = np.load(path)
     z = _regen(g)
@@ -178,5 +178,26 @@ def test_spectral_mixture_restatement_and_golden():
     assert np.linalg.eigvalsh(out["e"]).min() > -1e-10
     sup = g["support"]
     pred = O.regression_predict(g["z"][sup], g["labels"][sup], g["z"], hyp, kernel="spectral")
+    np.testing.assert_allclose(pred["mean"], g["pred_mean"], rtol=1e-10)
+    np.testing.assert_allclose(pred["var"], g["pred_var"], rtol=1e-10)
+
+
+def test_cfg0_fixture_matches_the_oracle_and_its_generator():
+    """tests/golden/cfg0_qmul_regression_rbf.npz (BASELINE.json configs[0] shape): the committed values are what the float64
+    oracle computes from the regenerated features (scikit-learn / scipy cross-checks are stored next to them)."""
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    from make_golden import cfg0_features
+    g = np.load(os.path.join(gold, "cfg0_qmul_regression_rbf.npz"))
+    z, labels = cfg0_features(int(g["seed"]), int(g["n"]), int(g["d"]))
+    hyp = O.GPHypers(g["outputscale"], g["mean"], g["noise"], lengthscale=float(g["lengthscale"]))
+    out = O.regression_episode(z, labels, hyp, kernel="rbf")
+    assert abs(out["loss"] - float(g["loss"])) < 1e-12
+    assert abs(float(g["logp_sklearn"]) - out["logp"][0]) < 1e-8 * abs(out["logp"][0])
+    assert abs(float(g["logp_scipy"]) - out["logp"][0]) < 1e-8 * abs(out["logp"][0])
+    np.testing.assert_allclose(out["dz"][:3], g["dz_rows"], rtol=1e-10, atol=1e-14)
+    pred = O.regression_predict(z[g["support"]], labels[g["support"]], z, hyp, kernel="rbf")
     np.testing.assert_allclose(pred["mean"], g["pred_mean"], rtol=1e-10)
     np.testing.assert_allclose(pred["var"], g["pred_var"], rtol=1e-10)

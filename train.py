@@ -22,7 +22,10 @@ def _set_seed(seed, verbose=True):
         random.seed(seed)
         np.random.seed(seed)
         torch.manual_seed(seed)
+        torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
+        torch.backends.cudnn.deterministic = True             # reference train.py:31-32 (MIOpen honours both flags on ROCm)
+        torch.backends.cudnn.benchmark = False
         if verbose:
             print("[INFO] Setting SEED: " + str(seed))
     elif verbose:
@@ -38,6 +41,10 @@ def train(base_loader, val_loader, model, optimization, start_epoch, stop_epoch,
     for epoch in range(start_epoch, stop_epoch):
         model.train()
         model.train_loop(epoch, base_loader, optimizer)
+        # every rank saw its own episodes: the BatchNorm running estimates differ per rank.  Average them (SURVEY.md 8e:
+        # "BN running stats: broadcast / average buffers at checkpoint time") so that the checkpoint does not depend on
+        # which rank writes it, and every rank validates / continues with the same buffers.
+        distributed.average_module_buffers(model)
         model.eval()
         if not os.path.isdir(params.checkpoint_dir):
             os.makedirs(params.checkpoint_dir, exist_ok=True)
@@ -71,11 +78,16 @@ def main(argv=None):
     n_ep = params.n_episode or 100
     base_loader = get_episode_loader(params, 'base', params.train_n_way, params.n_shot, n_query, n_ep, image_size,
                                      seed=params.seed + 100 * distributed.rank())
-    val_loader = get_episode_loader(params, 'val', params.test_n_way, params.n_shot, n_query, n_ep, image_size, seed=params.seed)
+    # validation episodes are sharded like test.py's: rank r evaluates its own len(shard) episodes (rank-dependent seed) and
+    # DKT.test_loop gathers the per-episode accuracies -- n_ep independent episodes in total, not W copies of the same ones
+    val_shard = distributed.shard_episodes(n_ep)
+    val_loader = get_episode_loader(params, 'val', params.test_n_way, params.n_shot, n_query, len(val_shard), image_size,
+                                    seed=params.seed + 1000 * distributed.rank())
 
     model = dkt_amd.DKT(model_dict[params.model], n_way=params.train_n_way, n_support=params.n_shot,
                         kernel_type=configs.kernel_type)
     model.init_summary()
+    model.meta_batch = max(1, getattr(params, 'meta_batch', 1))
     model = model.to(torch.device('cuda', local))
     distributed.broadcast_module_state(model)
 
