@@ -6,6 +6,7 @@ raises if the shared object is missing or a symbol of the header is absent.
 from __future__ import annotations
 
 import ctypes
+import json
 import os
 import subprocess
 import threading
@@ -60,8 +61,58 @@ def _lib_path() -> str:
 
 
 def _flags() -> list:
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", INCLUDE, "-I", CSRC] + \
-        os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split()
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+            "-I", INCLUDE, "-I", CSRC] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split()
+
+
+# Register-spill budget per kernel (regex on the mangled name -> max VGPR spills); everything else must not spill at all.
+# The headline instantiation of the MFMA marginal-likelihood kernel sits at its 168-VGPR cap (3 waves per SIMD) and keeps ~30
+# values of the round prologue in scratch across the factorisation -- stored / reloaded once per matrix, none inside the sweeps or
+# the MFMA phases.  The check fails the build when a change makes the compiler spill inside the hot loops.
+SPILL_BUDGET = {
+    r"mll_mfma_kernelILi7ELb1ELb0ELb1": 40,        # <NT = 7, GRAD, !CHOL, 5 waves per episode>: the bench kernel
+    r"mll_mfma_kernelILi[78]E": 260,               # other NT >= 7 instantiations (Cholesky output, odd class counts): not on a hot path
+    r"mll_mfma_kernelILi[56]E": 120,
+    r"mll_mfma_kernelILi[1-4]ELb.ELb1": 60,        # CHOL instantiations of the small shapes (regression head)
+    r"mll_reg_kernel|chol_inv_block_kernel": 80,   # round-1 register sweep (validation twin / blocked path's diagonal blocks)
+    # Gram forward: the default variants for N <= 112 (<7, 2, 2, 32, 2, 3> f16 split, <7, 1, 1, 32, 3, 4> bf16 split) do not spill;
+    # the non-default pipeline variants kept for A/B runs (DKT_GRAM_UNIT_VAR / DKT_GRAM_SPLIT_VAR) and the NT = 8 shapes
+    # (112 < N <= 128, 36 accumulator tiles) do
+    r"gram_sym_ep_split_kernelILi7ELi1E": 70,
+    r"gram_sym_ep_split_kernelILi8E": 140,
+}
+
+
+def _parse_resource_remarks(text: str) -> dict:
+    """-Rpass-analysis=kernel-resource-usage remarks -> {kernel: {vgprs, agprs, sgprs, scratch, vgpr_spill, sgpr_spill, lds, occupancy}}"""
+    import re
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def check_resources(usage: dict) -> list:
+    """Kernels whose VGPR spill count exceeds their budget (SPILL_BUDGET; default 0)."""
+    import re
+    bad = []
+    for name, u in usage.items():
+        budget = 0
+        for pat, b in SPILL_BUDGET.items():
+            if re.search(pat, name):
+                budget = b
+                break
+        if u.get("vgpr_spill", 0) > budget:
+            bad.append((name, u.get("vgpr_spill", 0), budget))
+    return bad
 
 
 def _digest(src: str) -> str:
@@ -97,18 +148,30 @@ def _compile_link(sources, target, replace=None, verbose=False) -> str:
     def one(name):
         src = (replace or {}).get(name, os.path.join(CSRC, name))
         obj = os.path.join(OBJ_DIR, "%s.%s.o" % (os.path.basename(src), _digest(src)))
-        if not os.path.exists(obj):
+        if not os.path.exists(obj) or not os.path.exists(obj + ".res.json"):
             cmd = [hipcc] + _flags() + ["-c", src, "-o", obj + ".tmp"]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed on %s:\n%s%s" % (name, res.stdout, res.stderr))
+            with open(obj + ".res.json", "w") as fh:
+                json.dump(_parse_resource_remarks(res.stderr), fh)
             os.replace(obj + ".tmp", obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(one, sources))
+    usage = {}
+    for o in objs:
+        with open(o + ".res.json") as fh:
+            usage.update(json.load(fh))
+    with open(os.path.join(OBJ_DIR, os.path.basename(target) + ".resource_usage.json"), "w") as fh:
+        json.dump(usage, fh, indent=1, sort_keys=True)
+    bad = check_resources(usage)
+    if bad:
+        raise RuntimeError("register spills beyond the budget (deep-kernel-transfer_amd/_lib.py SPILL_BUDGET):\n" +
+                           "\n".join("  %s: %d VGPR spills (budget %d)" % b for b in bad))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

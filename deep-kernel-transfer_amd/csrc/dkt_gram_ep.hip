@@ -738,9 +738,25 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
     }
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
+// Measurement / validation switches: read from the environment ONCE, at the first launch -- not per call.
+// dkt_reload_env() (below, exported for the test-suite and the A/B tools, which flip switches inside one process) re-reads them.
+struct GramEnv {
+    int ep, minb, split, ep_bk, ep_bd, unit_var, split_var, bwd_unit_var, bwd_split_var, bwd_unit_mind, bwd_split_mind;
+    static int get(const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v ? atoi(v) : dflt;
+    }
+    void load() {
+        ep = get("DKT_GRAM_EP", 1); minb = get("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
+        ep_bk = get("DKT_GRAM_EP_BK", 64); ep_bd = get("DKT_GRAM_EP_BD", 32);
+        unit_var = get("DKT_GRAM_UNIT_VAR", 2223); split_var = get("DKT_GRAM_SPLIT_VAR", 11);
+        bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 222); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
+        bwd_unit_mind = get("DKT_GRAM_BWD_UNIT_MIND", 64); bwd_split_mind = get("DKT_GRAM_BWD_SPLIT_MIND", 1024);
+    }
+};
+GramEnv& gram_env() {
+    static GramEnv e = [] { GramEnv x; x.load(); return x; }();
+    return e;
 }
 
 template <int NT>
@@ -748,7 +764,7 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit
     if (bk == 3) {
         // <LDS buffers><prefetch depth> of the bf16 split; 2xxx = scaled-f16 split (unit-norm rows only):
         // 2223 = 2 stage buffers, prefetch depth 2, 3 workgroups per CU
-        const int v = unit ? env_int("DKT_GRAM_UNIT_VAR", 2223) : env_int("DKT_GRAM_SPLIT_VAR", 11);
+        const int v = unit ? gram_env().unit_var : gram_env().split_var;
         if (v == 21) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 611) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 612) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
@@ -772,7 +788,7 @@ template <int NT>
 void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, bool unit, hipStream_t st) {
     if (bd == 3) {
         // <LDS buffers><prefetch depth> of the bf16 split; 2xx = scaled-f16 split (unit-norm rows of Z only)
-        const int v = unit ? env_int("DKT_GRAM_BWD_UNIT_VAR", 222) : env_int("DKT_GRAM_BWD_SPLIT_VAR", 11);
+        const int v = unit ? gram_env().bwd_unit_var : gram_env().bwd_split_var;
         if (v == 222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 221) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 212) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
@@ -791,10 +807,10 @@ void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, 
 
 // Returns true when the episode-resident kernel was launched.
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st) {
-    if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
-    if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
+    if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || gram_env().ep == 0) return false;
+    if (B < gram_env().minb) return false;
     // DKT_GRAM_SPLIT=1 (default): 3-way bf16 split on the bf16 MFMA pipe; 0: exact-fp32 MFMA (BK from DKT_GRAM_EP_BK)
-    const int bk = env_int("DKT_GRAM_SPLIT", 1) ? 3 : env_int("DKT_GRAM_EP_BK", 64);
+    const int bk = gram_env().split ? 3 : gram_env().ep_bk;
     switch ((N + 15) / 16) {
         case 5: launch_sym<5>(Z, E, B, N, D, bk, unit, st); return true;
         case 6: launch_sym<6>(Z, E, B, N, D, bk, unit, st); return true;
@@ -805,12 +821,12 @@ bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool 
 }
 
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st) {
-    if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || env_int("DKT_GRAM_EP", 1) == 0) return false;
-    if (B < env_int("DKT_GRAM_EP_MINB", 64)) return false;
+    if (N <= 64 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || gram_env().ep == 0) return false;
+    if (B < gram_env().minb) return false;
     // the split kernel pays a per-episode setup (A-fragment split, LDS zero fill): it wins from ~16 slabs of 64 features
     // (the f16 kernel for unit-norm rows has the cheaper staging path and already wins at D = 64: 0.27 vs 0.40 ms per 8192 episodes)
-    const int mind = unit ? env_int("DKT_GRAM_BWD_UNIT_MIND", 64) : env_int("DKT_GRAM_BWD_SPLIT_MIND", 1024);
-    const int bd = (env_int("DKT_GRAM_SPLIT", 1) && D >= mind) ? 3 : env_int("DKT_GRAM_EP_BD", 32);
+    const int mind = unit ? gram_env().bwd_unit_mind : gram_env().bwd_split_mind;
+    const int bd = (gram_env().split && D >= mind) ? 3 : gram_env().ep_bd;
     switch ((N + 15) / 16) {
         case 5: launch_bwd<5>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
         case 6: launch_bwd<6>(W, Z, dZ, B, N, D, sc, bd, unit, st); return true;
@@ -819,3 +835,6 @@ bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, in
         default: return false;
     }
 }
+
+// Re-read the measurement switches (tests / A-B tools flip them inside one process).  Not part of include/dkt_abi.h.
+extern "C" void dkt_reload_env(void) { gram_env().load(); }

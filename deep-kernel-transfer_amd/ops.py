@@ -13,6 +13,7 @@ which replace `-self.mll(self.model(*inputs), targets)` + `.backward()` of the r
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -101,6 +102,21 @@ class _timed:
 # ------------------------------------------------------------------------------------------------
 # raw (non-differentiable) entry points
 # ------------------------------------------------------------------------------------------------
+_ENV_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_EP_MINB", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR",
+                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND")
+_env_seen = None
+
+
+def _sync_env(lib) -> None:
+    """The library reads its measurement switches once; when a test or an A/B tool changed one inside this process, tell it."""
+    global _env_seen
+    cur = tuple(os.environ.get(k) for k in _ENV_SWITCHES)
+    if cur != _env_seen:
+        if _env_seen is not None or any(v is not None for v in cur):
+            lib.dkt_reload_env()
+        _env_seen = cur
+
+
 def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_LINEAR,
          lengthscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """E[b] = k(a[b], bm[b]); a:[B,M,D], bm:[B,N,D] or None (symmetric)."""
@@ -117,6 +133,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
         lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
     e = torch.empty((b_, m, n), device=a.device, dtype=torch.float32)
     lib = _lib.load()
+    _sync_env(lib)
     with _timed("dkt_gram_f32"):
         st = lib.dkt_gram_f32(_p(a), _p(bm), _p(e), b_, m, n, d, kind, _p(lengthscale), _stream())
     _lib.check(st, "dkt_gram_f32")
@@ -189,6 +206,7 @@ def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] 
             raise RuntimeError("gram_bwd: ep_scale must have B elements")
     dz = torch.empty_like(z)
     lib = _lib.load()
+    _sync_env(lib)
     with _timed("dkt_gram_bwd_f32"):
         st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale), GRAM_UNIT_ROWS if unit_rows else 0, _stream())
     _lib.check(st, "dkt_gram_bwd_f32")

@@ -1109,6 +1109,60 @@ def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
     assert np.abs(logits.t().cpu().numpy() - mu_r.numpy()).max() < 2e-3 * max(1.0, np.abs(mu_r.numpy()).max())
 
 
+@pytest.mark.parametrize("kernel", ["bncossim", "rbf"])
+def test_correct_with_test_time_adaptation_matches_float64_adam(cuda, kernel):
+    """`correct(x, N > 0)` (methods/DKT.py:242-272): N Adam steps (lr 1e-3) on the GP hyper-parameters only, on the support set,
+    then the posterior-mean labels of the queries.  Against a float64 restatement run on a CPU copy: same average loss, the same
+    adapted hyper-parameters to Adam's step size, identical query labels and correct-count."""
+    import copy
+    torch.manual_seed(3)
+    n_way, n_support, n_query, n_steps = 5, 5, 15, 3
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=n_way, n_support=n_support, kernel_type=kernel).to(cuda)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
+        m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
+        if m.model.raw_lengthscale is not None:
+            m.model.raw_lengthscale.copy_(torch.tensor([8.0, 6.5, 9.0, 7.0, 10.0]))
+    m.train()                                             # a few train-mode passes so that the BatchNorm running estimates are not the init values
+    with torch.no_grad():
+        for k in range(3):
+            m.feature_extractor(torch.rand(50, 3, 28, 28, generator=torch.Generator().manual_seed(10 + k)).to(cuda))
+    ref = copy.deepcopy(m).cpu().double()
+    x = _Loader(1, n_way, n_support + n_query, 28, 5).x[0]
+    m.eval()
+    m.n_query = n_query
+    top1, count, avg_loss = m.correct(x, N=n_steps)
+    # float64 restatement
+    ref.eval()
+    with torch.no_grad():
+        zs = ref._embed(x[:, :n_support].reshape(n_way * n_support, 3, 28, 28).double())
+        zq = ref._embed(x[:, n_support:].reshape(n_way * n_query, 3, 28, 28).double())
+    kn = kernel if kernel != "cossim" else "linear"
+    opt = torch.optim.Adam([{'params': ref.model.parameters()}], lr=1e-3)
+    tot = 0.0
+    for _ in range(n_steps):
+        opt.zero_grad()
+        loss_r, _, _ = T.classification_loss(zs, n_way, ref.model.outputscale, ref.model.mean, ref.model.noise, kn, ref.model.lengthscale)
+        loss_r.backward()
+        opt.step()
+        tot += loss_r.item()
+    with torch.no_grad():
+        _, _, alpha_r = T.classification_loss(zs, n_way, ref.model.outputscale, ref.model.mean, ref.model.noise, kn, ref.model.lengthscale)
+        mu_r = T.predict_mean(zs, zq, alpha_r, ref.model.outputscale, ref.model.mean, kn, ref.model.lengthscale)
+    labels_r = torch.sigmoid(mu_r).argmax(0).numpy()
+    y_q = np.repeat(np.arange(n_way), n_query)
+    assert count == n_way * n_query
+    assert abs(avg_loss - tot / n_steps) < 1e-4 * abs(tot / n_steps)
+    assert top1 == float((labels_r == y_q).sum())
+    for name in ("raw_outputscale", "mean_constant", "raw_lengthscale"):
+        p, pr = getattr(m.model, name), getattr(ref.model, name)
+        if p is not None:
+            assert np.abs(p.detach().cpu().numpy() - pr.detach().numpy()).max() < 2e-4, name      # 3 steps of 1e-3 each
+    m.n_query = n_query
+    logits = m.get_logits(x)                               # with the adapted hyper-parameters
+    assert (logits.argmax(1).cpu().numpy() == labels_r).all()
+
+
 def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
     torch.manual_seed(0)
     m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5).to(cuda)
