@@ -316,3 +316,56 @@ extern "C" int dkt_diag_sweep_ubench(float* out, int nblocks, int waves_per_bloc
     else hipLaunchKernelGGL(sweep_ubench_kernel<2>, g, b, 0, (hipStream_t)stream, out, iters);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- do fp32 MFMAs and VALU instructions of DIFFERENT waves of one SIMD overlap?  (tools/ubench_valu.py) ----
+// 8 waves per workgroup = 2 per SIMD.  role 0: waves 0-3 run an MFMA stream, waves 4-7 a v_fmac stream, at the same time;
+// role 1: everybody MFMA;  role 2: everybody v_fmac;  role 3: waves 0-3 bf16 MFMA (XDL pipe), waves 4-7 v_fmac.
+// out[wave] = ticks per instruction of that wave's stream.
+__global__ __launch_bounds__(512) void overlap_ubench_kernel(float* out, int iters, int role) {
+    const int wave = threadIdx.x >> 6;
+    const bool mfma_wave = role == 1 || ((role == 0 || role == 3) && wave < 4);
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = 1.0f + threadIdx.x * 1e-3f + i;
+    float t = 1e-6f;
+    dg_f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (mfma_wave && role != 3) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], a[3], c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], a[5], c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[6], a[7], c3, 0, 0, 0);
+            }
+        }
+    } else if (mfma_wave) {
+        dg_bf16x8 x, y;
+        for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(a[e]); y[e] = (__bf16)(a[8 + e]); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c3, 0, 0, 0);
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t));
+            DG_REP16(DG_X)
+#undef DG_X
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = c0[0] + c1[1] + c2[2] + c3[3];
+    for (int i = 0; i < 16; ++i) s += a[i];
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + wave] = (float)(t1 - t0) / (16.f * iters);
+    if (s == 123.456f) out[0] = s;
+}
+extern "C" int dkt_diag_overlap_ubench(float* out, int nblocks, int iters, int role, void* stream) {
+    hipLaunchKernelGGL(overlap_ubench_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, out, iters, role);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -89,6 +89,50 @@ class _MetaBatched:
                 xs, ys = [], []
 
 
+class _GraphedTrainStep:
+    """One training step (backbone forward / backward, the GP hot path, Adam) captured into a hipGraph (torch.cuda.CUDAGraph):
+    three eager warm-up steps on a side stream -- they are real steps on real episodes --, then capture, then one graph launch
+    per episode.  Static input buffer `x`; the outputs (loss, aux, z_train) are static tensors overwritten by every replay."""
+
+    WARMUP = 3
+
+    def __init__(self, model, optimizer, x_like, y_targets, nb, n_ep, key):
+        self.m, self.opt, self.y, self.nb, self.n_ep, self.key = model, optimizer, y_targets, nb, n_ep, key
+        self.x = torch.empty_like(x_like)
+        self.bad = torch.zeros((), device=x_like.device, dtype=torch.float32)
+        self.graph, self.out, self.steps = None, None, 0
+        self.side = torch.cuda.Stream(device=x_like.device)
+
+    def _step(self):
+        loss, aux, z_train, fused = self.m._train_forward(self.x, self.y, self.nb, self.n_ep, True)
+        loss.backward()
+        self.bad.add_(aux["info"].abs().max().float())
+        self.opt.step()
+        return loss.detach(), aux, z_train, fused
+
+    def run(self, x_dev):
+        self.x.copy_(x_dev)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out
+        cur = torch.cuda.current_stream()
+        if self.steps < self.WARMUP:
+            self.steps += 1
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.opt.zero_grad(set_to_none=True)
+                out = self._step()
+            cur.wait_stream(self.side)
+            return out
+        self.opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.out = self._step()
+        self.graph = g
+        g.replay()                       # capture only records: run the step for this episode
+        return self.out
+
+
 class DKT(MetaTemplate):
     def __init__(self, model_func, n_way, n_support, kernel_type=None):
         super(DKT, self).__init__(model_func, n_way, n_support)
@@ -313,6 +357,34 @@ class DKT(MetaTemplate):
         mu, labels = ops.predict(e_all[:, ns:, :ns].contiguous(), out["alpha"], sv.detach(), mean.detach())
         return mu[0], labels[0], out
 
+    def _train_forward(self, x_all, y_targets, nb, n_ep, want_z=True):
+        """Forward of one training step from the uploaded images x_all:[nb * N, ch, H, W]: returns (loss, aux, z_train, fused)."""
+        self.model.train()
+        self.likelihood.train()
+        self.feature_extractor.train()
+        # ONE backbone pass over the nb * N images of the step (meta-batch: the backbone's own BatchNorm2d layers then see
+        # all of them as one batch, as any mini-batch training does; bn_out and the GPs stay per episode)
+        x_feat = self._trunk_features(x_all)
+        fused = x_feat.dim() == 2 and self._fused_front_end(n_ep, x_feat.shape[1])
+        if fused:
+            if nb > 1:
+                x_feat = x_feat.view(nb, n_ep, -1)
+            loss, aux, z_train = self._episode_loss_from_trunk(x_feat, y_targets, want_z=want_z)
+            return loss, aux, z_train, True
+        bn = getattr(self.feature_extractor.trunk, "bn_out", None)        # torch bn_out / F.normalize in front of the Gram kernels
+        if bn is None:
+            z_train = x_feat
+        elif nb == 1:
+            z_train = bn(x_feat)
+        else:                                                               # per-episode batch statistics, like the fused path
+            z_train = torch.cat([bn(x_feat[k * n_ep:(k + 1) * n_ep]) for k in range(nb)], 0)
+        if self.normalize:
+            z_train = F.normalize(z_train, p=2, dim=1)
+        if nb > 1:
+            z_train = z_train.view(nb, n_ep, -1)
+        loss, aux = self._episode_loss(z_train, y_targets)
+        return loss, aux, z_train, False
+
     def _sync_grads(self, flag=None):
         """One all-reduce of the flat gradient bucket; `flag` (max |info| of this rank's step) is summed over the ranks in the
         same collective.  Returns the (global) flag."""
@@ -329,6 +401,13 @@ class DKT(MetaTemplate):
                                       {'params': self.feature_extractor.parameters(), 'lr': 1e-3}])
         dev = self.device
         self._bad_steps = None
+        # DKT_TRAIN_GRAPH=1: capture the per-episode step into a hipGraph (the loop is launch-bound: ~150 launches for ~1 ms of
+        # GPU work).  Needs static shapes, no TensorBoard writer inside the step and a single process.
+        use_graph = os.environ.get("DKT_TRAIN_GRAPH", "0") == "1" and not distributed.is_distributed()
+        graph_step = None
+        if use_graph:
+            optimizer = torch.optim.Adam([{'params': self.model.parameters(), 'lr': 1e-4},
+                                          {'params': self.feature_extractor.parameters(), 'lr': 1e-3}], capturable=True)
         mb = max(1, int(getattr(self, "meta_batch", 1) or 1))
         if mb > 1:          # opt-in (train.py --meta_batch B): B episodes per Adam step; 1 = the reference's semantics (DKT.py:160-164)
             train_loader = _MetaBatched(train_loader, mb)
@@ -344,28 +423,12 @@ class DKT(MetaTemplate):
             x_all = xe.contiguous().view(nb * n_ep, *xe.size()[3:]).to(dev, non_blocking=True)
             y_targets = self._targets(self.n_way, per, dev)
 
-            self.model.train()
-            self.likelihood.train()
-            self.feature_extractor.train()
-            # ONE backbone pass over the nb * N images of the step (meta-batch: the backbone's own BatchNorm2d layers then see
-            # all of them as one batch, as any mini-batch training does; bn_out and the GPs stay per episode)
-            x_feat = self._trunk_features(x_all)
-            fused = x_feat.dim() == 2 and self._fused_front_end(n_ep, x_feat.shape[1])
-            if not fused:                                 # torch bn_out / F.normalize in front of the Gram kernels
-                bn = getattr(self.feature_extractor.trunk, "bn_out", None)
-                if bn is None:
-                    z_train = x_feat
-                elif nb == 1:
-                    z_train = bn(x_feat)
-                else:                                     # per-episode batch statistics, like the fused path
-                    z_train = torch.cat([bn(x_feat[k * n_ep:(k + 1) * n_ep]) for k in range(nb)], 0)
-                if self.normalize:
-                    z_train = F.normalize(z_train, p=2, dim=1)
-                if nb > 1:
-                    z_train = z_train.view(nb, n_ep, -1)
-            elif nb > 1:
-                x_feat = x_feat.view(nb, n_ep, -1)
-            x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
+            graphed = None
+            if use_graph:
+                key = (tuple(x_all.shape), nb)
+                if graph_step is None or graph_step.key != key:
+                    graph_step = _GraphedTrainStep(self, optimizer, x_all, y_targets, nb, n_ep, key)
+                graphed = graph_step
 
             # hyper-parameter means for the log line, read BEFORE the step (DKT.py:145-157); kept on
             # the device, converted to Python floats only when printed
@@ -377,18 +440,21 @@ class DKT(MetaTemplate):
                     ls = self.model.lengthscale
                     log_lengthscale = ls.mean() if ls is not None else torch.zeros((), device=dev)
 
-            optimizer.zero_grad()
-            if fused:
-                loss, aux, z_train = self._episode_loss_from_trunk(x_feat, y_targets, want_z=need_eval)
+            if graphed is not None:
+                # the whole step (backbone forward / backward, the GP kernels, Adam) as ONE hipGraph launch
+                loss, aux, z_train, fused = graphed.run(x_all)
+                self._bad_steps = graphed.bad
             else:
-                loss, aux = self._episode_loss(z_train, y_targets)
-            loss.backward()
-            # failure flag of the step (not positive definite after every jitter retry), kept on the device, summed over the
-            # ranks with the gradients and accumulated over the iterations: checked -- on every rank alike -- at the next
-            # print point (GPyTorch raises NotPSDError synchronously; a failed step has poisoned the update with NaN)
-            bad = self._sync_grads(aux["info"].abs().max().float())
-            self._bad_steps = bad if self._bad_steps is None else self._bad_steps + bad
-            optimizer.step()
+                optimizer.zero_grad()
+                loss, aux, z_train, fused = self._train_forward(x_all, y_targets, nb, n_ep, need_eval)
+                loss.backward()
+                # failure flag of the step (not positive definite after every jitter retry), kept on the device, summed over the
+                # ranks with the gradients and accumulated over the iterations: checked -- on every rank alike -- at the next
+                # print point (GPyTorch raises NotPSDError synchronously; a failed step has poisoned the update with NaN)
+                bad = self._sync_grads(aux["info"].abs().max().float())
+                self._bad_steps = bad if self._bad_steps is None else self._bad_steps + bad
+                optimizer.step()
+            x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
 
             self.iteration = i + (epoch * len(train_loader))
             if self.writer is not None:

@@ -38,3 +38,15 @@ for mode, name in ((0, "v_fmac_f32_dpp, s_nop 1 per update"), (2, "v_fmac_f32_dp
         o = out.cpu().numpy()
         row.append("%d w/blk: mean %.0f max %.0f" % (wpb, o.mean(), o.max()))
     print("  %-38s %s" % (name, " | ".join(row)))
+
+lib.dkt_diag_overlap_ubench.restype = ctypes.c_int
+lib.dkt_diag_overlap_ubench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+print("two waves per SIMD (ticks per instruction; waves 0-3 | waves 4-7):")
+for role, name in ((1, "all waves: fp32 MFMA 16x16x4"), (2, "all waves: v_fmac_f32"), (0, "waves 0-3 fp32 MFMA, waves 4-7 v_fmac_f32"),
+                   (3, "waves 0-3 bf16 MFMA 16x16x32, waves 4-7 v_fmac_f32")):
+    out = torch.zeros(256 * 8, device="cuda")
+    for _ in range(2):
+        lib.dkt_diag_overlap_ubench(out.data_ptr(), 256, 1000, role, None)
+    torch.cuda.synchronize()
+    o = out.view(256, 8).mean(0).cpu().numpy()
+    print("  %-52s %.2f | %.2f" % (name, o[:4].mean(), o[4:].mean()))
