@@ -21,6 +21,8 @@ struct MllArgs {
     float* jitter_used;
     int32_t* info;
     float* ws;
+    const int32_t* only_failed;   // generic kernel as the fix-up pass of the blocked path: redo only episodes with a non-zero entry here
+    int b0;                       // first episode of the launch (workgroup x handles episode b0 + x; the workspace is indexed by x)
     int B, C, N, LD;
     float jitter0;
     int max_tries;
@@ -40,3 +42,7 @@ void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int l
 // Blocked path for N > 127 (dkt_mll_big.hip).
 size_t dkt_mll_big_workspace_bytes(int B, int C, int N);
 int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
+// Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes
+// -- with the full jitter-retry ladder -- only the episodes the blocked path reported as failed.  No host synchronisation.
+void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipStream_t st);
+size_t dkt_mll_generic_global_floats(int count, int N);

@@ -32,14 +32,20 @@ inline bool mll_fits_lds(int N) { return (mll_vec_floats(N) + mll_mat_floats(N))
 template <bool GLOBAL>
 __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = a.b0 + blockIdx.x, tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int N = a.N, C = a.C, LD = a.LD, R = N + 1;
+    if (a.only_failed) {                       // fix-up pass of the blocked path: nothing to do for an episode without a failure
+        bool need = false;
+        for (int c = 0; c < C; ++c) need = need || a.only_failed[(size_t)b * C + c] != 0;
+        __syncthreads();                       // every thread has read the flags before anybody rewrites info[]
+        if (!need) return;
+    }
     float* cs = smem;            // [R]  scaled column of the current sweep step
     float* ldiag = cs + R;       // [R]  diag(L)
     float* al = ldiag + R;       // [R]  alpha
     float* red = al + R;         // [32] reduction scratch
-    float* Mw = GLOBAL ? (a.ws + (size_t)b * R * LD) : (red + 32);
+    float* Mw = GLOBAL ? (a.ws + (size_t)blockIdx.x * R * LD) : (red + 32);
 #define MW(p, j) Mw[(p) * LD + (j)]
 
     const float* Eb = a.E + (size_t)b * N * N;
@@ -188,6 +194,13 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
 
 }  // namespace
 
+size_t dkt_mll_generic_global_floats(int count, int N) { return (size_t)count * mll_mat_floats(N); }
+
+void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipStream_t st) {
+    a.b0 = b0; a.ws = ws; a.LD = mll_ld(a.N);
+    hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(count), dim3(256), mll_vec_floats(a.N) * sizeof(float), st, a);
+}
+
 extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
     if (B <= 0 || N <= 0 || C <= 0) return 0;
     if (N + 1 <= 128) return 0;                              // register-resident kernel
@@ -209,7 +222,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.E = E; a.Y = Y; a.y_bstride = y_bstride; a.sv = sv; a.mean = mean; a.noise = noise;
     a.cls_weight = cls_weight; a.logp = logp; a.alpha = alpha; a.L = L; a.W = W; a.dsv = dsv;
     a.dmean = dmean; a.dnoise = dnoise; a.jitter_used = jitter_used; a.info = info;
-    a.ws = (float*)workspace; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
+    a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

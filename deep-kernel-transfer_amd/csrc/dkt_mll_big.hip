@@ -7,7 +7,9 @@
 //     GEMMs over all B x C matrices of a chunk (one launch per block operation, independent of C),
 //   * alpha = V (V^T r), log det from the diagonal of L, the scalar identities of dkt_mll_reg.hip for the hyper-gradients,
 //   * W[b] = sum_c coef_c (alpha_c alpha_c^T - K_c^-1) summed over the classes in a fixed order (deterministic).
-// Jitter retries follow GPyTorch's psd_safe_cholesky per matrix; the host reads one failure counter per attempt.
+// The blocked pass runs WITHOUT jitter (attempt 0 of GPyTorch's psd_safe_cholesky); an episode with a matrix that fails it is redone
+// -- full retry ladder, per matrix -- by the generic kernel in a fix-up launch that exits at once for every other episode:
+// no host read-back, the call stays asynchronous on its stream.
 // Replaces the same reference lines as dkt_mll.hip (methods/DKT.py:161-163,177,187,252-254,265,330).
 #include "dkt_mll.h"
 
@@ -151,20 +153,6 @@ __global__ __launch_bounds__(256) void big_form_kernel(const float* __restrict__
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * N; idx += gridDim.x * 256) {
         const int i = idx / N, j = idx - i * N;
         if (j / nb <= i / nb) K[idx] = s * Eb[idx] + (i == j ? dg : 0.f);
-    }
-}
-
-// after a factorisation attempt: matrices whose info != 0 move to the next jitter level; counts them
-__global__ void big_retry_kernel(const int32_t* __restrict__ info, float* __restrict__ jit, int* __restrict__ attempt_of,
-                                 int* __restrict__ nfail, float jitter0, int max_tries, int nmat) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nmat) return;
-    if (info[m] != 0 && attempt_of[m] < max_tries) {
-        const int a = ++attempt_of[m];
-        float j = jitter0;
-        for (int i = 1; i < a; ++i) j *= 10.f;
-        jit[m] = j;
-        atomicAdd(nfail, 1);
     }
 }
 
@@ -334,29 +322,19 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
     for (int b0 = 0; b0 < a.B; b0 += Bc) {
         const int bcnt = (a.B - b0 < Bc) ? a.B - b0 : Bc;
         const int nmat = bcnt * C;
-        if (hipMemsetAsync(jit, 0, nmat_max * sizeof(float) * 3, st) != hipSuccess) return DKT_ERR_LAUNCH;   // jit, attempt_of, info_m
-        for (int attempt = 0; attempt <= a.max_tries; ++attempt) {
-            hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, b0, C, N, nb);
-            if (hipMemsetAsync(info_m, 0, nmat * sizeof(int32_t), st) != hipSuccess) return DKT_ERR_LAUNCH;
-            // ---- blocked Cholesky, LEFT-looking, with explicit inverses of the diagonal blocks.  Per block column j three
-            //      launches: (a) all row blocks i >= j at once:  A_ij -= sum_{k<j} L_ik L_jk^T  -- the blocks k < j are contiguous
-            //      columns, so this is ONE GEMM with M = N - off(j), K = off(j) (one pass over the result instead of j);
-            //      (b) the diagonal block: L_jj and U_jj = L_jj^-T by the register sweep;  (c) the panel below it, all row
-            //      blocks at once:  L_ij = A_ij U_jj.
-            for (int j = 0; j < nbk; ++j) {
-                if (j > 0)
-                    gemm(st, nmat, false, true, N - off(j), sz(j), off(j), -1.f, blk(Lm, j, 0), N, nn, blk(Lm, j, 0), N, nn, 1.f, blk(Kw, j, j), N, nn);
-                dkt_chol_inv_block_launch(blk(Kw, j, j), N, nn, blk(Lm, j, j), N, nn, blk(Vm, j, j), N, nn, sz(j), off(j), info_m, nmat, st);
-                if (j + 1 < nbk)
-                    gemm(st, nmat, false, false, N - off(j + 1), sz(j), sz(j), 1.f, blk(Kw, j + 1, j), N, nn, blk(Vm, j, j), N, nn, 0.f, blk(Lm, j + 1, j), N, nn);
-            }
-            if (attempt == a.max_tries) break;
-            if (hipMemsetAsync(nfail, 0, sizeof(int), st) != hipSuccess) return DKT_ERR_LAUNCH;
-            hipLaunchKernelGGL(big_retry_kernel, dim3((nmat + 255) / 256), dim3(256), 0, st, info_m, jit, attempt_of, nfail, a.jitter0, a.max_tries, nmat);
-            int h_fail = 0;
-            if (hipMemcpyAsync(&h_fail, nfail, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return DKT_ERR_LAUNCH;
-            if (hipStreamSynchronize(st) != hipSuccess) return DKT_ERR_LAUNCH;
-            if (h_fail == 0) break;
+        if (hipMemsetAsync(jit, 0, nmat_max * sizeof(float) * 3, st) != hipSuccess) return DKT_ERR_LAUNCH;   // jit (stays 0), attempt_of, info_m
+        hipLaunchKernelGGL(big_form_kernel, dim3(32, nmat), dim3(256), 0, st, a.E, a.sv, a.noise, jit, Kw, b0, C, N, nb);
+        // ---- blocked Cholesky, LEFT-looking, with explicit inverses of the diagonal blocks.  Per block column j three
+        //      launches: (a) all row blocks i >= j at once:  A_ij -= sum_{k<j} L_ik L_jk^T  -- the blocks k < j are contiguous
+        //      columns, so this is ONE GEMM with M = N - off(j), K = off(j) (one pass over the result instead of j);
+        //      (b) the diagonal block: L_jj and U_jj = L_jj^-T by the register sweep;  (c) the panel below it, all row
+        //      blocks at once:  L_ij = A_ij U_jj.
+        for (int j = 0; j < nbk; ++j) {
+            if (j > 0)
+                gemm(st, nmat, false, true, N - off(j), sz(j), off(j), -1.f, blk(Lm, j, 0), N, nn, blk(Lm, j, 0), N, nn, 1.f, blk(Kw, j, j), N, nn);
+            dkt_chol_inv_block_launch(blk(Kw, j, j), N, nn, blk(Lm, j, j), N, nn, blk(Vm, j, j), N, nn, sz(j), off(j), info_m, nmat, st);
+            if (j + 1 < nbk)
+                gemm(st, nmat, false, false, N - off(j + 1), sz(j), sz(j), 1.f, blk(Kw, j + 1, j), N, nn, blk(Vm, j, j), N, nn, 0.f, blk(Lm, j + 1, j), N, nn);
         }
         // ---- V = L^-T, upper block triangular: V_jj = U_jj (already in Vm), V_ij = -U_ii sum_{k=i+1..j} L_ki^T V_kj ----
         for (int j = 1; j < nbk; ++j) {
@@ -379,6 +357,13 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
             for (int i = 0; i < nbk; ++i)
                 gemm(st, nmat, false, true, sz(i), off(i) + sz(i), N - off(i), 1.f, blk(Vm, i, i), N, nn, blk(Vm, 0, i), N, nn, 0.f, blk(Kinv, i, 0), N, nn);
             hipLaunchKernelGGL(big_w_kernel, dim3(32, bcnt), dim3(256), 0, st, a, Kinv, al, info_m, b0, nb);
+        }
+        // ---- fix-up: episodes with a failed matrix (info != 0 in the outputs just written) are redone by the generic kernel with
+        //      the jitter ladder 1e-6, 1e-5, 1e-4 per matrix; its global working matrices reuse the Kw / Lm region ----
+        {
+            MllArgs f = a;
+            f.only_failed = a.info;
+            dkt_mll_generic_global_launch(f, b0, bcnt, Kw, st);
         }
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

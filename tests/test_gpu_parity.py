@@ -736,6 +736,48 @@ def test_full_size_properties_cfg2(cuda, unit):
     assert float((z3.grad - 2.5 * z.grad).norm() / (2.5 * z.grad).norm()) < 1e-4
 
 
+@pytest.mark.parametrize("n_way,per", [(20, 21), (20, 16)], ids=["cfg4_n420", "cfg4_n320"])
+def test_full_size_properties_cfg4(cuda, n_way, per):
+    """BASELINE.json configs[4] (20-way, ResNet18 features D = 512; N = 420 as train_loop builds it and the 320 x 320 Gram the
+    config quotes) at a full chunk of the blocked large-N path plus a ragged second chunk: residual K alpha = y - m for every
+    episode and class, symmetric unit-diagonal Gram, bitwise determinism, linearity of the backward, oracle spot checks --
+    through the asynchronous (no host read-back) call."""
+    b, d, c = 132, 512, n_way                      # 128 = one workspace chunk, + 4
+    n = c * per
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    zr = torch.randn(b, n, d, generator=gen)
+    zr = (zr - zr.mean(1, keepdim=True)) / torch.sqrt(zr.var(1, unbiased=False, keepdim=True) + 1e-5)
+    z = torch.nn.functional.normalize(zr, dim=2).to(cuda).requires_grad_(True)
+    y = dev_t(O.one_vs_rest_targets(c, per), cuda)
+    hyp = O.perturbed_hypers(c, 9)
+    sv, mean, noise = dev_t(hyp.outputscale, cuda), dev_t(hyp.mean, cuda), dev_t(hyp.noise, cuda)
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=True)
+    obj.sum().backward()
+    assert int(info.abs().max().item()) == 0 and torch.isfinite(logp).all() and float(jit.abs().max()) == 0.0
+    assert torch.allclose(torch.diagonal(e, dim1=1, dim2=2), torch.ones(b, n, device=cuda), atol=2e-6)
+    assert torch.equal(e, e.transpose(1, 2))
+    worst = 0.0
+    for lo in range(0, b, 33):                     # K alpha = y - m, in slices (20 x 420 x 420 doubles per episode)
+        hi = min(b, lo + 33)
+        k = sv.view(1, c, 1, 1) * e[lo:hi].unsqueeze(1) + noise.view(1, c, 1, 1) * torch.eye(n, device=cuda)
+        r = torch.matmul(k.double(), alpha[lo:hi].double().unsqueeze(-1)).squeeze(-1) - (y.double().unsqueeze(0) - mean.double().view(1, c, 1))
+        worst = max(worst, r.abs().max().item())
+    assert worst < 5e-4
+    z2 = z.detach().clone().requires_grad_(True)
+    obj2, logp2, *_ = ops.episode_loss_linear(z2, y, sv, mean, noise, cw, unit_rows=True)
+    obj2.sum().backward()
+    assert torch.equal(logp, logp2) and torch.equal(z.grad, z2.grad)
+    for i in (0, 127, 131):                        # first chunk, its last episode, the ragged tail
+        ref = O.train_episode(z[i].detach().cpu().numpy().astype(np.float64), c, hyp)
+        assert np.abs((logp[i].cpu().numpy() - ref["logp"]) / ref["logp"]).max() < MLL_RTOL
+        assert rel_l2(z.grad[i].cpu().numpy(), ref["dz"]) < GRAD_RTOL
+    z3 = z.detach().clone().requires_grad_(True)
+    obj3, *_ = ops.episode_loss_linear(z3, y, sv, mean, noise, cw, unit_rows=True)
+    (2.5 * obj3.sum()).backward()
+    assert float((z3.grad - 2.5 * z.grad).norm() / (2.5 * z.grad).norm()) < 1e-4
+
+
 def test_mll_bitwise_stable_next_to_split_gram_kernels(cuda):
     """dkt_mll_f32 on one stream while split Gram kernels run on another (co-resident workgroups on the same CUs): the result
     must be bitwise the single-stream result.  Regression test for the packed row-factor forms."""
