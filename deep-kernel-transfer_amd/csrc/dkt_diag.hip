@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void stream_linear_kernel(const float* __restr
 
 // Read + write ceiling of the Gram-backward pattern: per 64-feature slab every row's 256-byte segment is read and a 256-byte
 // segment of the output row written (no arithmetic, no LDS); `out` must hold B*N*D floats for modes 3 / 4.
+typedef float dg_v4 __attribute__((ext_vector_type(4)));
+// POL: bit 0 = non-temporal stores, bit 1 = non-temporal loads
+template <int POL>
 __global__ __launch_bounds__(448) void copy_slab_kernel(const float* __restrict__ Z, float* __restrict__ out, int N, int D) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* Zb = Z + (size_t)b * N * D;
@@ -48,17 +51,46 @@ __global__ __launch_bounds__(448) void copy_slab_kernel(const float* __restrict_
         for (int idx = tid; idx < N * 16; idx += 448) {
             const int row = idx >> 4, c4 = idx & 15;
             const size_t o = (size_t)row * D + sl * 64 + 4 * c4;
-            *reinterpret_cast<float4*>(Ob + o) = *reinterpret_cast<const float4*>(Zb + o);
+            const dg_v4* src = reinterpret_cast<const dg_v4*>(Zb + o);
+            dg_v4* dst = reinterpret_cast<dg_v4*>(Ob + o);
+            dg_v4 v;
+            if constexpr (POL & 2) v = __builtin_nontemporal_load(src);
+            else v = *src;
+            if constexpr (POL & 1) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
         }
     }
 }
 
+template <int POL>
 __global__ __launch_bounds__(256) void copy_linear_kernel(const float* __restrict__ Z, float* __restrict__ out, int N, int D) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float4* Zb = reinterpret_cast<const float4*>(Z + (size_t)b * N * D);
-    float4* Ob = reinterpret_cast<float4*>(out + (size_t)b * N * D);
+    const dg_v4* Zb = reinterpret_cast<const dg_v4*>(Z + (size_t)b * N * D);
+    dg_v4* Ob = reinterpret_cast<dg_v4*>(out + (size_t)b * N * D);
     const int n4 = N * D / 4;
-    for (int i = tid; i < n4; i += 256) Ob[i] = Zb[i];
+    for (int i = tid; i < n4; i += 256) {
+        dg_v4 v;
+        if constexpr (POL & 2) v = __builtin_nontemporal_load(Zb + i);
+        else v = Zb[i];
+        if constexpr (POL & 1) __builtin_nontemporal_store(v, Ob + i);
+        else Ob[i] = v;
+    }
+}
+
+// read ceiling with non-temporal loads (the slab pattern of the Gram forward, 128-byte row slices)
+__global__ __launch_bounds__(256) void stream_slab_nt_kernel(const float* __restrict__ Z, float* __restrict__ out, int N, int D) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* Zb = Z + (size_t)b * N * D;
+    const int nst = D / 32;
+    float acc = 0.f;
+    for (int st = 0; st < nst; ++st) {
+        for (int idx = tid; idx < N * 8; idx += 256) {
+            const int row = idx >> 3, c4 = idx & 7;
+            const dg_v4 v = __builtin_nontemporal_load(reinterpret_cast<const dg_v4*>(Zb + (size_t)row * D + st * 32 + 4 * c4));
+            acc += v.x + v.y + v.z + v.w;
+        }
+    }
+    if (acc == 123.456f) out[b] = acc;
 }
 
 }  // namespace
@@ -67,8 +99,13 @@ extern "C" int dkt_diag_stream_f32(const float* Z, float* out, int B, int N, int
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL((stream_slab_kernel<128>), dim3(B), dim3(256), 0, st, Z, out, N, D);
     else if (mode == 2) hipLaunchKernelGGL((stream_slab_kernel<256>), dim3(B), dim3(256), 0, st, Z, out, N, D);
-    else if (mode == 3) hipLaunchKernelGGL(copy_slab_kernel, dim3(B), dim3(448), 0, st, Z, out, N, D);
-    else if (mode == 4) hipLaunchKernelGGL(copy_linear_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
+    else if (mode == 3) hipLaunchKernelGGL(copy_slab_kernel<0>, dim3(B), dim3(448), 0, st, Z, out, N, D);
+    else if (mode == 4) hipLaunchKernelGGL(copy_linear_kernel<0>, dim3(B), dim3(256), 0, st, Z, out, N, D);
+    else if (mode == 5) hipLaunchKernelGGL(copy_slab_kernel<1>, dim3(B), dim3(448), 0, st, Z, out, N, D);
+    else if (mode == 6) hipLaunchKernelGGL(copy_slab_kernel<2>, dim3(B), dim3(448), 0, st, Z, out, N, D);
+    else if (mode == 7) hipLaunchKernelGGL(copy_slab_kernel<3>, dim3(B), dim3(448), 0, st, Z, out, N, D);
+    else if (mode == 8) hipLaunchKernelGGL(copy_linear_kernel<3>, dim3(B), dim3(256), 0, st, Z, out, N, D);
+    else if (mode == 9) hipLaunchKernelGGL(stream_slab_nt_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
     else hipLaunchKernelGGL(stream_linear_kernel, dim3(B), dim3(256), 0, st, Z, out, N, D);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

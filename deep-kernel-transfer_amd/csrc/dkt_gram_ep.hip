@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 // absolute error of at most 2^-30 |b| per product -- far below the fp32 resolution of a cosine similarity.
 #define DKT_F16_SCALE 32768.f
 #define DKT_F16_UNSCALE (1.f / (32768.f * 32768.f))
-template <int NT, int NBUF, int PF, int BK = 32, int SPL = 3, int MINWG = ((NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2)>
+template <int NT, int NBUF, int PF, int BK = 32, int SPL = 3, int MINWG = ((NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2), int POL = 0>
 __global__ __launch_bounds__(256, MINWG) void gram_sym_ep_split_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
     constexpr int NP = 16 * NT;
     constexpr int SPLD = BK + 16;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, MINWG) void gram_sym_ep_split_kernel(const flo
         for (int i = 0; i < NLD; ++i) {
             int vo = voff[i];
             if (ragged) vo = (k0 + 4 * ((tid + 256 * i) % V4_PER_ROW) < D) ? vo : 0x7ffffff0;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, vo, k0 * 4, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, vo, k0 * 4, (POL & 2) ? 2 : 0);
             rg[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -580,7 +580,8 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
 //   * the A operand s (W + W^T) has no a-priori range, so every ROW is scaled by its own power of two (row maximum ->
 //     [2^14, 2^15)) before the split -- exact, and undone per output row in the epilogue together with the 2^-15 of Z;
 //   * the staging copy of W shares the LDS with both stage buffers (74 KB, 2 workgroups per CU).
-template <int NT, int NBUF, int PF>
+//   * POL (measurement variants): bit 0 = non-temporal dZ stores, bit 1 = non-temporal Z loads (aux = 2)
+template <int NT, int NBUF, int PF, int POL = 0>
 __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
                                                                       float* __restrict__ dZ, int N, int D,
                                                                       const float* __restrict__ ep_scale) {
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
         const bool in = d0 + 4 * d4 < D;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, in ? voff[rr] : 0x7ffffff0, d0 * 4, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, in ? voff[rr] : 0x7ffffff0, d0 * 4, (POL & 2) ? 2 : 0);
             rg[rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -704,9 +705,12 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
         for (int reg = 0; reg < 4; ++reg) {
             const int row = wave * 16 + 4 * q + reg;
             const float u = rowinv[row];
-            if (row < N && d < D)
-                *reinterpret_cast<float4*>(dZb + (size_t)row * D + d) =
-                    make_float4(acc[0][reg] * u, acc[1][reg] * u, acc[2][reg] * u, acc[3][reg] * u);
+            if (row < N && d < D) {
+                const f32x4 o = {acc[0][reg] * u, acc[1][reg] * u, acc[2][reg] * u, acc[3][reg] * u};
+                f32x4* dst = reinterpret_cast<f32x4*>(dZb + (size_t)row * D + d);
+                if constexpr (POL & 1) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
+            }
         }
     };
     auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
@@ -750,7 +754,7 @@ struct GramEnv {
         ep = get("DKT_GRAM_EP", 1); minb = get("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
         ep_bk = get("DKT_GRAM_EP_BK", 64); ep_bd = get("DKT_GRAM_EP_BD", 32);
         unit_var = get("DKT_GRAM_UNIT_VAR", 2223); split_var = get("DKT_GRAM_SPLIT_VAR", 11);
-        bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 222); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
+        bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 1222); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
         bwd_unit_mind = get("DKT_GRAM_BWD_UNIT_MIND", 64); bwd_split_mind = get("DKT_GRAM_BWD_SPLIT_MIND", 1024);
     }
 };
@@ -777,6 +781,7 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit
         else if (v == 26114) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 4>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 26122) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 2223) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        else if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 2213) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else if (v == 2115) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2, 5>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
@@ -790,6 +795,9 @@ void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, 
         // <LDS buffers><prefetch depth> of the bf16 split; 2xx = scaled-f16 split (unit-norm rows of Z only)
         const int v = unit ? gram_env().bwd_unit_var : gram_env().bwd_split_var;
         if (v == 222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 2222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 3222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 3>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 221) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 212) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 211) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
