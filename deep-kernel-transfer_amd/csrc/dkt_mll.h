@@ -42,6 +42,10 @@ void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int l
 // Blocked path for N > 127 (dkt_mll_big.hip).
 size_t dkt_mll_big_workspace_bytes(int B, int C, int N);
 int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
+// Tile-array path for N > 127 (dkt_mll_tiled.hip; the default there unless the Cholesky factors are requested).
+bool dkt_mll_tiled_supports(int N, unsigned flags);
+size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
+int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes
 // -- with the full jitter-retry ladder -- only the episodes the blocked path reported as failed.  No host synchronisation.
 void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipStream_t st);

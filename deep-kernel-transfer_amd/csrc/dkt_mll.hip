@@ -206,7 +206,9 @@ extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
     if (N + 1 <= 128) return 0;                              // register-resident kernel
     const size_t big = dkt_mll_big_workspace_bytes(B, C, N); // blocked path; also covers the generic kernel's global matrices
     const size_t gen = mll_fits_lds(N) ? 0 : (size_t)B * mll_mat_floats(N) * sizeof(float);
-    return big > gen ? big : gen;
+    const size_t til = dkt_mll_tiled_supports(N, 0) ? dkt_mll_tiled_workspace_bytes(B, C, N) : 0;
+    const size_t mx = big > gen ? big : gen;
+    return mx > til ? mx : til;
 }
 
 extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv, const float* mean,
@@ -227,6 +229,9 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags) && workspace &&
+        workspace_bytes >= dkt_mll_tiled_workspace_bytes(B, C, N))
+        return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
     if (!(flags & DKT_MLL_FORCE_GENERIC) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))
         return dkt_mll_big_launch(a, workspace, workspace_bytes, st);
     if (mll_fits_lds(N)) {

@@ -1,0 +1,562 @@
+// dkt_mll_tiled.hip -- exact-GP marginal likelihood for N + 1 > 128 (the 20-way shapes: N = 320 / 420, C = 20), the algorithm of
+// dkt_mll_mfma.hip with the 16 x 16 tiles of every class matrix in a TILE ARRAY in memory instead of VGPRs.
+//
+// Replaces the same reference lines as dkt_mll_mfma.hip (methods/DKT.py:161-163, 177, 187, 252-254, 265, 330): GPyTorch's
+// psd_safe_cholesky / inv_quad_logdet / cholesky_solve and their backward for the C one-vs-rest models K_c = sv_c E + noise_c I.
+//
+// Storage: per (episode, class) matrix the upper block triangle of the (N+1)-augmented, 16-padded matrix as NT (NT+1) / 2 tiles of
+// 1 KB in the MFMA accumulator layout (lane l holds the 16 bytes at 16 l: element [4g + q][c], l = 16 g + c), tile rows contiguous.
+// A tile is therefore ONE coalesced 1-KB load straight into MFMA operand registers -- no LDS staging, no transposes -- and every
+// product is D += X^T Y = 4 x v_mfma_f32_16x16x4_f32 (dkt_mfma_tiles.h).  Three kernels, all LEFT-looking (every tile is written
+// once; what a step needs from earlier steps is read back through L2 / MALL), 4 waves per workgroup, each wave a register block of
+// 4 x MC accumulator tiles against 4 + MC operand tiles per step (double-buffered loads, no barriers in the K loops):
+//   tiled_factor_kernel  (workgroup = matrix): block row I of 4 tile rows.  S_ij = form(E)_ij + sum_{k < i0} R_ki^T R_kj for the
+//       wave's columns j = i0 + w (mod 4), then the 4 tile rows of the block one after the other: the diagonal tile is swept by
+//       its owner (M_ii = R_ii^-T, pivots -> log det, first bad pivot, the quadratic form at the augmented pivot), M_ii goes
+//       through LDS, every wave turns its tiles of the row into R_ij = (-V_ii)^T S_ij and applies them to the block's later rows.
+//   tiled_invert_kernel  (workgroup = matrix): M = R^-T in place, block column J: slot (i, j) <- M_ji =
+//       (-V_jj)^T sum_{i <= k < j} R_kj^T M_ki for the wave's rows i = w (mod 4); the columns of the block one after the other
+//       (a column needs the finished ones of the same rows: registers of the same wave).  Row N of M is -alpha^T; the trace of
+//       K^-1 - alpha alpha^T for the hyper-gradients is summed as the tiles become final; logp / gradients scalars are written here.
+//   tiled_w_kernel       (workgroup = episode x block column of W): W_ij = sum_c coef_c sum_{k >= j} flip(M_ki)^T M_kj accumulated
+//       over the classes IN REGISTERS and stored once (tile + mirror).
+// The pass runs without jitter (attempt 0 of psd_safe_cholesky); an episode with a failed matrix is redone -- jitter ladder and all --
+// by the generic kernel in a fix-up launch (dkt_mll.hip), exactly as the blocked path does.  No host read-back.
+#include "dkt_mfma_tiles.h"
+
+namespace {
+
+using namespace dkt_mfma;
+
+constexpr int TB = 4;                         // tile rows / columns per block = waves per workgroup
+
+struct TiledScal {                            // per matrix, factor -> invert -> w
+    float lsum2, quad, coef;
+    int msc, fail_at;
+};
+
+struct TiledArgs {
+    MllArgs a;
+    float* tiles;                             // [nmat][NTT][256]
+    TiledScal* scal;                          // [nmat]
+    int b0, NT;
+};
+
+__device__ __forceinline__ int tslot(const int NT, const int i, const int j) { return i * NT - (i * (i - 1)) / 2 + (j - i); }      // i <= j
+__device__ __forceinline__ int toff(const int NT, const int i, const int j, const int lane) { return (tslot(NT, i, j) * 64 + lane) * 16; }
+
+struct Geo {
+    int lane, c16, g4, pN, N, NT;
+    Lane ln;
+};
+__device__ __forceinline__ Geo make_geo(const int tid, const int N, const int NT) {
+    Geo g;
+    g.lane = tid & 63; g.c16 = tid & 15; g.g4 = (tid >> 2) & 12; g.N = N; g.NT = NT;
+    g.pN = N - 16 * (NT - 1);
+    g.ln.lane = g.lane; g.ln.g = g.g4 >> 2; g.ln.c = g.c16;
+    g.ln.g0 = g.ln.g == 0; g.ln.g1 = g.ln.g == 1; g.ln.g2 = g.ln.g == 2;
+    return g;
+}
+
+struct FormRt {
+    brsrc Er, yr;
+    float nsv, dg, mc, rsc;
+};
+
+// Tile (i, j), i <= j, of S = -K' / kappa in the accumulator layout straight from E[b] (symmetric: element [4g+q][c] =
+// E[16j + c][16i + 4g + q], one 16-byte load per lane); the augmented column / row, its zero pivot and the identity padding as in
+// form_tile of dkt_mll_mfma.hip.
+__device__ __forceinline__ f32x4 form_tile_rt(const FormRt& f, const Geo& g, const int i, const int j) {
+    const int NT = g.NT, N = g.N, pN = g.pN, c16 = g.c16, g4 = g.g4;
+    const int row = 16 * j + c16;
+    const bool row_ok = (j < NT - 1) || (c16 < pN);
+    f32x4 e;
+    if (i < NT - 1) {
+        e = bload4(f.Er, row_ok ? (row * N + 16 * i + g4) * 4 : OOB, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.Er, (row_ok && g4 + q < pN) ? (row * N + 16 * i + g4 + q) * 4 : OOB, 0, 0));
+    }
+    f32x4 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = f.nsv * e[q];
+        if (i == j) v = (g4 + q == c16) ? v + f.dg : v;
+        s[q] = v;
+    }
+    if (j == NT - 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * i + g4 + q;
+            const float yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.yr, (c16 == pN && r < N) ? r * 4 : OOB, 0, 0));
+            s[q] = (c16 == pN) ? ((r < N) ? (f.mc - yv) * f.rsc : 0.f) : s[q];
+        }
+        if (i == NT - 1) {
+            const float yc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.yr, (c16 < pN) ? (16 * i + c16) * 4 : OOB, 0, 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = s[q];
+                v = (g4 + q == pN) ? ((c16 < pN) ? (f.mc - yc) * f.rsc : 0.f) : v;
+                v = (g4 + q > pN) ? ((g4 + q == c16) ? -1.0f : 0.f) : v;
+                s[q] = v;
+            }
+        }
+    }
+    return s;
+}
+
+__device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
+    f32x4 n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n[q] = (g.g4 + q == g.c16) ? -1.0f : 0.0f;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Factorisation.  Wave w owns the tile columns j = i0 + w + 4 bb of block row I.
+template <int MC>
+__global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
+    __shared__ f32x4 mbuf[64];
+    __shared__ f32x4 xbuf[TB][64];
+    __shared__ float red[TB];
+    __shared__ float lsum_w[TB];
+    __shared__ int fail_w[TB];
+    const MllArgs& a = t.a;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, NT = t.NT, C = a.C;
+    const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
+    const Geo g = make_geo(tid, N, NT);
+    const int lane = g.lane;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2;
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * ntt * 256, (unsigned)(ntt * 1024));
+    const float* Eb = a.E + (size_t)b * N * N;
+    // kappa = 4^msc >= max_i K_ii
+    float emax = 0.f;
+    for (int i = tid; i < N; i += 64 * TB) emax = fmaxf(emax, Eb[(size_t)i * (N + 1)]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emax = fmaxf(emax, __shfl_xor(emax, o, DKT_WAVE));
+    if (lane == 0) red[w] = emax;
+    __syncthreads();
+    emax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
+    int ex;
+    (void)frexpf(fmaf(svc, emax, nzc), &ex);
+    const int msc = max(0, (ex + 1) >> 1);
+    const float ikap = ldexpf(1.0f, -2 * msc);
+    FormRt f;
+    f.Er = mk_rsrc(Eb, (unsigned)((size_t)N * N * 4));
+    f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
+    f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc);
+    const f32x4 negI = neg_identity(g);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    int fail_at = 0;
+    float lsum = 0.f, quad = 0.f;
+    for (int i0 = 0; i0 < NT; i0 += TB) {
+        f32x4 acc[TB][MC];
+        // ---- init from E ----
+#pragma unroll
+        for (int r = 0; r < TB; ++r)
+#pragma unroll
+            for (int bb = 0; bb < MC; ++bb) {
+                const int i = i0 + r, j = i0 + w + TB * bb;
+                acc[r][bb] = (i < NT && j < NT && j >= i) ? form_tile_rt(f, g, i, j) : zero4;
+            }
+        // ---- K loop over the finished tile rows, operands double-buffered ----
+        auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int kt) {
+            const bool kin = kt < i0;
+#pragma unroll
+            for (int r = 0; r < TB; ++r) X[r] = bload4(Tr, (kin && i0 + r < NT) ? toff(NT, kt, i0 + r, lane) : OOB, 0);
+#pragma unroll
+            for (int bb = 0; bb < MC; ++bb) {
+                const int j = i0 + w + TB * bb;
+                Y[bb] = bload4(Tr, (kin && j < NT) ? toff(NT, kt, j, lane) : OOB, 0);
+            }
+        };
+        auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC]) {
+#pragma unroll
+            for (int bb = 0; bb < MC; ++bb) {
+                if (i0 + w + TB * bb < NT) {
+#pragma unroll
+                    for (int r = 0; r < TB; ++r) acc[r][bb] = xty(X[r], Y[bb], acc[r][bb]);
+                }
+            }
+        };
+        if (i0 > 0) {
+            f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
+            loadk(X0, Y0, 0);
+            for (int kt = 0; kt < i0; kt += 2) {
+                loadk(X1, Y1, kt + 1);
+                mulk(X0, Y0);
+                loadk(X0, Y0, kt + 2);
+                mulk(X1, Y1);
+            }
+        }
+        // ---- the block's tile rows ----
+#pragma unroll
+        for (int r = 0; r < TB; ++r) {
+            const int i = i0 + r;
+            if (i < NT) {                                                   // uniform
+                if (w == r) {
+                    float x[16], dv;
+                    sweep_begin(acc[r][0], x, dv);
+                    const bool last = i == NT - 1;
+                    if (last) sweep_plain<0, true>(x, dv, g.ln, g.pN);
+                    else sweep_plain<0, false>(x, dv, g.ln, g.pN);
+                    const f32x4 M = sweep_end(x, g.ln);
+                    const bool valid = !last || (g.c16 < g.pN);
+                    const unsigned long long badm = __ballot(valid && !(dv > 0.f)) & 0xffffull;
+                    const int first = (int)__builtin_ctzll(badm | 0x10000ull);
+                    fail_at = (fail_at == 0 && badm != 0) ? 16 * i + first + 1 : fail_at;
+                    lsum += (valid && g.ln.g0) ? __builtin_amdgcn_logf(dv) : 0.f;
+                    if (last) quad = -__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), g.pN));
+                    mbuf[lane] = M;
+                    acc[r][0] = M;                                          // the diagonal slot keeps M_ii
+                }
+                __syncthreads();
+                const f32x4 nV = xty0(mbuf[lane], negI);
+#pragma unroll
+                for (int bb = 0; bb < MC; ++bb) {
+                    const int j = i0 + w + TB * bb;
+                    if (j > i && j < NT) acc[r][bb] = xty0(nV, acc[r][bb]);
+                }
+                if (w > r && i0 + w < NT) xbuf[w][lane] = acc[r][0];       // R(i, i0 + w): the X operand of block row w's update
+                __syncthreads();
+#pragma unroll
+                for (int r2 = r + 1; r2 < TB; ++r2) {
+                    if (i0 + r2 < NT) {
+                        const f32x4 X = xbuf[r2][lane];
+#pragma unroll
+                        for (int bb = 0; bb < MC; ++bb) {
+                            const int j = i0 + w + TB * bb;
+                            if (j >= i0 + r2 && j < NT) acc[r2][bb] = xty(X, acc[r][bb], acc[r2][bb]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- store the block row ----
+#pragma unroll
+        for (int r = 0; r < TB; ++r)
+#pragma unroll
+            for (int bb = 0; bb < MC; ++bb) {
+                const int i = i0 + r, j = i0 + w + TB * bb;
+                bstore4(Tr, acc[r][bb], (i < NT && j < NT && j >= i) ? toff(NT, i, j, lane) : OOB, 0);
+            }
+        __syncthreads();                                                    // visible to every wave's loads of the next block row
+    }
+    // ---- per-matrix scalars ----
+    lsum = wave_allsum(lsum);
+    if (lane == 0) { lsum_w[w] = lsum; fail_w[w] = fail_at; }
+    if (w == ((NT - 1) & (TB - 1)) && lane == 0) red[0] = quad;            // the owner of the last diagonal tile
+    __syncthreads();
+    if (tid == 0) {
+        int fa = 0;
+        for (int k = 0; k < TB; ++k) fa = (fail_w[k] != 0 && (fa == 0 || fail_w[k] < fa)) ? fail_w[k] : fa;
+        TiledScal s;
+        s.lsum2 = lsum_w[0] + lsum_w[1] + lsum_w[2] + lsum_w[3] + (float)(2 * msc * N);
+        s.quad = red[0];
+        s.coef = 0.f;
+        s.msc = msc;
+        s.fail_at = fa;
+        t.scal[m] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// M = R^-T in place.  Wave w owns the tile rows i = w + 4 aa of block column J.
+template <int MC, bool GRAD>
+__global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
+    __shared__ float tr_w[TB], as_w[TB];
+    const MllArgs& a = t.a;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, NT = t.NT, C = a.C;
+    const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
+    const Geo g = make_geo(tid, N, NT);
+    const int lane = g.lane, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2;
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * ntt * 256, (unsigned)(ntt * 1024));
+    const size_t bc = (size_t)b * C + c;
+    const brsrc ar = mk_rsrc(a.alpha + bc * N, (unsigned)(N * 4));
+    const TiledScal sc = t.scal[m];
+    const float rsc = ldexpf(1.0f, -sc.msc);
+    const float qnan = __int_as_float(0x7fc00000);
+    const bool failed = sc.fail_at != 0;
+    const f32x4 negI = neg_identity(g);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool arow = (g.ln.g == (pN >> 2));
+    const int qn = pN & 3;
+    float trpp = 0.f, asum = 0.f;
+
+    // trace of flip(M)^T M over the real columns, the part of one final tile: rows 16 j + 4g + q, columns 16 i + c
+    auto trace_tile = [&](const f32x4 v, const int i, const int j) {
+        const bool col_ok = 16 * i + c16 < N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * j + g4 + q;
+            const float s = (row == N) ? -1.0f : 1.0f;
+            trpp += col_ok ? s * v[q] * v[q] : 0.f;
+        }
+    };
+    auto alpha_tile = [&](const f32x4 v, const int i) {                    // tile of block row NT - 1: its row pN is -alpha^T (scaled)
+        const float x = -(qn == 0 ? v[0] : qn == 1 ? v[1] : qn == 2 ? v[2] : v[3]) * rsc;
+        const bool ok = arow && (16 * i + c16 < N);
+        bstore1(ar, failed ? qnan : x, ok ? (16 * i + c16) * 4 : OOB, 0);
+        asum += ok ? x : 0.f;
+    };
+
+    for (int j0 = 0; j0 < NT; j0 += TB) {
+        f32x4 acc[MC][TB];
+#pragma unroll
+        for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+            for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = zero4;
+        // ---- K loop over the finished columns k < j0:  acc(i, j) += R_kj^T M_ki  (slot (i, k); the diagonal slot is M_ii) ----
+        auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int k) {
+            const bool kin = k < j0;
+#pragma unroll
+            for (int jj = 0; jj < TB; ++jj) X[jj] = bload4(Tr, (kin && j0 + jj < NT) ? toff(NT, k, j0 + jj, lane) : OOB, 0);
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa) {
+                const int i = w + TB * aa;
+                Y[aa] = bload4(Tr, (kin && i <= k) ? toff(NT, i, k, lane) : OOB, 0);
+            }
+        };
+        auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC], const int k) {
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa) {
+                if (w + TB * aa <= k) {
+#pragma unroll
+                    for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = xty(X[jj], Y[aa], acc[aa][jj]);
+                }
+            }
+        };
+        if (j0 > 0) {
+            f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
+            loadk(X0, Y0, 0);
+            for (int k = 0; k < j0; k += 2) {
+                loadk(X1, Y1, k + 1);
+                mulk(X0, Y0, k);
+                loadk(X0, Y0, k + 2);
+                mulk(X1, Y1, k + 1);
+            }
+        }
+        // ---- the block's columns, one after the other ----
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+            const int j = j0 + jj;
+            if (j < NT) {                                                   // uniform
+#pragma unroll
+                for (int kk = 0; kk < jj; ++kk) {
+                    const int k = j0 + kk;
+                    const f32x4 Xk = bload4(Tr, toff(NT, k, j, lane), 0);                     // R_kj of the diagonal block (still original)
+                    const f32x4 Mkk = bload4(Tr, (w == kk) ? toff(NT, k, k, lane) : OOB, 0);    // row i = k belongs to wave kk
+#pragma unroll
+                    for (int aa = 0; aa < MC; ++aa) {
+                        const int i = w + TB * aa;
+                        if (i <= k) acc[aa][jj] = xty(Xk, (i == k) ? Mkk : acc[aa][kk], acc[aa][jj]);
+                    }
+                }
+                const f32x4 Mjj = bload4(Tr, toff(NT, j, j, lane), 0);
+                const f32x4 nV = xty0(Mjj, negI);
+#pragma unroll
+                for (int aa = 0; aa < MC; ++aa) {
+                    const int i = w + TB * aa;
+                    if (i < j) {
+                        acc[aa][jj] = xty0(nV, acc[aa][jj]);
+                        if constexpr (GRAD) trace_tile(acc[aa][jj], i, j);
+                        if (j == NT - 1) alpha_tile(acc[aa][jj], i);
+                    }
+                }
+                if (w == jj) {                                              // the diagonal tile of column j: trace / alpha once
+                    if constexpr (GRAD) trace_tile(Mjj, j, j);
+                    if (j == NT - 1) alpha_tile(Mjj, j);
+                }
+            }
+        }
+        __syncthreads();                                                    // every wave has read the block's R tiles
+#pragma unroll
+        for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+            for (int jj = 0; jj < TB; ++jj) {
+                const int i = w + TB * aa, j = j0 + jj;
+                bstore4(Tr, acc[aa][jj], (j < NT && i < j) ? toff(NT, i, j, lane) : OOB, 0);
+            }
+        __syncthreads();
+    }
+    trpp = wave_allsum(trpp);
+    asum = wave_allsum(asum);
+    if (lane == 0) { tr_w[w] = trpp; as_w[w] = asum; }
+    __syncthreads();
+    if (tid == 0) {
+        const float tr = (tr_w[0] + tr_w[1] + tr_w[2] + tr_w[3]) * ldexpf(1.0f, -2 * sc.msc);
+        const float as = as_w[0] + as_w[1] + as_w[2] + as_w[3];
+        const float svc = a.sv[c], nzc = a.noise[c];
+        const bool ok = !failed;
+        a.logp[bc] = ok ? (-0.5f * sc.quad - 0.34657359027997264f * sc.lsum2 - (float)N * DKT_HALF_LOG_2PI) : qnan;
+        a.jitter_used[bc] = 0.f;
+        a.info[bc] = sc.fail_at;
+        if constexpr (GRAD) {
+            a.dmean[bc] = ok ? as : qnan;
+            a.dnoise[bc] = ok ? -0.5f * tr : qnan;
+            a.dsv[bc] = ok ? 0.5f * ((sc.quad - (float)N) + nzc * tr) / svc : qnan;
+            const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
+            t.scal[m].coef = ok ? -0.5f * cw * svc * ldexpf(1.0f, -2 * sc.msc) : qnan;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// W[b] = sum_c coef_c (K_c^-1 - alpha_c alpha_c^T)_s:  output block column J (grid x), episode (grid y); wave w owns rows i = w + 4 aa.
+template <int MC>
+__global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
+    const MllArgs& a = t.a;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, NT = t.NT, C = a.C;
+    const int j0 = blockIdx.x * TB, bl = blockIdx.y, b = t.b0 + bl;
+    const Geo g = make_geo(tid, N, NT);
+    const int lane = g.lane, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sgn;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sgn[q] = (g4 + q == pN) ? -1.0f : 1.0f;
+    f32x4 acc[MC][TB];
+#pragma unroll
+    for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = zero4;
+    const int jmax = min(j0 + TB, NT) - 1;                                  // last column of the block
+    for (int c = 0; c < C; ++c) {
+        const size_t m = (size_t)bl * C + c;
+        const brsrc Tr = mk_rsrc(t.tiles + m * ntt * 256, (unsigned)(ntt * 1024));
+        const float coef = t.scal[m].coef;
+        auto loadk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB], const int k) {
+            const bool kin = k < NT;
+#pragma unroll
+            for (int jj = 0; jj < TB; ++jj) {
+                const int j = j0 + jj;
+                Bt[jj] = bload4(Tr, (kin && j <= k) ? toff(NT, j, k, lane) : OOB, 0);          // M_kj (the diagonal slot for k = j)
+            }
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa) {
+                const int i = w + TB * aa;
+                A[aa] = bload4(Tr, (kin && i <= jmax && i <= k) ? toff(NT, i, k, lane) : OOB, 0);
+            }
+        };
+        auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB], const int k) {
+#pragma unroll
+            for (int jj = 0; jj < TB; ++jj) Bt[jj] *= coef;
+            if (k == NT - 1) {
+#pragma unroll
+                for (int aa = 0; aa < MC; ++aa) A[aa] *= sgn;
+            }
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa) {
+                if (w + TB * aa <= jmax) {
+#pragma unroll
+                    for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = xty(A[aa], Bt[jj], acc[aa][jj]);
+                }
+            }
+        };
+        f32x4 A0[MC], B0[TB], A1[MC], B1[TB];
+        loadk(A0, B0, j0);
+        for (int k = j0; k < NT; k += 2) {
+            loadk(A1, B1, k + 1);
+            mulk(A0, B0, k);
+            loadk(A0, B0, k + 2);
+            mulk(A1, B1, k + 1);
+        }
+    }
+    // ---- store: tile (i, j) and its mirror ----
+    const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
+#pragma unroll
+    for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+            const int i = w + TB * aa, j = j0 + jj;
+            if (j < NT && i <= j) {                                         // uniform
+                const f32x4 v = acc[aa][jj];
+                const bool col_ok = 16 * j + c16 < N;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // a diagonal tile is stored from its upper half only (element and mirror image from the same register: W[b] is
+                    // bitwise symmetric although the two halves of the accumulator were summed in different orders)
+                    const bool row_ok = 16 * i + g4 + q < N && (i < j || g4 + q <= c16);
+                    bstore1(Wr, v[q], (row_ok && col_ok) ? ((16 * i + g4 + q) * N + 16 * j + c16) * 4 : OOB, 0);
+                    if (i == j) bstore1(Wr, v[q], (row_ok && col_ok && g4 + q < c16) ? ((16 * j + c16) * N + 16 * i + g4 + q) * 4 : OOB, 0);
+                }
+                if (i < j) bstore4(Wr, v, col_ok ? ((16 * j + c16) * N + 16 * i + g4) * 4 : OOB, 0);   // i < j <= NT - 1: 16 i + g4 + 3 < N
+            }
+        }
+}
+
+inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
+inline size_t tiled_ws_floats(int Bc, int C, int N) {
+    const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
+    size_t fl = nmat * ntt * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
+    const size_t gen = dkt_mll_generic_global_floats(Bc, N);               // the fix-up pass works in the same region
+    return fl > gen ? fl : gen;
+}
+constexpr int TILED_CHUNK = 256;           // episodes per pass over the workspace
+
+template <int MC>
+void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
+    const int nmat = bcnt * t.a.C;
+    hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(nmat), dim3(64 * TB), 0, st, t);
+    if (grad) {
+        hipLaunchKernelGGL((tiled_invert_kernel<MC, true>), dim3(nmat), dim3(64 * TB), 0, st, t);
+        hipLaunchKernelGGL((tiled_w_kernel<MC>), dim3((t.NT + TB - 1) / TB, bcnt), dim3(64 * TB), 0, st, t);
+    } else {
+        hipLaunchKernelGGL((tiled_invert_kernel<MC, false>), dim3(nmat), dim3(64 * TB), 0, st, t);
+    }
+}
+
+}  // namespace
+
+bool dkt_mll_tiled_supports(int N, unsigned flags) {
+    return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
+}
+
+size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N) {
+    const int bc = B < TILED_CHUNK ? B : TILED_CHUNK;
+    return tiled_ws_floats(bc, C, N) * sizeof(float);
+}
+
+// Returns 0 on success, a negative DKT status otherwise.
+int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st) {
+    const int N = a.N, C = a.C;
+    if (!workspace || ws_bytes < dkt_mll_tiled_workspace_bytes(a.B, C, N)) return DKT_ERR_WORKSPACE;
+    const int NT = tiled_nt(N);
+    const int Bc = a.B < TILED_CHUNK ? a.B : TILED_CHUNK;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2, nmat_max = (size_t)Bc * C;
+    TiledArgs t;
+    t.a = a;
+    t.tiles = (float*)workspace;
+    t.scal = (TiledScal*)(t.tiles + nmat_max * ntt * 256);
+    t.NT = NT;
+    const bool grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
+    const int mc = (NT + TB - 1) / TB;
+    for (int b0 = 0; b0 < a.B; b0 += Bc) {
+        const int bcnt = (a.B - b0 < Bc) ? a.B - b0 : Bc;
+        t.b0 = b0;
+        switch (mc) {
+            case 3: tiled_chunk<3>(t, bcnt, grad, st); break;
+            case 4: tiled_chunk<4>(t, bcnt, grad, st); break;
+            case 5: tiled_chunk<5>(t, bcnt, grad, st); break;
+            case 6: tiled_chunk<6>(t, bcnt, grad, st); break;
+            case 7: tiled_chunk<7>(t, bcnt, grad, st); break;
+            default: return DKT_ERR_BAD_ARG;
+        }
+        // fix-up: episodes with a failed matrix are redone by the generic kernel with the jitter ladder (its global working
+        // matrices reuse the tile region, which is dead by now)
+        MllArgs f = a;
+        f.only_failed = a.info;
+        dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -29,6 +29,7 @@ MLL_WANT_GRAD = 1
 MLL_WANT_CHOL = 2
 MLL_FORCE_GENERIC = 4
 MLL_FORCE_REG = 8
+MLL_FORCE_BLOCKED = 16
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -142,7 +143,8 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
 
 def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
-        jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False) -> dict:
+        jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False,
+        force_blocked: bool = False) -> dict:
     """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N]."""
     e = _req(e, "e", 3)
     b_, n, n2 = e.shape
@@ -167,7 +169,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
-    flags = (MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0)
+    flags = (MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0)
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL

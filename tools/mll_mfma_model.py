@@ -174,3 +174,109 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Large-N tiled path (csrc/dkt_mll_tiled.hip): the same three phases LEFT-looking over a tile array in memory
+# (slot (i, j), i <= j; diagonal slot (i, i) holds M_ii = R_ii^-T after phase 1), block rows / block columns of RB tiles.
+def run_tiled(N, K, rvec, RB=4):
+    NT = (N + 1 + 15) // 16
+    NP = 16 * NT
+    pN = N - 16 * (NT - 1)
+    e = int(np.frexp(np.diag(K).max())[1])
+    m = max(0, (e + 1) // 2)
+    kappa = 4.0 ** m
+    Sfull = np.zeros((NP, NP))
+    Sfull[:N, :N] = -K / kappa
+    Sfull[:N, N] = -rvec / 2.0 ** m
+    Sfull[N, :N] = -rvec / 2.0 ** m
+    for p in range(N + 1, NP):
+        Sfull[p, p] = -1.0
+    form = lambda i, j: tile_to_acc(Sfull[16 * i:16 * i + 16, 16 * j:16 * j + 16])
+    negI = tile_to_acc(-np.eye(16))
+    G_ = {}                                              # the tile array in memory
+    logdet, quad = 0.0, None
+    # ---- K1: factorisation, block row I ----
+    for i0 in range(0, NT, RB):
+        rows = range(i0, min(i0 + RB, NT))
+        acc = {(i, j): form(i, j) for i in rows for j in range(i0, NT)}        # (the strictly lower part of the diagonal block is unused)
+        for kt in range(i0):
+            for i in rows:
+                for j in range(i0, NT):
+                    acc[(i, j)] = xty(G_[(kt, i)], G_[(kt, j)], acc[(i, j)])
+        for i in rows:
+            last = i == NT - 1
+            M, dv, _ = sweep(acc[(i, i)], pN if last else None)
+            valid = (16 * i + Cc) < N
+            logdet += np.sum(np.log(dv[:16])[valid[:16]])
+            if last:
+                quad = -dv[pN]
+            nV = xty(M, negI)
+            for j in range(i + 1, NT):
+                acc[(i, j)] = xty(nV, acc[(i, j)])
+            acc[(i, i)] = M
+            for i2 in rows:
+                if i2 > i:
+                    for j in range(i2, NT):
+                        acc[(i2, j)] = xty(acc[(i, i2)], acc[(i, j)], acc[(i2, j)])
+        for i in rows:
+            for j in range(i, NT):
+                G_[(i, j)] = acc[(i, j)]
+    # ---- K2: M = R^-T, block column J; slot (i, j) <- M_ji ----
+    alpha = np.zeros(NP)
+    for j0 in range(0, NT, RB):
+        cols = range(j0, min(j0 + RB, NT))
+        acc = {(i, j): np.zeros((4, 64)) for j in cols for i in range(j)}
+        Rblk = {(k, j): G_[(k, j)] for j in cols for k in range(j0, j)}         # diagonal-block R tiles, read before anything is stored
+        for k in range(j0):                                                     # previous columns are final
+            for j in cols:
+                for i in range(k + 1):
+                    acc[(i, j)] = xty(G_[(k, j)], G_[(i, k)], acc[(i, j)])     # slot (i, i) = M_ii, slot (i, k) = M_ki
+        fin = {}
+        for j in cols:
+            for k in range(j0, j):
+                for i in range(k + 1):
+                    Mki = G_[(k, k)] if i == k else fin[(i, k)]
+                    acc[(i, j)] = xty(Rblk[(k, j)], Mki, acc[(i, j)])
+            nV = xty(G_[(j, j)], negI)
+            for i in range(j):
+                fin[(i, j)] = xty(nV, acc[(i, j)])
+        for (i, j), v in fin.items():
+            G_[(i, j)] = v
+    for i in range(NT - 1):
+        alpha[16 * i:16 * i + 16] = -acc_to_tile(G_[(i, NT - 1)])[pN, :]
+    alpha[16 * (NT - 1):] = -acc_to_tile(G_[(NT - 1, NT - 1)])[pN, :]
+    # ---- K3: P''_ij = sum_{k >= j} flip(M_ki)^T M_kj, block column J of the OUTPUT (a separate array) ----
+    sg = np.stack([np.where(4 * G + r == pN, -1.0, 1.0) for r in range(4)])
+    P = np.zeros((NP, NP))
+    for j0 in range(0, NT, RB):
+        for j in range(j0, min(j0 + RB, NT)):
+            for i in range(j + 1):
+                acc = np.zeros((4, 64))
+                for k in range(j, NT):
+                    A = G_[(i, k)] * (sg if k == NT - 1 else 1.0)
+                    acc = xty(A, G_[(j, k)], acc)
+                t = acc_to_tile(acc)
+                P[16 * i:16 * i + 16, 16 * j:16 * j + 16] = t
+                P[16 * j:16 * j + 16, 16 * i:16 * i + 16] = t.T
+    return logdet + N * np.log(kappa), quad, alpha[:N] / 2.0 ** m, P[:N, :N] / kappa
+
+
+def main_tiled():
+    rng = np.random.default_rng(1)
+    for N in (40, 100, 130, 191):
+        Z = rng.standard_normal((N, 60))
+        Z /= np.linalg.norm(Z, axis=1, keepdims=True)
+        K = (0.7 * Z @ Z.T + 0.1 * np.eye(N)) * (5.0 if N % 2 else 1.0)
+        r = rng.standard_normal(N)
+        logdet, quad, alpha, P = run_tiled(N, K, r)
+        Ki = np.linalg.inv(K)
+        a_ref = Ki @ r
+        err = [abs(logdet - np.linalg.slogdet(K)[1]), abs(quad - r @ a_ref), np.abs(alpha - a_ref).max(),
+               np.abs(P - (Ki - np.outer(a_ref, a_ref))).max()]
+        print("tiled N=%3d  logdet %.2e  quad %.2e  alpha %.2e  P %.2e" % (N, *err))
+        assert max(err) < 1e-8
+
+
+if __name__ == "__main__" and "tiled" in __import__("sys").argv:
+    main_tiled()
