@@ -37,13 +37,18 @@ struct TiledScal {                            // per matrix, factor -> invert ->
 
 struct TiledArgs {
     MllArgs a;
-    float* tiles;                             // [nmat][NTT][256]
+    float* tiles;                             // [nmat][NTT + 1][256]; tile NTT of every matrix is all zero
     TiledScal* scal;                          // [nmat]
     int b0, NT;
 };
 
 __device__ __forceinline__ int tslot(const int NT, const int i, const int j) { return i * NT - (i * (i - 1)) / 2 + (j - i); }      // i <= j
 __device__ __forceinline__ int toff(const int NT, const int i, const int j, const int lane) { return (tslot(NT, i, j) * 64 + lane) * 16; }
+// tile (i, j) into operand registers: the slot offset is wave-uniform (SGPR operand of the buffer load), the lane part a constant VGPR
+// (a tile that is structurally absent reads the matrix' all-zero tile, slot NT (NT+1) / 2, instead: the select is scalar)
+__device__ __forceinline__ f32x4 tload(const brsrc Tr, const int NT, const bool ok, const int i, const int j, const int lane16) {
+    return bload4(Tr, lane16, (ok ? tslot(NT, i, j) : (NT * (NT + 1)) / 2) * 1024);
+}
 
 struct Geo {
     int lane, c16, g4, pN, N, NT;
@@ -106,6 +111,25 @@ __device__ __forceinline__ f32x4 form_tile_rt(const FormRt& f, const Geo& g, con
     return s;
 }
 
+// c[u] += x[u]^T y (u = 0..3) resp. c[u] += x^T y[u]: four independent accumulator chains advanced together, so that no MFMA waits
+// for the one issued just before it.
+__device__ __forceinline__ void xty4_x(const f32x4 (&x)[TB], const f32x4 y, f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0][q], y[q], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[1][q], y[q], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[2][q], y[q], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[3][q], y[q], c3, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void xty4_y(const f32x4 x, const f32x4 (&y)[TB], f32x4 (&c)[TB]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int u = 0; u < TB; ++u) c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[u][q], c[u], 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
     f32x4 n;
 #pragma unroll
@@ -128,9 +152,9 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     const int N = a.N, NT = t.NT, C = a.C;
     const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
     const Geo g = make_geo(tid, N, NT);
-    const int lane = g.lane;
+    const int lane = g.lane, lane16 = g.lane * 16;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
-    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * ntt * 256, (unsigned)(ntt * 1024));
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
     const float* Eb = a.E + (size_t)b * N * N;
     // kappa = 4^msc >= max_i K_ii
     float emax = 0.f;
@@ -152,6 +176,8 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     const f32x4 negI = neg_identity(g);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    if (w == 0) bstore4(Tr, zero4, lane16, (int)ntt * 1024);               // the matrix' zero tile (read by this and the later kernels)
+    __syncthreads();
     int fail_at = 0;
     float lsum = 0.f, quad = 0.f;
     for (int i0 = 0; i0 < NT; i0 += TB) {
@@ -168,20 +194,17 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
         auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int kt) {
             const bool kin = kt < i0;
 #pragma unroll
-            for (int r = 0; r < TB; ++r) X[r] = bload4(Tr, (kin && i0 + r < NT) ? toff(NT, kt, i0 + r, lane) : OOB, 0);
+            for (int r = 0; r < TB; ++r) X[r] = tload(Tr, NT, kin && i0 + r < NT, kt, i0 + r, lane16);
 #pragma unroll
             for (int bb = 0; bb < MC; ++bb) {
                 const int j = i0 + w + TB * bb;
-                Y[bb] = bload4(Tr, (kin && j < NT) ? toff(NT, kt, j, lane) : OOB, 0);
+                Y[bb] = tload(Tr, NT, kin && j < NT, kt, j, lane16);
             }
         };
         auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC]) {
 #pragma unroll
             for (int bb = 0; bb < MC; ++bb) {
-                if (i0 + w + TB * bb < NT) {
-#pragma unroll
-                    for (int r = 0; r < TB; ++r) acc[r][bb] = xty(X[r], Y[bb], acc[r][bb]);
-                }
+                if (i0 + w + TB * bb < NT) xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
             }
         };
         if (i0 > 0) {
@@ -276,9 +299,9 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
     const int N = a.N, NT = t.NT, C = a.C;
     const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
     const Geo g = make_geo(tid, N, NT);
-    const int lane = g.lane, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
-    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * ntt * 256, (unsigned)(ntt * 1024));
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
     const size_t bc = (size_t)b * C + c;
     const brsrc ar = mk_rsrc(a.alpha + bc * N, (unsigned)(N * 4));
     const TiledScal sc = t.scal[m];
@@ -318,11 +341,11 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
         auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int k) {
             const bool kin = k < j0;
 #pragma unroll
-            for (int jj = 0; jj < TB; ++jj) X[jj] = bload4(Tr, (kin && j0 + jj < NT) ? toff(NT, k, j0 + jj, lane) : OOB, 0);
+            for (int jj = 0; jj < TB; ++jj) X[jj] = tload(Tr, NT, kin && j0 + jj < NT, k, j0 + jj, lane16);
 #pragma unroll
             for (int aa = 0; aa < MC; ++aa) {
                 const int i = w + TB * aa;
-                Y[aa] = bload4(Tr, (kin && i <= k) ? toff(NT, i, k, lane) : OOB, 0);
+                Y[aa] = tload(Tr, NT, kin && i <= k, i, k, lane16);
             }
         };
         auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC], const int k) {
@@ -330,7 +353,9 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
             for (int aa = 0; aa < MC; ++aa) {
                 if (w + TB * aa <= k) {
 #pragma unroll
-                    for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = xty(X[jj], Y[aa], acc[aa][jj]);
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[jj][q], Y[aa][q], acc[aa][jj], 0, 0, 0);
                 }
             }
         };
@@ -419,7 +444,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
     const int N = a.N, NT = t.NT, C = a.C;
     const int j0 = blockIdx.x * TB, bl = blockIdx.y, b = t.b0 + bl;
     const Geo g = make_geo(tid, N, NT);
-    const int lane = g.lane, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 sgn;
@@ -431,45 +456,58 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
 #pragma unroll
         for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = zero4;
     const int jmax = min(j0 + TB, NT) - 1;                                  // last column of the block
-    for (int c = 0; c < C; ++c) {
-        const size_t m = (size_t)bl * C + c;
-        const brsrc Tr = mk_rsrc(t.tiles + m * ntt * 256, (unsigned)(ntt * 1024));
-        const float coef = t.scal[m].coef;
-        auto loadk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB], const int k) {
-            const bool kin = k < NT;
+    // One descriptor over the C tile arrays of the episode; the (class, k) steps form ONE software-pipelined stream (the loads of
+    // the next class's first step fly during the last step of the current one).
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)bl * C * (ntt + 1) * 256, (unsigned)((size_t)C * (ntt + 1) * 1024));
+    const TiledScal* sc = t.scal + (size_t)bl * C;
+    const int nk = NT - j0, total = C * nk;
+    // rows of this wave: aa = 0 is its row of the diagonal block (i = j0 + w, only the columns j >= i), aa >= 1 the rows above it
+    // (i = j0 + w - 4 aa >= 0, all four columns)
+    auto row_of = [&](const int aa) { return j0 + w - TB * aa; };
+    int lc = 0, lk = j0;                                                    // load cursor
+    auto loadk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB]) {
+        const int cbase = min(lc, C - 1) * (int)(ntt + 1), k = lk, zt = (int)ntt;
+        const bool in = lc < C;
 #pragma unroll
-            for (int jj = 0; jj < TB; ++jj) {
-                const int j = j0 + jj;
-                Bt[jj] = bload4(Tr, (kin && j <= k) ? toff(NT, j, k, lane) : OOB, 0);          // M_kj (the diagonal slot for k = j)
-            }
+        for (int jj = 0; jj < TB; ++jj) {
+            const int j = j0 + jj;
+            Bt[jj] = bload4(Tr, lane16, (cbase + ((in && j <= k) ? tslot(NT, j, k) : zt)) * 1024);      // M_kj (the diagonal slot for k = j)
+        }
 #pragma unroll
-            for (int aa = 0; aa < MC; ++aa) {
-                const int i = w + TB * aa;
-                A[aa] = bload4(Tr, (kin && i <= jmax && i <= k) ? toff(NT, i, k, lane) : OOB, 0);
-            }
-        };
-        auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB], const int k) {
+        for (int aa = 0; aa < MC; ++aa) {
+            const int i = row_of(aa);
+            A[aa] = bload4(Tr, lane16, (cbase + ((in && i >= 0 && i <= jmax && i <= k) ? tslot(NT, i, k) : zt)) * 1024);
+        }
+        if (++lk == NT) { lk = j0; ++lc; }
+    };
+    int mcl = 0, mk = j0;                                                   // multiply cursor
+    auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB]) {
+        const float coef = sc[min(mcl, C - 1)].coef;
 #pragma unroll
-            for (int jj = 0; jj < TB; ++jj) Bt[jj] *= coef;
-            if (k == NT - 1) {
+        for (int jj = 0; jj < TB; ++jj) Bt[jj] *= coef;
+        if (mk == NT - 1) {
 #pragma unroll
-                for (int aa = 0; aa < MC; ++aa) A[aa] *= sgn;
-            }
+            for (int aa = 0; aa < MC; ++aa) A[aa] *= sgn;
+        }
+        if (j0 + w <= jmax) {                                               // the diagonal-block row: columns jj >= w
 #pragma unroll
-            for (int aa = 0; aa < MC; ++aa) {
-                if (w + TB * aa <= jmax) {
+            for (int jj = 0; jj < TB; ++jj)
+                if (jj >= w) acc[0][jj] = xty(A[0], Bt[jj], acc[0][jj]);
+        }
 #pragma unroll
-                    for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = xty(A[aa], Bt[jj], acc[aa][jj]);
-                }
-            }
-        };
+        for (int aa = 1; aa < MC; ++aa) {
+            if (row_of(aa) >= 0) xty4_y(A[aa], Bt, acc[aa]);
+        }
+        if (++mk == NT) { mk = j0; ++mcl; }
+    };
+    {
         f32x4 A0[MC], B0[TB], A1[MC], B1[TB];
-        loadk(A0, B0, j0);
-        for (int k = j0; k < NT; k += 2) {
-            loadk(A1, B1, k + 1);
-            mulk(A0, B0, k);
-            loadk(A0, B0, k + 2);
-            mulk(A1, B1, k + 1);
+        loadk(A0, B0);
+        for (int it = 0; it < total; it += 2) {
+            loadk(A1, B1);
+            mulk(A0, B0);
+            loadk(A0, B0);
+            if (it + 1 < total) mulk(A1, B1);
         }
     }
     // ---- store: tile (i, j) and its mirror ----
@@ -478,8 +516,8 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
     for (int aa = 0; aa < MC; ++aa)
 #pragma unroll
         for (int jj = 0; jj < TB; ++jj) {
-            const int i = w + TB * aa, j = j0 + jj;
-            if (j < NT && i <= j) {                                         // uniform
+            const int i = j0 + w - TB * aa, j = j0 + jj;
+            if (j < NT && i >= 0 && i <= j) {                               // uniform
                 const f32x4 v = acc[aa][jj];
                 const bool col_ok = 16 * j + c16 < N;
 #pragma unroll
@@ -498,11 +536,11 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
 inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
 inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
-    size_t fl = nmat * ntt * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
+    size_t fl = nmat * (ntt + 1) * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
     const size_t gen = dkt_mll_generic_global_floats(Bc, N);               // the fix-up pass works in the same region
     return fl > gen ? fl : gen;
 }
-constexpr int TILED_CHUNK = 256;           // episodes per pass over the workspace
+constexpr int TILED_CHUNK = 1024;          // episodes per pass over the workspace (N = 420, C = 20: 7.7 GB of tiles)
 
 template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
@@ -537,7 +575,7 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
     TiledArgs t;
     t.a = a;
     t.tiles = (float*)workspace;
-    t.scal = (TiledScal*)(t.tiles + nmat_max * ntt * 256);
+    t.scal = (TiledScal*)(t.tiles + nmat_max * (ntt + 1) * 256);
     t.NT = NT;
     const bool grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     const int mc = (NT + TB - 1) / TB;

@@ -460,10 +460,13 @@ def test_jitter_retry_and_failure_info(cuda, path):
     assert int(o["info"].item()) == 0 and o["jitter"].item() == 0.0
 
 
+@pytest.mark.parametrize("path", ["tiled", "blocked"])
 @pytest.mark.parametrize("n", [150, 230, 333])
-def test_jitter_retry_and_failure_info_blocked_path(cuda, n):
-    """N > 127: blocked path (diagonal-block sweeps + batched GEMMs).  A batch mixes healthy matrices, matrices that need
-    1e-5 / 1e-4 of jitter and a hopeless one; every matrix must retry on its own (GPyTorch psd_safe_cholesky per matrix)."""
+def test_jitter_retry_and_failure_info_blocked_path(cuda, n, path):
+    """N > 127: the tile-array path (default) and its blocked twin (diagonal-block sweeps + batched GEMMs; also what serves
+    want_chol).  A batch mixes healthy matrices, matrices that need 1e-5 / 1e-4 of jitter and a hopeless one; every matrix must
+    retry on its own (GPyTorch psd_safe_cholesky per matrix)."""
+    blocked = path == "blocked"
     rng = np.random.default_rng(n)
     qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
     base = np.linspace(0.3, 2.0, n)
@@ -477,8 +480,8 @@ def test_jitter_retry_and_failure_info_blocked_path(cuda, n):
     e_all = np.stack(es)
     y = np.sign(rng.standard_normal((2, n)))
     sv, mean, noise = np.array([1.0, 1.0]), np.array([0.0, 0.1]), np.array([0.1, 0.1])
-    o = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), want_grad=True, want_chol=True,
-                cls_weight=dev_t([1.0, 1.0], cuda))
+    o = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), want_grad=True, want_chol=blocked,
+                cls_weight=dev_t([1.0, 1.0], cuda), force_blocked=blocked)
     info, jit = o["info"].cpu().numpy(), o["jitter"].cpu().numpy()
     assert (info[[0, 1, 2, 4]] == 0).all() and (info[3] > 0).all()
     assert np.allclose(jit[0], 0.0) and np.allclose(jit[4], 0.0)
@@ -496,11 +499,54 @@ def test_jitter_retry_and_failure_info_blocked_path(cuda, n):
             assert abs(o["logp"][i, c].item() - logp) < tol * abs(logp)
             if jit[i, c] == 0.0:
                 assert rel_l2(o["alpha"][i, c].cpu().numpy(), alpha) < 5e-4
-                assert rel_l2(o["chol"][i, c].cpu().numpy(), l) < 5e-5
+                if blocked:
+                    assert rel_l2(o["chol"][i, c].cpu().numpy(), l) < 5e-5
     # the generic twin agrees on what failed and which jitter was used
     g = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), force_generic=True)
     assert (g["info"].cpu().numpy() != 0).tolist() == (info != 0).tolist()
     assert np.allclose(g["jitter"].cpu().numpy(), jit)
+
+
+@pytest.mark.parametrize("n,c", [(128, 2), (143, 3), (144, 1), (257, 4), (320, 20), (447, 2)])
+def test_mll_tile_array_path_edges(cuda, n, c):
+    """The tile-array kernels (N > 127) at the edges of their tiling -- the augmented row first / last in its tile (N = 128 / 143),
+    a tile count that is not a multiple of the 4-tile blocks, the largest supported size -- against float64 and the blocked and
+    generic twins, with and without gradients; W must be bitwise symmetric."""
+    rng = np.random.default_rng(n + c)
+    z = rng.standard_normal((3, n, 40))
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    e_np = np.einsum("bnd,bmd->bnm", z, z)
+    y = np.sign(rng.standard_normal((c, n)))
+    sv = 0.6 + 0.1 * np.arange(c)
+    mean = 0.02 * np.arange(c)
+    noise = np.full(c, 0.1)
+    cw = np.full(c, -1.0 / (c * n))
+    args = [dev_t(x, cuda) for x in (e_np, y, sv, mean, noise)]
+    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    o_fwd = ops.mll(*args, want_grad=False)
+    blk = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_blocked=True)
+    gen = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_generic=True)
+    assert int(o["info"].abs().max().item()) == 0 and float(o["jitter"].abs().max().item()) == 0.0
+    assert torch.equal(o["w"], o["w"].transpose(1, 2))
+    w_ref = np.zeros((3, n, n))
+    for b in range(3):
+        for k in range(c):
+            kk = sv[k] * e_np[b] + noise[k] * np.eye(n)
+            l = np.linalg.cholesky(kk)
+            r = y[k] - mean[k]
+            alpha = np.linalg.solve(kk, r)
+            logp = -0.5 * r @ alpha - np.log(np.diag(l)).sum() - 0.5 * n * np.log(2 * np.pi)
+            assert abs(o["logp"][b, k].item() - logp) < MLL_RTOL * abs(logp)
+            assert abs(o_fwd["logp"][b, k].item() - logp) < MLL_RTOL * abs(logp)
+            assert rel_l2(o["alpha"][b, k].cpu().numpy(), alpha) < 2e-4
+            assert rel_l2(o_fwd["alpha"][b, k].cpu().numpy(), alpha) < 2e-4
+            w_ref[b] += cw[k] * sv[k] * 0.5 * (np.outer(alpha, alpha) - np.linalg.inv(kk))
+    assert rel_l2(o["w"].cpu().numpy(), w_ref) < 2e-4
+    for twin in (blk, gen):
+        assert rel_l2(o["w"].cpu().numpy(), twin["w"].cpu().numpy()) < 1e-4
+        np.testing.assert_allclose(o["logp"].cpu().numpy(), twin["logp"].cpu().numpy(), rtol=2e-5)
+        for key in ("dsv", "dmean", "dnoise"):
+            assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
 
 
 def test_duplicate_rows_rank_deficient_gram(cuda):
