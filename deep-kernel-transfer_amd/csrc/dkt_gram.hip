@@ -17,6 +17,7 @@
 
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st);
+bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st);
 
 namespace {
 
@@ -378,8 +379,10 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
 
 extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
                                 const float* ep_scale, unsigned flags, void* stream) {
-    if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0 || (flags & ~DKT_GRAM_UNIT_ROWS)) return DKT_ERR_BAD_ARG;
+    if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0 || (flags & ~(DKT_GRAM_UNIT_ROWS | DKT_GRAM_W_SYMMETRIC))) return DKT_ERR_BAD_ARG;
     if (dkt_gram_bwd_ep_launch(W, Z, dZ, B, N, D, ep_scale, (flags & DKT_GRAM_UNIT_ROWS) != 0, (hipStream_t)stream))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (dkt_gram_bwd_big_launch(W, Z, dZ, B, N, D, ep_scale, flags, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((D + GT - 1) / GT, (N + GT - 1) / GT, B), block(256);

@@ -1,0 +1,189 @@
+// dkt_gram_big.hip -- Gram backward for 128 < N <= 448 (the 20-way shapes) on the f16 MFMA pipe:  dZ[b] = s_b (W[b] + W[b]^T) Z[b]
+// for unit-norm rows of Z (DKT_GRAM_UNIT_ROWS) and a W the caller declares symmetric (DKT_GRAM_W_SYMMETRIC: dkt_mll_f32 writes
+// W[b] bitwise symmetric), so that the A operand 2 s W is built from ROW reads only.
+//
+// Replaces autograd through matmul(Z, Z^T) in loss.backward() (reference methods/DKT.py:163) at the sizes of train.py:132-133
+// (n_way = 20), where the episode-resident kernel of dkt_gram_ep.hip (N <= 128: one workgroup holds every row's A fragments) no
+// longer applies and the generic fp32 kernel of dkt_gram.hip ran at 0.08 of the HBM roof.
+//
+// Workgroup = 4 waves = 64 output rows of one episode; wave w keeps the A fragments of its 16 rows for the WHOLE contraction range
+// (KS k32-slices x 2 f16 planes: 8 KS VGPRs) in registers, every row scaled by its own power of two (row maximum -> [2^14, 2^15))
+// before the 2-way f16 split (dkt_split.h) -- exact, undone per output row in the epilogue.  Z is streamed in slabs of 32 features:
+// all N rows of the slab are split (scaled by 2^15) and transposed into a [feature][row] f16 image in LDS (two planes; the same
+// staging as gram_bwd_ep_f16x2_kernel), from which a lane's 8 consecutive-row B values are one ds_read_b128.  The row blocks of an
+// episode re-read the same Z slabs: the workgroup -> (episode, row block) map keeps them on ONE XCD (workgroup id mod 8 = XCD), so
+// the re-reads are served by that XCD's L2.
+#include "dkt_split.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+                                                                    float* __restrict__ dZ, int B, int N, int D,
+                                                                    const float* __restrict__ ep_scale, int nrb) {
+    constexpr int KP = 32 * KS;
+    constexpr int BD = 32;
+    constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);
+    constexpr int RS = 8 * SU;                           // f16 per LDS row (one feature, all rows j), 16-byte units == 2 mod 4
+    constexpr int PLANE = BD * RS;
+    constexpr int NPASS = (KP + 127) / 128;              // staging passes of 128 rows
+    static_assert(SU % 4 == 2 && RS >= KP, "LDS row stride");
+    __shared__ __attribute__((aligned(16))) _Float16 zt[2 * PLANE];
+    __shared__ float rowinv[64];
+
+    // workgroup -> (episode, row block): consecutive workgroup ids go to consecutive XCDs, so the row blocks of one episode are
+    // given ids that are 8 apart
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int b = (slot / nrb) * 8 + xcd, rb = slot % nrb;
+    if (b >= B) return;
+    const int r0 = 64 * rb;
+    const float* Wb = W + (size_t)b * N * N;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* dZb = dZ + (size_t)b * N * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const float s2 = 2.0f * (ep_scale ? ep_scale[b] : 1.0f);
+
+    // ---- Z staging: thread = 4 rows (4 jg .. 4 jg + 3, + 128 per pass) x 4 features (4 d4 .. 4 d4 + 3) ----
+    const int d4 = tid & 7, jg = tid >> 3;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    auto gload = [&](float4 (&rg)[NPASS][4], int d0) {
+        const bool in = d0 + 4 * d4 < D;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 128 * p + 4 * jg + rr;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (in && row < N) ? (row * D + 4 * d4) * 4 : 0x7ffffff0, d0 * 4, 0);
+                rg[p][rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+    };
+    // feature d = 4 d4 + t of the slab goes to LDS row 16 (d & 1) + (d >> 1): output tile tt = d & 1 holds the features {2 r + tt},
+    // so the two accumulators of a lane are 2 consecutive features (8-byte stores of dZ)
+    auto lstore = [&](const float4 (&rg)[NPASS][4]) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (128 * p + 4 * jg < KP) {
+                const float x[4][4] = {{rg[p][0].x, rg[p][1].x, rg[p][2].x, rg[p][3].x}, {rg[p][0].y, rg[p][1].y, rg[p][2].y, rg[p][3].y},
+                                       {rg[p][0].z, rg[p][1].z, rg[p][2].z, rg[p][3].z}, {rg[p][0].w, rg[p][1].w, rg[p][2].w, rg[p][3].w}};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f16x4 h, m;
+                    split2h(make_float4(x[t][0], x[t][1], x[t][2], x[t][3]), 32768.f, h, m);
+                    const int lrow = 16 * (t & 1) + 2 * d4 + (t >> 1);
+                    _Float16* dst = zt + lrow * RS + 128 * p + 4 * jg;
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                    *reinterpret_cast<f16x4*>(dst + PLANE) = m;
+                }
+            }
+        }
+    };
+    const int nslab = (D + BD - 1) / BD;
+    float4 rg[NPASS][4];
+
+    // ---- A fragments: row r0 + 16 wave + r16, slot e of slice ks on lane (r16, q) is k = 32 ks + 8 q + e; value 2 s W[row][k] ----
+    f16x8 ah[KS], am[KS];
+    {
+        const int row = r0 + 16 * wave + r16;
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, N * N * 4, 0x00020000);
+        auto wload = [&](float (&v)[8], int ks) {
+            const int k = 32 * ks + 8 * q;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int kk = k + 4 * hh;
+                if (kk + 3 < N || row >= N) {            // (a 16-byte load that would run past the row end is done element by element)
+                    const auto u = __builtin_amdgcn_raw_buffer_load_b128(wr, (row < N) ? (row * N + kk) * 4 : 0x7ffffff0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * hh + e] = s2 * __uint_as_float(u[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[4 * hh + e] = s2 * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, (kk + e < N) ? (row * N + kk + e) * 4 : 0x7ffffff0, 0, 0));
+                }
+            }
+        };
+        float rmax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+            wload(v, ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rmax = fmaxf(rmax, fabsf(v[e]));
+        }
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 16, DKT_WAVE));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, DKT_WAVE));
+        // power-of-two row scale: row maximum -> [2^14, 2^15); clamped so that its inverse (times 2^-15) stays normal
+        const int eb = (int)((__float_as_uint(rmax) >> 23) & 0xffu);
+        const int sexp = min(268 - eb, 237);
+        const float rscale = __uint_as_float((unsigned)sexp << 23);
+        if (q == 0) rowinv[16 * wave + r16] = __uint_as_float((unsigned)(254 - sexp - 15) << 23);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+            wload(v, ks);                                // second pass: served by L2
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = v[e] * rscale;
+                const _Float16 hi = (_Float16)xs;
+                ah[ks][e] = hi;
+                am[ks][e] = (_Float16)(xs - (float)hi);
+            }
+        }
+    }
+    gload(rg, 0);
+    lstore(rg);
+    __syncthreads();
+    for (int sl = 0; sl < nslab; ++sl) {
+        if (sl + 1 < nslab) gload(rg, (sl + 1) * BD);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const _Float16* base = zt + r16 * RS + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const _Float16* p = base + 16 * tt * RS + 32 * ks;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p);
+                const f16x8 bm = *reinterpret_cast<const f16x8*>(p + PLANE);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bm, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], bh, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[tt], 0, 0, 0);
+            }
+        }
+        const int d = sl * BD + 2 * r16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int lr = 16 * wave + 4 * q + reg, row = r0 + lr;
+            const float u = rowinv[lr];
+            if (row < N && d < D) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 o = {acc[0][reg] * u, acc[1][reg] * u};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(dZb + (size_t)row * D + d));
+            }
+        }
+        __syncthreads();
+        if (sl + 1 < nslab) lstore(rg);
+        __syncthreads();
+    }
+}
+
+template <int KS>
+void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
+    const int nrb = (N + 63) / 64;
+    const int grid = 8 * ((B + 7) / 8) * nrb;
+    hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS>), dim3(grid), dim3(256), 0, st, W, Z, dZ, B, N, D, sc, nrb);
+}
+
+}  // namespace
+
+// Returns true when the kernel was launched (128 < N <= 448, unit rows, symmetric W, D % 4 == 0, 16-byte aligned Z / dZ).
+bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st) {
+    if (N <= 128 || N > 448 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 7)) return false;
+    if (!(flags & DKT_GRAM_UNIT_ROWS) || !(flags & DKT_GRAM_W_SYMMETRIC)) return false;
+    const int ks = (N + 31) / 32;
+    if (ks <= 6) launch_rows<6>(W, Z, dZ, B, N, D, sc, st);
+    else if (ks <= 8) launch_rows<8>(W, Z, dZ, B, N, D, sc, st);
+    else if (ks <= 10) launch_rows<10>(W, Z, dZ, B, N, D, sc, st);
+    else if (ks <= 12) launch_rows<12>(W, Z, dZ, B, N, D, sc, st);
+    else launch_rows<14>(W, Z, dZ, B, N, D, sc, st);
+    return true;
+}

@@ -25,6 +25,7 @@ KERNEL_RBF = 1
 KERNEL_SQDIST = 2
 KERNEL_LINEAR_UNIT = 3      # linear + the promise |a| <= 1 element-wise (rows went through F.normalize)
 GRAM_UNIT_ROWS = 1          # the same promise for the rows of Z in gram_bwd
+GRAM_W_SYMMETRIC = 2        # gram_bwd: every W[b] is symmetric (as dkt_mll_f32 writes it)
 MLL_WANT_GRAD = 1
 MLL_WANT_CHOL = 2
 MLL_FORCE_GENERIC = 4
@@ -194,9 +195,11 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
 
 
-def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] = None, unit_rows: bool = False) -> torch.Tensor:
+def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] = None, unit_rows: bool = False,
+             w_symmetric: bool = False) -> torch.Tensor:
     """dZ[b] = ep_scale[b] * (W[b] + W[b]^T) Z[b].  unit_rows: the caller guarantees |z| <= 1 element-wise (rows that went
-    through F.normalize), which lets the kernel use the scaled 2-way f16 split (DKT_GRAM_UNIT_ROWS)."""
+    through F.normalize), which lets the kernel use the scaled 2-way f16 split (DKT_GRAM_UNIT_ROWS).  w_symmetric: the caller
+    states W[b] = W[b]^T (what dkt_mll_f32 writes): DKT_GRAM_W_SYMMETRIC, used by the 128 < N <= 448 kernel."""
     w = _req(w, "w", 3)
     z = _req(z, "z", 3)
     b_, n, d = z.shape
@@ -210,7 +213,8 @@ def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] 
     lib = _lib.load()
     _sync_env(lib)
     with _timed("dkt_gram_bwd_f32"):
-        st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale), GRAM_UNIT_ROWS if unit_rows else 0, _stream())
+        st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale),
+                                  (GRAM_UNIT_ROWS if unit_rows else 0) | (GRAM_W_SYMMETRIC if w_symmetric else 0), _stream())
     _lib.check(st, "dkt_gram_bwd_f32")
     return dz
 
@@ -477,7 +481,7 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
     def backward(ctx, gobj, *_unused):
         z, w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        dz = gram_bwd(w, z, gobj, unit_rows=ctx.unit_rows) if ctx.needs_input_grad[0] else None
+        dz = gram_bwd(w, z, gobj, unit_rows=ctx.unit_rows, w_symmetric=True) if ctx.needs_input_grad[0] else None   # W: from dkt_mll_f32
         gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
         gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
         gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None

@@ -48,6 +48,8 @@ extern "C" {
 
 /* gram_bwd flags */
 #define DKT_GRAM_UNIT_ROWS 1u /* the same promise for the rows of Z in dkt_gram_bwd_f32 (W is unrestricted) */
+#define DKT_GRAM_W_SYMMETRIC 2u /* dkt_gram_bwd_f32: the caller states that every W[b] is symmetric (dkt_mll_f32 writes it so); */
+                                /* s (W + W^T) is then formed as 2 s W from row reads only (used by the 128 < N <= 448 kernel)    */
 
 /* mll flags */
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
@@ -110,7 +112,7 @@ int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv,
 /*
  * dkt_gram_bwd_f32 -- backward of the linear Gram: dZ[b] = scale_b * (W[b] + W[b]^T) Z[b].
  *   W:[B,N,N]  Z:[B,N,D]  dZ:[B,N,D];  ep_scale: [B] device per-episode factor (upstream
- *   gradient of the episode objective) or NULL (= 1).  flags: 0 or DKT_GRAM_UNIT_ROWS.
+ *   gradient of the episode objective) or NULL (= 1).  flags: 0 or DKT_GRAM_UNIT_ROWS | DKT_GRAM_W_SYMMETRIC.
  * Replaces: autograd through matmul(Z, Z^T) in loss.backward() (methods/DKT.py:163).
  */
 int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,

@@ -549,6 +549,27 @@ def test_mll_tile_array_path_edges(cuda, n, c):
             assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
 
 
+@pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (448, 36), (257, 100)])
+def test_gram_bwd_large_n_symmetric_w_kernel(cuda, n, d):
+    """128 < N <= 448 with unit rows and a W declared symmetric: the row-block f16-split kernel (dkt_gram_big.hip) against float64
+    and against the generic kernel (same call without the two promises)."""
+    rng = np.random.default_rng(n * d)
+    b = 5
+    z = rng.standard_normal((b, n, d))
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    w = rng.standard_normal((b, n, n)) * np.exp(rng.standard_normal((b, n, 1)))       # rows of very different magnitude
+    w = 0.5 * (w + w.transpose(0, 2, 1))
+    s = rng.uniform(0.5, 2.0, b)
+    ref = s[:, None, None] * np.einsum("bij,bjd->bid", w + w.transpose(0, 2, 1), z)
+    zt, wt, st = dev_t(z, cuda), dev_t(w, cuda), dev_t(s, cuda)
+    fast = ops.gram_bwd(wt, zt, st, unit_rows=True, w_symmetric=True)
+    slow = ops.gram_bwd(wt, zt, st)
+    mag = s[:, None, None] * np.einsum("bij,bjd->bid", np.abs(w + w.transpose(0, 2, 1)), np.abs(z))
+    assert (np.abs(fast.cpu().numpy() - ref) / mag).max() < 4e-7
+    assert (np.abs(slow.cpu().numpy() - ref) / mag).max() < 2e-6          # the sequential fp32 chain of the generic kernel is the less accurate one
+    assert rel_l2(fast.cpu().numpy(), ref) < 2e-6
+
+
 def test_duplicate_rows_rank_deficient_gram(cuda):
     g = np.load(os.path.join(GOLD, "degenerate.npz"))
     z = g["z"]
