@@ -38,8 +38,9 @@ struct TiledScal {                            // per matrix, factor -> invert ->
 struct TiledArgs {
     MllArgs a;
     float* tiles;                             // [nmat][NTT + 1][256]; tile NTT of every matrix is all zero
+    float* etiles;                            // [episodes of the chunk][NTT][256]: E[b] in tile layout
     TiledScal* scal;                          // [nmat]
-    int b0, NT;
+    int b0, NT, bcnt;
 };
 
 __device__ __forceinline__ int tslot(const int NT, const int i, const int j) { return i * NT - (i * (i - 1)) / 2 + (j - i); }      // i <= j
@@ -64,25 +65,37 @@ __device__ __forceinline__ Geo make_geo(const int tid, const int N, const int NT
 }
 
 struct FormRt {
-    brsrc Er, yr;
+    brsrc Et, yr;                 // the episode's E in tile layout (tiled_etile_kernel), this class' targets
     float nsv, dg, mc, rsc;
 };
 
-// Tile (i, j), i <= j, of S = -K' / kappa in the accumulator layout straight from E[b] (symmetric: element [4g+q][c] =
-// E[16j + c][16i + 4g + q], one 16-byte load per lane); the augmented column / row, its zero pivot and the identity padding as in
-// form_tile of dkt_mll_mfma.hip.
-__device__ __forceinline__ f32x4 form_tile_rt(const FormRt& f, const Geo& g, const int i, const int j) {
-    const int NT = g.NT, N = g.N, pN = g.pN, c16 = g.c16, g4 = g.g4;
-    const int row = 16 * j + c16;
-    const bool row_ok = (j < NT - 1) || (c16 < pN);
+// E[b] -> tile layout, once per episode (shared by its C class matrices): tile (i, j), i <= j, element [4g+q][c] = E[16i + 4g + q][16j + c]
+// = E[16j + c][16i + 4g + q] (symmetric: one 16-byte load per lane), zero beyond N; written as one coalesced 1-KB tile.
+__global__ __launch_bounds__(256) void tiled_etile_kernel(const float* __restrict__ E, float* __restrict__ Et, int b0, int N, int NT) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
+    const int ntt = NT * (NT + 1) / 2, bl = blockIdx.y, slot = blockIdx.x * 4 + wave;
+    if (slot >= ntt) return;
+    int i = 0, rem = slot;
+    while (rem >= NT - i) { rem -= NT - i; ++i; }                           // slot -> (i, j): tile rows are contiguous
+    const int j = i + rem;
+    const brsrc Er = mk_rsrc(E + (size_t)(b0 + bl) * N * N, (unsigned)((size_t)N * N * 4));
+    const int row = 16 * j + c16, col = 16 * i + g4;
     f32x4 e;
-    if (i < NT - 1) {
-        e = bload4(f.Er, row_ok ? (row * N + 16 * i + g4) * 4 : OOB, 0);
+    if (col + 3 < N) {
+        e = bload4(Er, row < N ? (row * N + col) * 4 : OOB, 0);
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.Er, (row_ok && g4 + q < pN) ? (row * N + 16 * i + g4 + q) * 4 : OOB, 0, 0));
+            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
     }
+    reinterpret_cast<f32x4*>(Et + ((size_t)bl * ntt + slot) * 256)[lane] = e;
+}
+
+// Tile (i, j), i <= j, of S = -K' / kappa in the accumulator layout from the episode's E tiles; the augmented column / row, its zero
+// pivot and the identity padding as in form_tile of dkt_mll_mfma.hip.
+__device__ __forceinline__ f32x4 form_tile_rt(const FormRt& f, const Geo& g, const int i, const int j) {
+    const int NT = g.NT, N = g.N, pN = g.pN, c16 = g.c16, g4 = g.g4;
+    const f32x4 e = bload4(f.Et, g.lane * 16, tslot(NT, i, j) * 1024);
     f32x4 s;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -150,7 +163,11 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, NT = t.NT, C = a.C;
-    const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
+    // workgroup -> (episode, class): consecutive workgroup ids go to consecutive XCDs; the C classes of an episode read the same E[b],
+    // so they are given ids 8 apart (one XCD, one L2)
+    const int bl = ((int)(blockIdx.x >> 3) / C) * 8 + (int)(blockIdx.x & 7), c = (int)(blockIdx.x >> 3) % C;
+    if (bl >= t.bcnt) return;
+    const int m = bl * C + c, b = t.b0 + bl;
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     const int msc = max(0, (ex + 1) >> 1);
     const float ikap = ldexpf(1.0f, -2 * msc);
     FormRt f;
-    f.Er = mk_rsrc(Eb, (unsigned)((size_t)N * N * 4));
+    f.Et = mk_rsrc(t.etiles + (size_t)bl * ntt * 256, (unsigned)(ntt * 1024));
     f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
     f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc);
     const f32x4 negI = neg_identity(g);
@@ -180,8 +197,15 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     __syncthreads();
     int fail_at = 0;
     float lsum = 0.f, quad = 0.f;
+#ifdef DKT_TILED_CLOCKS      // measurement build (tools/tiled_phase_clocks.py): shader clocks per phase of this wave, summed over the block rows
+    unsigned long long ck[6] = {0, 0, 0, 0, 0, 0}, c0 = __builtin_amdgcn_s_memtime();
+#define TCLK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long c1 = __builtin_amdgcn_s_memtime(); ck[i] += c1 - c0; c0 = c1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TCLK(i) do { } while (0)
+#endif
     for (int i0 = 0; i0 < NT; i0 += TB) {
         f32x4 acc[TB][MC];
+        TCLK(5);
         // ---- init from E ----
 #pragma unroll
         for (int r = 0; r < TB; ++r)
@@ -207,6 +231,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                 if (i0 + w + TB * bb < NT) xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
             }
         };
+        TCLK(0);
         if (i0 > 0) {
             f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
             loadk(X0, Y0, 0);
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                 mulk(X1, Y1);
             }
         }
+        TCLK(1);
         // ---- the block's tile rows ----
 #pragma unroll
         for (int r = 0; r < TB; ++r) {
@@ -238,7 +264,9 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                     mbuf[lane] = M;
                     acc[r][0] = M;                                          // the diagonal slot keeps M_ii
                 }
+                TCLK(2);
                 __syncthreads();
+                TCLK(3);
                 const f32x4 nV = xty0(mbuf[lane], negI);
 #pragma unroll
                 for (int bb = 0; bb < MC; ++bb) {
@@ -258,8 +286,10 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                         }
                     }
                 }
+                TCLK(4);
             }
         }
+        TCLK(4);
         // ---- store the block row ----
 #pragma unroll
         for (int r = 0; r < TB; ++r)
@@ -270,6 +300,14 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
             }
         __syncthreads();                                                    // visible to every wave's loads of the next block row
     }
+#ifdef DKT_TILED_CLOCKS
+    TCLK(5);
+    if (lane == 0 && w == 0 && a.dnoise) {                                  // phases of wave 0: form | K loop | own sweeps | waiting for a sweep | panel + updates | stores
+        const size_t bcx = (size_t)b * C + c;
+        a.logp[bcx] = (float)ck[0]; a.dsv[bcx] = (float)ck[1]; a.dmean[bcx] = (float)ck[2]; a.dnoise[bcx] = (float)ck[3];
+        a.jitter_used[bcx] = (float)ck[4]; a.alpha[bcx * N] = (float)ck[5];
+    }
+#endif
     // ---- per-matrix scalars ----
     lsum = wave_allsum(lsum);
     if (lane == 0) { lsum_w[w] = lsum; fail_w[w] = fail_at; }
@@ -293,6 +331,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
 template <int MC, bool GRAD>
 __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
     __shared__ float tr_w[TB], as_w[TB];
+    __shared__ f32x4 dblk[10][64];               // the diagonal block of the current block column: R_kj (k < j, slot j (j-1) / 2 + k), M_jj (6 + j)
     const MllArgs& a = t.a;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,9 +398,21 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
                 }
             }
         };
-        if (j0 > 0) {
+        // the 10 tiles of the diagonal block (all original R / M_jj), fetched by the waves together into LDS under the K loop's first loads
+        f32x4 dl[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tt = w + TB * u;                                      // 0..5: (kk, jj) = (0,1) (0,2) (1,2) (0,3) (1,3) (2,3); 6..9: the diagonal
+            const int jj = tt >= 6 ? tt - 6 : (tt >= 3 ? 3 : (tt >= 1 ? 2 : 1));
+            const int kk = tt >= 6 ? jj : tt - (jj * (jj - 1)) / 2;
+            dl[u] = tload(Tr, NT, tt < 10 && j0 + jj < NT, j0 + kk, j0 + jj, lane16);
+        }
+        {
             f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
             loadk(X0, Y0, 0);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (w + TB * u < 10) dblk[w + TB * u][lane] = dl[u];
             for (int k = 0; k < j0; k += 2) {
                 loadk(X1, Y1, k + 1);
                 mulk(X0, Y0, k);
@@ -369,6 +420,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
                 mulk(X1, Y1, k + 1);
             }
         }
+        __syncthreads();
         // ---- the block's columns, one after the other ----
 #pragma unroll
         for (int jj = 0; jj < TB; ++jj) {
@@ -377,15 +429,15 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #pragma unroll
                 for (int kk = 0; kk < jj; ++kk) {
                     const int k = j0 + kk;
-                    const f32x4 Xk = bload4(Tr, toff(NT, k, j, lane), 0);                     // R_kj of the diagonal block (still original)
-                    const f32x4 Mkk = bload4(Tr, (w == kk) ? toff(NT, k, k, lane) : OOB, 0);    // row i = k belongs to wave kk
+                    const f32x4 Xk = dblk[(jj * (jj - 1)) / 2 + kk][lane];                   // R_kj of the diagonal block (still original)
+                    const f32x4 Mkk = dblk[6 + kk][lane];                                     // (row i = k belongs to wave kk)
 #pragma unroll
                     for (int aa = 0; aa < MC; ++aa) {
                         const int i = w + TB * aa;
                         if (i <= k) acc[aa][jj] = xty(Xk, (i == k) ? Mkk : acc[aa][kk], acc[aa][jj]);
                     }
                 }
-                const f32x4 Mjj = bload4(Tr, toff(NT, j, j, lane), 0);
+                const f32x4 Mjj = dblk[6 + jj][lane];
                 const f32x4 nV = xty0(Mjj, negI);
 #pragma unroll
                 for (int aa = 0; aa < MC; ++aa) {
@@ -536,7 +588,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
 inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
 inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
-    size_t fl = nmat * (ntt + 1) * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
+    size_t fl = nmat * (ntt + 1) * 256 + (size_t)Bc * ntt * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
     const size_t gen = dkt_mll_generic_global_floats(Bc, N);               // the fix-up pass works in the same region
     return fl > gen ? fl : gen;
 }
@@ -545,7 +597,11 @@ constexpr int TILED_CHUNK = 1024;          // episodes per pass over the workspa
 template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
-    hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(nmat), dim3(64 * TB), 0, st, t);
+    hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
+    hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(64 * TB), 0, st, t);
+#ifdef DKT_TILED_CLOCKS
+    return;
+#endif
     if (grad) {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, true>), dim3(nmat), dim3(64 * TB), 0, st, t);
         hipLaunchKernelGGL((tiled_w_kernel<MC>), dim3((t.NT + TB - 1) / TB, bcnt), dim3(64 * TB), 0, st, t);
@@ -575,13 +631,15 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
     TiledArgs t;
     t.a = a;
     t.tiles = (float*)workspace;
-    t.scal = (TiledScal*)(t.tiles + nmat_max * (ntt + 1) * 256);
+    t.etiles = t.tiles + nmat_max * (ntt + 1) * 256;
+    t.scal = (TiledScal*)(t.etiles + (size_t)Bc * ntt * 256);
     t.NT = NT;
     const bool grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     const int mc = (NT + TB - 1) / TB;
     for (int b0 = 0; b0 < a.B; b0 += Bc) {
         const int bcnt = (a.B - b0 < Bc) ? a.B - b0 : Bc;
         t.b0 = b0;
+        t.bcnt = bcnt;
         switch (mc) {
             case 3: tiled_chunk<3>(t, bcnt, grad, st); break;
             case 4: tiled_chunk<4>(t, bcnt, grad, st); break;
@@ -592,9 +650,11 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
         }
         // fix-up: episodes with a failed matrix are redone by the generic kernel with the jitter ladder (its global working
         // matrices reuse the tile region, which is dead by now)
+#ifndef DKT_TILED_CLOCKS
         MllArgs f = a;
         f.only_failed = a.info;
         dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);
+#endif
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }

@@ -442,10 +442,13 @@ class _MllObjectiveFn(torch.autograd.Function):
         ctx.save_for_backward(out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
         ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"])
+        ctx.set_materialize_grads(False)       # (otherwise autograd zero-fills a gradient tensor for every non-differentiable output)
         return obj, out["logp"], out["alpha"], out["info"], out["jitter"]
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
+        if gobj is None:
+            return (None,) * 8
         w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         ge = w * gobj.reshape(-1, 1, 1) if ctx.needs_input_grad[0] else None
@@ -475,10 +478,13 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
         ctx.unit_rows = bool(unit_rows)
         ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e)
+        ctx.set_materialize_grads(False)       # (otherwise autograd zero-fills a gradient tensor for every non-differentiable output: E alone is 361 MB at cfg2)
         return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
+        if gobj is None:
+            return (None,) * 9
         z, w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         dz = gram_bwd(w, z, gobj, unit_rows=ctx.unit_rows, w_symmetric=True) if ctx.needs_input_grad[0] else None   # W: from dkt_mll_f32
@@ -588,10 +594,13 @@ class _EpisodeLossBnFn(torch.autograd.Function):
         ctx.save_for_backward(x, e, out["w"], a, s, bmean, rstd, rnorm, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
         ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm)
+        ctx.set_materialize_grads(False)
         return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
+        if gobj is None:
+            return (None,) * 12
         x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         if ctx.use_bn:
