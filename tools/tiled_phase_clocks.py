@@ -36,7 +36,7 @@ for (b, c, n, d) in [(1024, 20, 420, 128), (1024, 20, 320, 128), (13, 20, 420, 1
     names = ["form E", "K loop", "own sweeps", "wait for a sweep (barrier)", "panel + barrier + updates", "stores / rest"]
     vals = [o["logp"], o["dsv"], o["dmean"], o["dnoise"], o["jitter"], o["alpha"][:, :, 0]]
     tot = sum(v.double().mean().item() for v in vals)
-    print("B=%d C=%d N=%d: factor kernel %.3f ms; wave 0 of a workgroup, mean s_memtime ticks (100 MHz) per phase:" % (b, c, n, s.elapsed_time(t)))
+    print("B=%d C=%d N=%d: factor kernel %.3f ms; wave 0 of a workgroup, mean s_memtime ticks per phase (the counter runs at the shader clock here: ticks = cycles):" % (b, c, n, s.elapsed_time(t)))
     for nm, v in zip(names, vals):
         print("   %-32s %9.0f  (%4.1f %%)" % (nm, v.double().mean().item(), 100 * v.double().mean().item() / tot))
-    print("   %-32s %9.0f ticks = %.1f us" % ("total", tot, tot / 100.0), flush=True)
+    print("   %-32s %9.0f ticks ~ %.1f us at 2.4 GHz" % ("total", tot, tot / 2400.0), flush=True)
