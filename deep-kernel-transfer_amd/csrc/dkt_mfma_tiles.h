@@ -127,6 +127,24 @@ __device__ __forceinline__ f32x4 sweep_end(const float (&x)[16], const Lane& ln)
     return M;
 }
 
+// Wave-wide sum / maximum without lane-index registers (the ds_bpermute form of __shfl_xor keeps six (lane ^ o) << 2 address VGPRs
+// alive -- hoisted out of every loop and spilled): DPP within the 16-lane rows, v_readlane across the four rows.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_dpp(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+#define DKT_DPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false))
+    v = op(v, DKT_DPP(v, 0xB1));        // quad_perm [1, 0, 3, 2]
+    v = op(v, DKT_DPP(v, 0x4E));        // quad_perm [2, 3, 0, 1]
+    v = op(v, DKT_DPP(v, 0x124));       // row_ror:4
+    v = op(v, DKT_DPP(v, 0x128));       // row_ror:8
+#undef DKT_DPP
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+
 // The plain sweep of one diagonal tile (no interleaved work): x in the replicated column layout, all 16 pivots.
 template <int P, bool LAST>
 __device__ __forceinline__ void sweep_plain(float (&x)[16], float& dv, const Lane& ln, const int pn) {

@@ -314,8 +314,10 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
     for (int round = 0; round < nrounds; ++round) {
         // lane coordinates and sizes made opaque per round: keeps the compiler from hoisting (and then spilling) every mask and
         // address of the round body into the kernel prologue
-        int c16 = tid & 15, g4 = (tid >> 2) & 12, lane = tid & 63, N = a.N;
-        DKT_OPAQUE_V(c16); DKT_OPAQUE_V(g4); DKT_OPAQUE_V(lane); DKT_OPAQUE_S(N);
+        int tq = tid;
+        DKT_OPAQUE_V(tq);
+        int c16 = tq & 15, g4 = (tq >> 2) & 12, lane = tq & 63, N = a.N;
+        DKT_OPAQUE_S(N);
         Lane ln;
         ln.lane = lane; ln.g = g4 >> 2; ln.c = c16;
         ln.g0 = ln.g == 0; ln.g1 = ln.g == 1; ln.g2 = ln.g == 2;
@@ -359,8 +361,7 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) emax = fmaxf(emax, (g4 + q == c16) ? e[q] : 0.f);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) emax = fmaxf(emax, __shfl_xor(emax, o, DKT_WAVE));
+            emax = wave_reduce_dpp<true>(emax);
             int fail_at = 0;
             float jit = 0.f, lsum = 0.f, quad = 0.f;
             int msc = 0;
@@ -418,7 +419,9 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
             // ---- phase 2: M = R^-T; M_ji (j > i) overwrites slot (i, j); two rows i at a time (independent MFMA chains) ----
             // (lane coordinates opaque again: what the later phases derive from them is recomputed here instead of being kept
             // alive -- spilled -- across the factorisation)
-            DKT_OPAQUE_V(c16); DKT_OPAQUE_V(g4); DKT_OPAQUE_V(lane);
+            tq = tid;
+            DKT_OPAQUE_V(tq);
+            c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63;
             f32x4 negI2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) negI2[q] = (g4 + q == c16) ? -1.0f : 0.0f;
@@ -509,20 +512,20 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                 }
             }
             DKT_CLK(5);
-            lsum = wave_allsum(lsum) + (float)(2 * msc * N);            // log2 det K = log2 det K_s + N log2 kappa
+            lsum = wave_reduce_dpp<false>(lsum) + (float)(2 * msc * N);            // log2 det K = log2 det K_s + N log2 kappa
             trpp *= ldexpf(1.0f, -2 * msc);
-            asum = wave_allsum(asum);
-            trpp = wave_allsum(trpp);
+            asum = wave_reduce_dpp<false>(asum);
+            trpp = wave_reduce_dpp<false>(trpp);
             if (lane == 0) {
                 const bool ok = fail_at == 0;
                 a.logp[bc] = ok ? (-0.5f * quad - 0.34657359027997264f * lsum - (float)N * DKT_HALF_LOG_2PI) : qnan;
                 a.jitter_used[bc] = jit;
                 a.info[bc] = fail_at;
                 if constexpr (GRAD) {
-                    const float nz_eff = nzc + jit;
+                    const float nz_eff = a.noise[c] + jit;                          // (re-read: cheaper than keeping them across the phases)
                     a.dmean[bc] = ok ? asum : qnan;
                     a.dnoise[bc] = ok ? -0.5f * trpp : qnan;                                    // 0.5 (alpha.alpha - tr K^-1)
-                    a.dsv[bc] = ok ? 0.5f * ((quad - (float)N) + nz_eff * trpp) / svc : qnan;
+                    a.dsv[bc] = ok ? 0.5f * ((quad - (float)N) + nz_eff * trpp) / a.sv[c] : qnan;
                 }
             }
             if constexpr (CHOL) {
@@ -532,14 +535,17 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
                 }
             }
             const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
-            coef = (fail_at == 0) ? -0.5f * cw * svc * ldexpf(1.0f, -2 * msc) : qnan;   // W_c = coef P''_s   (a failed class poisons W[b])
+            coef = (fail_at == 0) ? -0.5f * cw * a.sv[c] * ldexpf(1.0f, -2 * msc) : qnan;   // W_c = coef P''_s   (a failed class poisons W[b])
         }
         DKT_CLK(6);
         if constexpr (GRAD) {
             // ---- W[b] = sum over the classes of coef_c P''_c.  The staged E is dead once every wave is past its factorisation
             // (the barrier); its LDS becomes the exchange buffer. ----
             __syncthreads();
-            DKT_OPAQUE_V(c16); DKT_OPAQUE_V(g4); DKT_OPAQUE_V(lane); DKT_OPAQUE_S(N);
+            tq = tid;
+            DKT_OPAQUE_V(tq);
+            c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63;
+            DKT_OPAQUE_S(N);
             const int pNs = N - 16 * (NT - 1);
             const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)(N * N * 4));
             // tile n -> W[b]: element [4g+q][c] of tile (i, j) and its mirror; later rounds add to what this very wave stored before

@@ -765,8 +765,11 @@ def test_predict_variance_vs_oracle(cuda):
 # full-size properties (BASELINE.json cfg2 at bench batch): no oracle pass over 1024 episodes needed
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("unit", [False, True], ids=["bf16_split", "unit_rows_f16_split"])
-def test_full_size_properties_cfg2(cuda, unit):
-    b, n, d, c = 256, 105, 1600, 5
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg1", "cfg3"])
+def test_full_size_properties_cfg2(cuda, unit, cfg):
+    """BASELINE.json configs[1..3] at (N, D, C) full size and a batch the headline kernels take (>= 64 episodes): cfg2 = (105, 1600, 5),
+    cfg1 = (105, 64, 5) Conv4S features, cfg3 = (85, 512, 5) 5-way 1-shot ResNet10 features."""
+    b, n, d, c = {"cfg2": (256, 105, 1600, 5), "cfg1": (512, 105, 64, 5), "cfg3": (512, 85, 512, 5)}[cfg]
     gen = torch.Generator(device="cpu").manual_seed(1234)
     zr = torch.randn(b, n, d, generator=gen)
     zr = (zr - zr.mean(1, keepdim=True)) / torch.sqrt(zr.var(1, unbiased=False, keepdim=True) + 1e-5)
