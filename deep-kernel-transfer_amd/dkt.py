@@ -397,8 +397,11 @@ class DKT(MetaTemplate):
     # ------------------------------------------------------------------ training
     def train_loop(self, epoch, train_loader, optimizer, print_freq=10):
         # the optimizer argument is ignored and Adam re-created every call, as the reference does
+        # (same update rule; on the GPU the fused implementation: one launch per parameter group instead of a dozen element-wise
+        # ones, and it takes a device-side `found_inf` flag -- used below to SKIP the update of a step whose factorisation failed)
+        fused_adam = os.environ.get("DKT_FUSED_ADAM", "1") == "1" and self.device.type == "cuda"
         optimizer = torch.optim.Adam([{'params': self.model.parameters(), 'lr': 1e-4},
-                                      {'params': self.feature_extractor.parameters(), 'lr': 1e-3}])
+                                      {'params': self.feature_extractor.parameters(), 'lr': 1e-3}], **({"fused": True} if fused_adam else {}))
         dev = self.device
         self._bad_steps = None
         # DKT_TRAIN_GRAPH=1: capture the per-episode step into a hipGraph (the loop is launch-bound: ~150 launches for ~1 ms of
@@ -453,6 +456,8 @@ class DKT(MetaTemplate):
                 # print point (GPyTorch raises NotPSDError synchronously; a failed step has poisoned the update with NaN)
                 bad = self._sync_grads(aux["info"].abs().max().float())
                 self._bad_steps = bad if self._bad_steps is None else self._bad_steps + bad
+                if fused_adam:
+                    optimizer.found_inf = (bad != 0).to(torch.float32).reshape(())    # no NaN ever reaches the weights or Adam's moments
                 optimizer.step()
             x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
 

@@ -1308,6 +1308,22 @@ def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
     assert countb == 75 and np.isfinite(avg) and avg != 0.0
 
 
+def test_dkt_failed_step_is_skipped_on_the_device_and_raised_at_the_next_print(cuda, capsys):
+    """An episode whose factorisation fails (here: NaN pixels -> NaN Gram -> info != 0 after every jitter retry) must not reach the
+    weights: the fused Adam step takes the failure flag as `found_inf` and leaves parameters and moments untouched; the error
+    surfaces at the next print point (GPyTorch raises NotPSDError before the step, reference methods/DKT.py:161-164)."""
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type="cossim").to(cuda)
+    m.train()
+    ld = _Loader(3, 5, 21, 28, 0)
+    ld.x[1] = torch.full_like(ld.x[1], float("nan"))
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        m.train_loop(0, ld, None, print_freq=2)            # prints at i = 0 and i = 2; the NaN episode is i = 1
+    capsys.readouterr()
+    for name, p in list(m.model.named_parameters()) + list(m.feature_extractor.named_parameters()):
+        assert torch.isfinite(p).all(), name
+
+
 @pytest.mark.parametrize("kernel", ["bncossim", "cossim"])
 def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
     """correct() / get_logits() with bn_out (running statistics) + F.normalize folded into one Gram launch over the stacked

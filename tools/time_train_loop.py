@@ -45,4 +45,4 @@ for name, hw in (("Conv4S", 28), ("Conv4", 84), ("ResNet10", 224)):
     torch.cuda.synchronize()
     dte = (time.perf_counter() - t1) / n_ep
     sys.stdout = sys.__stdout__
-    print("graph=%s %-9s %3dx%-3d  train_loop %.2f ms / episode (%.0f episodes/s)   test_loop %.2f ms / episode" % (os.environ.get("DKT_TRAIN_GRAPH", "0"), name, hw, hw, 1e3 * dt, 1 / dt, 1e3 * dte), flush=True)
+    print("graph=%s fused_adam=%s %-9s %3dx%-3d  train_loop %.2f ms / episode (%.0f episodes/s)   test_loop %.2f ms / episode" % (os.environ.get("DKT_TRAIN_GRAPH", "0"), os.environ.get("DKT_FUSED_ADAM", "1"), name, hw, hw, 1e3 * dt, 1 / dt, 1e3 * dte), flush=True)
