@@ -26,11 +26,15 @@ class Loader:
 dev = torch.device("cuda", 0)
 for name, hw in (("Conv4S", 28), ("Conv4", 84), ("ResNet10", 224)):
     m = dkt_amd.DKT(getattr(dkt_amd.backbone, name), n_way=5, n_support=5).to(dev)
-    n_ep = 40 if name != "ResNet10" else 12
+    mb = int(os.environ.get("DKT_META_BATCH", "1"))          # episodes per Adam step (train.py --meta_batch)
+    m.meta_batch = mb
+    n_ep = (40 if name != "ResNet10" else 12) * (mb if mb > 1 else 1)
+    if mb > 1 and name == "ResNet10":
+        continue
     ld = Loader(n_ep, 5, 21, hw, 0)
     m.train()
     sys.stdout = open(os.devnull, "w")
-    m.train_loop(0, Loader(3, 5, 21, hw, 1), None, print_freq=1000)      # warm-up (MIOpen find, allocator)
+    m.train_loop(0, Loader(3 * mb, 5, 21, hw, 1), None, print_freq=1000)      # warm-up (MIOpen find, allocator)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     m.train_loop(1, ld, None, print_freq=1000)
@@ -45,4 +49,4 @@ for name, hw in (("Conv4S", 28), ("Conv4", 84), ("ResNet10", 224)):
     torch.cuda.synchronize()
     dte = (time.perf_counter() - t1) / n_ep
     sys.stdout = sys.__stdout__
-    print("graph=%s fused_adam=%s %-9s %3dx%-3d  train_loop %.2f ms / episode (%.0f episodes/s)   test_loop %.2f ms / episode" % (os.environ.get("DKT_TRAIN_GRAPH", "0"), os.environ.get("DKT_FUSED_ADAM", "1"), name, hw, hw, 1e3 * dt, 1 / dt, 1e3 * dte), flush=True)
+    print("meta_batch=%d graph=%s fused_adam=%s %-9s %3dx%-3d  train_loop %.2f ms / episode (%.0f episodes/s)   test_loop %.2f ms / episode" % (mb, os.environ.get("DKT_TRAIN_GRAPH", "0"), os.environ.get("DKT_FUSED_ADAM", "1"), name, hw, hw, 1e3 * dt, 1 / dt, 1e3 * dte), flush=True)
