@@ -17,6 +17,7 @@
 
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st);
+bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st);
 
 namespace {
@@ -361,6 +362,8 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     if (sym && M != N) return DKT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, unit, st))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_big_launch(A, E, B, N, D, unit, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, B), block(256);

@@ -166,6 +166,110 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Symmetric linear Gram for N > 128 and unit-norm rows (DKT_KERNEL_LINEAR_UNIT): 64 x 64 output tiles like the generic fp32 kernel of
+// dkt_gram.hip (which is bound by the fp32 MFMA pipe there: 127-132 TF), with the operands split into two scaled f16 planes while they
+// are staged (dkt_split.h) and 3 x v_mfma_f32_16x16x32_f16 per 32-wide slice and tile instead of 8 x v_mfma_f32_16x16x4_f32; two-level
+// accumulation as in the episode-resident kernels.  Only the lower tiles are computed and mirrored; the tiles of an episode are mapped
+// to one XCD (they re-read the same rows of Z).
+__global__ __launch_bounds__(256, 3) void gram_sym_tiles_f16x2_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D, int nt) {
+    constexpr int GT = 64, BK = 32, SPLD = BK + 16;
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GT * SPLD];     // [buffer][plane]
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][GT * SPLD];
+    const int ntile = nt * (nt + 1) / 2;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int b = (slot / ntile) * 8 + xcd;
+    if (b >= B) return;
+    int tm = 0, rem = slot % ntile;
+    while (rem > tm) { rem -= tm + 1; ++tm; }            // lower triangle, row by row: tile (tm, tn = rem), tn <= tm
+    const int tn = rem;
+    const bool diag = tn == tm;
+    const float* Zb = Z + (size_t)b * N * D;
+    float* Eb = E + (size_t)b * N * N;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q = lane >> 4;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+        const bool in = k0 + lc < D;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rowa = m0 + lr + 32 * h, rowb = n0 + lr + 32 * h;
+            const auto va = __builtin_amdgcn_raw_buffer_load_b128(zr, (in && rowa < N) ? (rowa * D + lc) * 4 : 0x7ffffff0, k0 * 4, 0);
+            ra[h] = make_float4(__uint_as_float(va[0]), __uint_as_float(va[1]), __uint_as_float(va[2]), __uint_as_float(va[3]));
+            if (!diag) {
+                const auto vb = __builtin_amdgcn_raw_buffer_load_b128(zr, (in && rowb < N) ? (rowb * D + lc) * 4 : 0x7ffffff0, k0 * 4, 0);
+                rb[h] = make_float4(__uint_as_float(vb[0]), __uint_as_float(vb[1]), __uint_as_float(vb[2]), __uint_as_float(vb[3]));
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f16x4 hh, mm;
+            split2h(ra[h], 32768.f, hh, mm);
+            *reinterpret_cast<f16x4*>(&As[buf][0][(lr + 32 * h) * SPLD + lc]) = hh;
+            *reinterpret_cast<f16x4*>(&As[buf][1][(lr + 32 * h) * SPLD + lc]) = mm;
+            if (!diag) {
+                split2h(rb[h], 32768.f, hh, mm);
+                *reinterpret_cast<f16x4*>(&Bs[buf][0][(lr + 32 * h) * SPLD + lc]) = hh;
+                *reinterpret_cast<f16x4*>(&Bs[buf][1][(lr + 32 * h) * SPLD + lc]) = mm;
+            }
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (D + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const _Float16* ah_ = As[buf][0];
+        const _Float16* am_ = As[buf][1];
+        const _Float16* bh_ = diag ? As[buf][0] : Bs[buf][0];
+        const _Float16* bm_ = diag ? As[buf][1] : Bs[buf][1];
+        f16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            ah[f] = *reinterpret_cast<const f16x8*>(&ah_[(wm * 32 + 16 * f + r16) * SPLD + 8 * q]);
+            am[f] = *reinterpret_cast<const f16x8*>(&am_[(wm * 32 + 16 * f + r16) * SPLD + 8 * q]);
+            bh[f] = *reinterpret_cast<const f16x8*>(&bh_[(wn * 32 + 16 * f + r16) * SPLD + 8 * q]);
+            bm[f] = *reinterpret_cast<const f16x8*>(&bm_[(wn * 32 + 16 * f + r16) * SPLD + 8 * q]);
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[fi], bm[fj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[fi], bh[fj], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[fi], bh[fj], t, 0, 0, 0);
+                acc[fi][fj] += t;
+            }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    constexpr float UNSCALE = 1.f / (32768.f * 32768.f);
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gm = m0 + wm * 32 + fi * 16 + 4 * q + reg, gn = n0 + wn * 32 + fj * 16 + r16;
+                if (gm >= N || gn >= N) continue;
+                if (diag && gn > gm) continue;           // keep the matrix exactly symmetric
+                const float v = acc[fi][fj][reg] * UNSCALE;
+                Eb[(size_t)gm * N + gn] = v;
+                if (gm != gn) Eb[(size_t)gn * N + gm] = v;
+            }
+}
+
 template <int KS>
 void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
     const int nrb = (N + 63) / 64;
@@ -185,5 +289,15 @@ bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, i
     else if (ks <= 10) launch_rows<10>(W, Z, dZ, B, N, D, sc, st);
     else if (ks <= 12) launch_rows<12>(W, Z, dZ, B, N, D, sc, st);
     else launch_rows<14>(W, Z, dZ, B, N, D, sc, st);
+    return true;
+}
+
+// Returns true when the kernel was launched (symmetric linear Gram, N > 128, unit rows, D % 4 == 0, 16-byte aligned Z).
+bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st) {
+    if (!unit || N <= 128 || (D & 3) || ((uintptr_t)Z & 15)) return false;
+    const int nt = (N + 63) / 64;
+    const long grid = 8L * ((B + 7) / 8) * (nt * (nt + 1) / 2);
+    if (grid > 0x7fffffffL) return false;
+    hipLaunchKernelGGL(gram_sym_tiles_f16x2_kernel, dim3((unsigned)grid), dim3(256), 0, st, Z, E, B, N, D, nt);
     return true;
 }

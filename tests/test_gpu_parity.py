@@ -549,6 +549,25 @@ def test_mll_tile_array_path_edges(cuda, n, c):
             assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
 
 
+@pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (257, 100)])
+def test_gram_large_n_unit_rows_kernel(cuda, n, d):
+    """Symmetric linear Gram at N > 128 with the unit-row promise: the 64 x 64-tile f16-split kernel (dkt_gram_big.hip) against float64
+    and the exact-fp32 generic kernel (same call without the promise); exactly symmetric, unit diagonal."""
+    rng = np.random.default_rng(n + d)
+    z = rng.standard_normal((6, n, d)) * np.exp(1.5 * rng.standard_normal((6, n, d)))          # heavy-tailed before the normalisation
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    zt = dev_t(z, cuda)
+    z = zt.double().cpu().numpy()                           # the fp32 values the kernels see
+    ref = np.einsum("bnd,bmd->bnm", z, z)
+    mag = np.einsum("bnd,bmd->bnm", np.abs(z), np.abs(z))
+    fast = ops.gram(zt, kind=ops.KERNEL_LINEAR_UNIT)
+    slow = ops.gram(zt)
+    assert torch.equal(fast, fast.transpose(1, 2))
+    assert (np.abs(fast.cpu().numpy() - ref) / mag).max() < 6e-7          # measured <= 4.9e-7 (heavy-tailed rows), 2.5e-7 (Gaussian rows)
+    assert (np.abs(slow.cpu().numpy() - ref) / mag).max() < 3e-6          # the sequential fp32 chain: measured up to 2.0e-6
+    assert np.abs(np.diagonal(fast.cpu().numpy(), axis1=1, axis2=2) - 1.0).max() < 2e-6
+
+
 @pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (448, 36), (257, 100)])
 def test_gram_bwd_large_n_symmetric_w_kernel(cuda, n, d):
     """128 < N <= 448 with unit rows and a W declared symmetric: the row-block f16-split kernel (dkt_gram_big.hip) against float64
