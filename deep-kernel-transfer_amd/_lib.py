@@ -104,11 +104,12 @@ def check_resources(usage: dict) -> list:
     """Kernels whose VGPR spill count exceeds their budget (SPILL_BUDGET; default 0)."""
     import re
     bad = []
+    floor = int(os.environ.get("DKT_SPILL_BUDGET_FLOOR", "0"))      # experiments with variant builds only (DKT_EXTRA_HIPCC_FLAGS)
     for name, u in usage.items():
-        budget = 0
+        budget = floor
         for pat, b in SPILL_BUDGET.items():
             if re.search(pat, name):
-                budget = b
+                budget = max(b, floor)
                 break
         if u.get("vgpr_spill", 0) > budget:
             bad.append((name, u.get("vgpr_spill", 0), budget))

@@ -488,8 +488,11 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // W[b] = sum_c coef_c (K_c^-1 - alpha_c alpha_c^T)_s:  output block column J (grid x), episode (grid y); wave w owns rows i = w + 4 aa.
+#ifndef DKT_TILED_W_WGS
+#define DKT_TILED_W_WGS 2
+#endif
 template <int MC>
-__global__ __launch_bounds__(64 * TB, 2) void tiled_w_kernel(TiledArgs t) {
+__global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(TiledArgs t) {
     const MllArgs& a = t.a;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace split of the tile-array marginal-likelihood path (tools/time_tiled.py); summary -> gpurun_out/prof_tiled/summary.txt
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_tiled
-mkdir -p $OUT
+rm -rf $OUT/stats; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/tools/time_tiled.py "$@" > $OUT/stats.log 2>&1
 tail -3 $OUT/stats.log
