@@ -42,6 +42,14 @@ using namespace dkt_mfma;
 #else
 #define DKT_CLK(i) do { } while (0)
 #endif
+// Issue priority of a wave while it sweeps a diagonal tile (VALU work that competes for the shared fp32-MFMA / VALU pipe with the
+// matrix instructions of the other waves of the SIMD): s_setprio.  0 = off.  Measured: -2 % (N = 105) / -3.5 % (N = 85) at 1; 3, or the
+// whole factorisation at 1, are no different.
+#ifndef DKT_MFMA_SWEEP_PRIO
+#define DKT_MFMA_SWEEP_PRIO 1
+#endif
+#define DKT_SWEEP_PRIO(p) do { if (DKT_MFMA_SWEEP_PRIO) __builtin_amdgcn_s_setprio(p); } while (0)
+
 constexpr int ntt(int nt) { return nt * (nt + 1) / 2; }
 __host__ __device__ constexpr int tidx(int i, int j) { return j * (j + 1) / 2 + i; }      // i <= j (the order the tile loops enumerate)
 
@@ -239,8 +247,10 @@ __device__ __forceinline__ void phase1_step(Tiles<NT>& T, const FormCtx& f, P1Ct
             c.clk[14 + 2 * K] = __builtin_amdgcn_s_memtime();      // panel + tile row K + 1 issued
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            DKT_SWEEP_PRIO(DKT_MFMA_SWEEP_PRIO);
             sweep_begin(T.t[K + 1][K + 1], x, dv);
             sweep_interleaved<NT, K, 0, K + 1 == NT - 1>(T, f, x, dv, ln, c.pN);
+            DKT_SWEEP_PRIO(0);
             phase1_step<NT, K + 1, CHOL>(T, f, c, x, dv, ln);
         }
     }
@@ -391,8 +401,10 @@ void mll_mfma_kernel(MllArgs a, const int wpg) {
 #endif
                 {
                     float dv, x[16];
+                    DKT_SWEEP_PRIO(DKT_MFMA_SWEEP_PRIO);
                     sweep_begin(T.t[0][0], x, dv);
                     sweep_interleaved<NT, -1, 0, NT == 1>(T, f, x, dv, ln, pN);
+                    DKT_SWEEP_PRIO(0);
                     phase1_step<NT, 0, CHOL>(T, f, pc, x, dv, ln);
                 }
                 fail_at = pc.fail_at; lsum = pc.lsum; quad = pc.quad;
