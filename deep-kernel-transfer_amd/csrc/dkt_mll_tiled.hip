@@ -38,7 +38,7 @@ struct TiledScal {                            // per matrix, factor -> invert ->
 struct TiledArgs {
     MllArgs a;
     float* tiles;                             // [nmat][NTT + 1][256]; tile NTT of every matrix is all zero
-    float* etiles;                            // [episodes of the chunk][NTT][256]: E[b] in tile layout
+    float* etiles;                            // [episodes of the chunk][NTT + 1][256]: E[b] in tile layout (+ a zero tile)
     TiledScal* scal;                          // [nmat]
     int b0, NT, bcnt;
 };
@@ -74,7 +74,11 @@ struct FormRt {
 __global__ __launch_bounds__(256) void tiled_etile_kernel(const float* __restrict__ E, float* __restrict__ Et, int b0, int N, int NT) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
     const int ntt = NT * (NT + 1) / 2, bl = blockIdx.y, slot = blockIdx.x * 4 + wave;
-    if (slot >= ntt) return;
+    if (slot > ntt) return;
+    if (slot == ntt) {                                   // the all-zero tile absent tiles are read from
+        reinterpret_cast<f32x4*>(Et + ((size_t)bl * (ntt + 1) + slot) * 256)[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     int i = 0, rem = slot;
     while (rem >= NT - i) { rem -= NT - i; ++i; }                           // slot -> (i, j): tile rows are contiguous
     const int j = i + rem;
@@ -88,14 +92,13 @@ __global__ __launch_bounds__(256) void tiled_etile_kernel(const float* __restric
         for (int q = 0; q < 4; ++q)
             e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
     }
-    reinterpret_cast<f32x4*>(Et + ((size_t)bl * ntt + slot) * 256)[lane] = e;
+    reinterpret_cast<f32x4*>(Et + ((size_t)bl * (ntt + 1) + slot) * 256)[lane] = e;
 }
 
 // Tile (i, j), i <= j, of S = -K' / kappa in the accumulator layout from the episode's E tiles; the augmented column / row, its zero
 // pivot and the identity padding as in form_tile of dkt_mll_mfma.hip.
-__device__ __forceinline__ f32x4 form_tile_rt(const FormRt& f, const Geo& g, const int i, const int j) {
+__device__ __forceinline__ f32x4 form_from_e(const FormRt& f, const Geo& g, const int i, const int j, const f32x4 e) {
     const int NT = g.NT, N = g.N, pN = g.pN, c16 = g.c16, g4 = g.g4;
-    const f32x4 e = bload4(f.Et, g.lane * 16, tslot(NT, i, j) * 1024);
     f32x4 s;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     const int msc = max(0, (ex + 1) >> 1);
     const float ikap = ldexpf(1.0f, -2 * msc);
     FormRt f;
-    f.Et = mk_rsrc(t.etiles + (size_t)bl * ntt * 256, (unsigned)(ntt * 1024));
+    f.Et = mk_rsrc(t.etiles + (size_t)bl * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
     f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
     f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc);
     const f32x4 negI = neg_identity(g);
@@ -206,15 +209,15 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     for (int i0 = 0; i0 < NT; i0 += TB) {
         f32x4 acc[TB][MC];
         TCLK(5);
-        // ---- init from E ----
-#pragma unroll
-        for (int r = 0; r < TB; ++r)
+        // ---- K loop over the finished tile rows, operands double-buffered; its first four steps are the block's own E tiles (one tile
+        //      row per step, S = -(sv E + noise I) / kappa formed by the VALU as they arrive), so that their latency is hidden too ----
+        auto loade = [&](f32x4 (&Y)[MC], const int r) {
 #pragma unroll
             for (int bb = 0; bb < MC; ++bb) {
                 const int i = i0 + r, j = i0 + w + TB * bb;
-                acc[r][bb] = (i < NT && j < NT && j >= i) ? form_tile_rt(f, g, i, j) : zero4;
+                Y[bb] = bload4(f.Et, lane16, ((i < NT && j < NT && j >= i) ? tslot(NT, i, j) : (int)ntt) * 1024);
             }
-        // ---- K loop over the finished tile rows, operands double-buffered ----
+        };
         auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int kt) {
             const bool kin = kt < i0;
 #pragma unroll
@@ -231,10 +234,25 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                 if (i0 + w + TB * bb < NT) xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
             }
         };
-        TCLK(0);
-        if (i0 > 0) {
+        {
             f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
+            auto forme = [&](const f32x4 (&Y)[MC], const int r) {               // r is a constant after unrolling
+#pragma unroll
+                for (int bb = 0; bb < MC; ++bb) {
+                    const int i = i0 + r, j = i0 + w + TB * bb;
+                    acc[r][bb] = (i < NT && j < NT && j >= i) ? form_from_e(f, g, i, j, Y[bb]) : zero4;
+                }
+            };
+            loade(Y0, 0);
+            loade(Y1, 1);
+            forme(Y0, 0);
+            loade(Y0, 2);
+            forme(Y1, 1);
+            loade(Y1, 3);
+            forme(Y0, 2);
             loadk(X0, Y0, 0);
+            forme(Y1, 3);
+            TCLK(0);
             for (int kt = 0; kt < i0; kt += 2) {
                 loadk(X1, Y1, kt + 1);
                 mulk(X0, Y0);
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(Tiled
 inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
 inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
-    size_t fl = nmat * (ntt + 1) * 256 + (size_t)Bc * ntt * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
+    size_t fl = nmat * (ntt + 1) * 256 + (size_t)Bc * (ntt + 1) * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
     const size_t gen = dkt_mll_generic_global_floats(Bc, N);               // the fix-up pass works in the same region
     return fl > gen ? fl : gen;
 }
@@ -600,7 +618,7 @@ constexpr int TILED_CHUNK = 1024;          // episodes per pass over the workspa
 template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
-    hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
+    hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
     hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(64 * TB), 0, st, t);
 #ifdef DKT_TILED_CLOCKS
     return;
@@ -635,7 +653,7 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
     t.a = a;
     t.tiles = (float*)workspace;
     t.etiles = t.tiles + nmat_max * (ntt + 1) * 256;
-    t.scal = (TiledScal*)(t.etiles + (size_t)Bc * ntt * 256);
+    t.scal = (TiledScal*)(t.etiles + (size_t)Bc * (ntt + 1) * 256);
     t.NT = NT;
     const bool grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     const int mc = (NT + TB - 1) / TB;
