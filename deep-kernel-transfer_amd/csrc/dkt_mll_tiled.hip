@@ -515,7 +515,12 @@ __global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(Tiled
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, NT = t.NT, C = a.C;
-    const int j0 = blockIdx.x * TB, bl = blockIdx.y, b = t.b0 + bl;
+    // workgroup -> (episode, block column): the block columns of an episode read the same tile arrays class by class, so they are given
+    // workgroup ids 8 apart (consecutive ids go to consecutive XCDs): one XCD, one L2
+    const int nblk = (NT + TB - 1) / TB;
+    const int bl = ((int)(blockIdx.x >> 3) / nblk) * 8 + (int)(blockIdx.x & 7);
+    if (bl >= t.bcnt) return;
+    const int j0 = ((int)(blockIdx.x >> 3) % nblk) * TB, b = t.b0 + bl;
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
@@ -625,7 +630,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 #endif
     if (grad) {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, true>), dim3(nmat), dim3(64 * TB), 0, st, t);
-        hipLaunchKernelGGL((tiled_w_kernel<MC>), dim3((t.NT + TB - 1) / TB, bcnt), dim3(64 * TB), 0, st, t);
+        hipLaunchKernelGGL((tiled_w_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB)), dim3(64 * TB), 0, st, t);
     } else {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, false>), dim3(nmat), dim3(64 * TB), 0, st, t);
     }
