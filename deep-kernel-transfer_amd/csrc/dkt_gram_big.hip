@@ -13,8 +13,11 @@
 // staging as gram_bwd_ep_f16x2_kernel), from which a lane's 8 consecutive-row B values are one ds_read_b128.  The row blocks of an
 // episode re-read the same Z slabs: the workgroup -> (episode, row block) map keeps them on ONE XCD (workgroup id mod 8 = XCD), so
 // the re-reads are served by that XCD's L2.
+#include <type_traits>
 #include "dkt_split.h"
 #include "../../include/dkt_abi.h"
+
+bool dkt_gram_split_enabled();           // dkt_gram_ep.hip: DKT_GRAM_SPLIT
 
 namespace {
 
@@ -167,15 +170,19 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Symmetric linear Gram for N > 128 and unit-norm rows (DKT_KERNEL_LINEAR_UNIT): 64 x 64 output tiles like the generic fp32 kernel of
-// dkt_gram.hip (which is bound by the fp32 MFMA pipe there: 127-132 TF), with the operands split into two scaled f16 planes while they
-// are staged (dkt_split.h) and 3 x v_mfma_f32_16x16x32_f16 per 32-wide slice and tile instead of 8 x v_mfma_f32_16x16x4_f32; two-level
-// accumulation as in the episode-resident kernels.  Only the lower tiles are computed and mirrored; the tiles of an episode are mapped
-// to one XCD (they re-read the same rows of Z).
-__global__ __launch_bounds__(256, 3) void gram_sym_tiles_f16x2_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D, int nt) {
+// Symmetric linear Gram for N > 128: 64 x 64 output tiles like the generic fp32 kernel of dkt_gram.hip (which is bound by the fp32
+// MFMA pipe there: 127-132 TF), with the operands split while they are staged (dkt_split.h) -- SPL = 2: two scaled f16 planes for
+// unit-norm rows (DKT_KERNEL_LINEAR_UNIT), 3 x v_mfma_f32_16x16x32_f16 per 32-wide slice and tile; SPL = 3: the exact 3-way bf16
+// split for operands of any range, 6 x v_mfma_f32_16x16x32_bf16 -- instead of 8 x v_mfma_f32_16x16x4_f32; two-level accumulation as in
+// the episode-resident kernels.  Only the lower tiles are computed and mirrored; the tiles of an episode are mapped to one XCD (they
+// re-read the same rows of Z).
+template <int SPL>
+__global__ __launch_bounds__(256, SPL == 2 ? 3 : 2) void gram_sym_tiles_split_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D, int nt) {
     constexpr int GT = 64, BK = 32, SPLD = BK + 16;
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GT * SPLD];     // [buffer][plane]
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][GT * SPLD];
+    typedef typename std::conditional<SPL == 2, _Float16, __bf16>::type half_t;
+    typedef typename std::conditional<SPL == 2, f16x8, bf16x8>::type frag_t;
+    __shared__ __attribute__((aligned(16))) half_t As[2][SPL][GT * SPLD];     // [buffer][plane]
+    __shared__ __attribute__((aligned(16))) half_t Bs[2][SPL][GT * SPLD];
     const int ntile = nt * (nt + 1) / 2;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int b = (slot / ntile) * 8 + xcd;
@@ -204,18 +211,25 @@ __global__ __launch_bounds__(256, 3) void gram_sym_tiles_f16x2_kernel(const floa
             }
         }
     };
+    auto put = [&](half_t (&planes)[SPL][GT * SPLD], const float4& v, int row) {
+        if constexpr (SPL == 2) {
+            f16x4 hh, mm;
+            split2h(v, 32768.f, hh, mm);
+            *reinterpret_cast<f16x4*>(&planes[0][row * SPLD + lc]) = hh;
+            *reinterpret_cast<f16x4*>(&planes[1][row * SPLD + lc]) = mm;
+        } else {
+            bf16x4 hh, mm, ll;
+            split3(v, hh, mm, ll);
+            *reinterpret_cast<bf16x4*>(&planes[0][row * SPLD + lc]) = hh;
+            *reinterpret_cast<bf16x4*>(&planes[1][row * SPLD + lc]) = mm;
+            *reinterpret_cast<bf16x4*>(&planes[2][row * SPLD + lc]) = ll;
+        }
+    };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f16x4 hh, mm;
-            split2h(ra[h], 32768.f, hh, mm);
-            *reinterpret_cast<f16x4*>(&As[buf][0][(lr + 32 * h) * SPLD + lc]) = hh;
-            *reinterpret_cast<f16x4*>(&As[buf][1][(lr + 32 * h) * SPLD + lc]) = mm;
-            if (!diag) {
-                split2h(rb[h], 32768.f, hh, mm);
-                *reinterpret_cast<f16x4*>(&Bs[buf][0][(lr + 32 * h) * SPLD + lc]) = hh;
-                *reinterpret_cast<f16x4*>(&Bs[buf][1][(lr + 32 * h) * SPLD + lc]) = mm;
-            }
+            put(As[buf], ra[h], lr + 32 * h);
+            if (!diag) put(Bs[buf], rb[h], lr + 32 * h);
         }
     };
     f32x4 acc[2][2];
@@ -230,31 +244,37 @@ __global__ __launch_bounds__(256, 3) void gram_sym_tiles_f16x2_kernel(const floa
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
-        const _Float16* ah_ = As[buf][0];
-        const _Float16* am_ = As[buf][1];
-        const _Float16* bh_ = diag ? As[buf][0] : Bs[buf][0];
-        const _Float16* bm_ = diag ? As[buf][1] : Bs[buf][1];
-        f16x8 ah[2], am[2], bh[2], bm[2];
+        frag_t af[SPL][2], bf[SPL][2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            ah[f] = *reinterpret_cast<const f16x8*>(&ah_[(wm * 32 + 16 * f + r16) * SPLD + 8 * q]);
-            am[f] = *reinterpret_cast<const f16x8*>(&am_[(wm * 32 + 16 * f + r16) * SPLD + 8 * q]);
-            bh[f] = *reinterpret_cast<const f16x8*>(&bh_[(wn * 32 + 16 * f + r16) * SPLD + 8 * q]);
-            bm[f] = *reinterpret_cast<const f16x8*>(&bm_[(wn * 32 + 16 * f + r16) * SPLD + 8 * q]);
-        }
+        for (int pl = 0; pl < SPL; ++pl)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                af[pl][f] = *reinterpret_cast<const frag_t*>(&As[buf][pl][(wm * 32 + 16 * f + r16) * SPLD + 8 * q]);
+                bf[pl][f] = *reinterpret_cast<const frag_t*>(&(diag ? As[buf][pl] : Bs[buf][pl])[(wn * 32 + 16 * f + r16) * SPLD + 8 * q]);
+            }
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
             for (int fj = 0; fj < 2; ++fj) {
-                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[fi], bm[fj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[fi], bh[fj], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[fi], bh[fj], t, 0, 0, 0);
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPL == 2) {
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][fi], bf[1][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1][fi], bf[0][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][fi], bf[0][fj], t, 0, 0, 0);
+                } else {                                 // smallest terms first: mm, hl, lh, hm, mh, hh
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][fi], bf[1][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][fi], bf[2][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][fi], bf[0][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][fi], bf[1][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][fi], bf[0][fj], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][fi], bf[0][fj], t, 0, 0, 0);
+                }
                 acc[fi][fj] += t;
             }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    constexpr float UNSCALE = 1.f / (32768.f * 32768.f);
+    constexpr float UNSCALE = SPL == 2 ? 1.f / (32768.f * 32768.f) : 1.f;
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -282,7 +302,7 @@ void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D,
 // Returns true when the kernel was launched (128 < N <= 448, unit rows, symmetric W, D % 4 == 0, 16-byte aligned Z / dZ).
 bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st) {
     if (N <= 128 || N > 448 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 7)) return false;
-    if (!(flags & DKT_GRAM_UNIT_ROWS) || !(flags & DKT_GRAM_W_SYMMETRIC)) return false;
+    if (!(flags & DKT_GRAM_UNIT_ROWS) || !(flags & DKT_GRAM_W_SYMMETRIC) || !dkt_gram_split_enabled()) return false;
     const int ks = (N + 31) / 32;
     if (ks <= 6) launch_rows<6>(W, Z, dZ, B, N, D, sc, st);
     else if (ks <= 8) launch_rows<8>(W, Z, dZ, B, N, D, sc, st);
@@ -292,12 +312,13 @@ bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, i
     return true;
 }
 
-// Returns true when the kernel was launched (symmetric linear Gram, N > 128, unit rows, D % 4 == 0, 16-byte aligned Z).
+// Returns true when the kernel was launched (symmetric linear Gram, N > 128, D % 4 == 0, 16-byte aligned Z).
 bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st) {
-    if (!unit || N <= 128 || (D & 3) || ((uintptr_t)Z & 15)) return false;
+    if (N <= 128 || (D & 3) || ((uintptr_t)Z & 15) || !dkt_gram_split_enabled()) return false;
     const int nt = (N + 63) / 64;
     const long grid = 8L * ((B + 7) / 8) * (nt * (nt + 1) / 2);
     if (grid > 0x7fffffffL) return false;
-    hipLaunchKernelGGL(gram_sym_tiles_f16x2_kernel, dim3((unsigned)grid), dim3(256), 0, st, Z, E, B, N, D, nt);
+    if (unit) hipLaunchKernelGGL(gram_sym_tiles_split_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, Z, E, B, N, D, nt);
+    else hipLaunchKernelGGL(gram_sym_tiles_split_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, Z, E, B, N, D, nt);
     return true;
 }

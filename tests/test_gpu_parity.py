@@ -560,11 +560,20 @@ def test_gram_large_n_unit_rows_kernel(cuda, n, d):
     z = zt.double().cpu().numpy()                           # the fp32 values the kernels see
     ref = np.einsum("bnd,bmd->bnm", z, z)
     mag = np.einsum("bnd,bmd->bnm", np.abs(z), np.abs(z))
-    fast = ops.gram(zt, kind=ops.KERNEL_LINEAR_UNIT)
-    slow = ops.gram(zt)
-    assert torch.equal(fast, fast.transpose(1, 2))
+    fast = ops.gram(zt, kind=ops.KERNEL_LINEAR_UNIT)                      # 2-way f16 split (unit rows)
+    mid = ops.gram(zt)                                                    # exact 3-way bf16 split (any range), same tile kernel
+    os.environ["DKT_GRAM_SPLIT"] = "0"
+    try:
+        slow = ops.gram(zt)                                               # generic exact-fp32 MFMA kernel
+    finally:
+        os.environ.pop("DKT_GRAM_SPLIT")
+    assert torch.equal(fast, fast.transpose(1, 2)) and torch.equal(mid, mid.transpose(1, 2))
     assert (np.abs(fast.cpu().numpy() - ref) / mag).max() < 6e-7          # measured <= 4.9e-7 (heavy-tailed rows), 2.5e-7 (Gaussian rows)
+    assert (np.abs(mid.cpu().numpy() - ref) / mag).max() < 6e-7
     assert (np.abs(slow.cpu().numpy() - ref) / mag).max() < 3e-6          # the sequential fp32 chain: measured up to 2.0e-6
+    zs = zt * 37.5                                                        # rows far from unit norm: only the range-free split may be used
+    big = ops.gram(zs)
+    assert (np.abs(big.cpu().numpy() - 37.5 * 37.5 * ref) / (37.5 * 37.5 * mag)).max() < 6e-7
     assert np.abs(np.diagonal(fast.cpu().numpy(), axis1=1, axis2=2) - 1.0).max() < 2e-6
 
 
