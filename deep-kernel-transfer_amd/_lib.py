@@ -16,13 +16,12 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
-SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_predict.hip",
+SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_h2.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_predict.hip",
            "dkt_spectral.hip", "dkt_frontend.hip"]
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
 DIAG_SOURCES = ["dkt_diag.hip"]
 DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
-HEADERS = [os.path.join(CSRC, "dkt_common.h"), os.path.join(CSRC, "dkt_mll.h"), os.path.join(CSRC, "dkt_tiles.h"),
-           os.path.join(CSRC, "dkt_split.h"), os.path.join(INCLUDE, "dkt_abi.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "dkt_abi.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 _c_p = ctypes.c_void_p
@@ -70,6 +69,9 @@ def _flags() -> list:
 # values of the round prologue in scratch across the factorisation -- stored / reloaded once per matrix, none inside the sweeps or
 # the MFMA phases.  The check fails the build when a change makes the compiler spill inside the hot loops.
 SPILL_BUDGET = {
+    r"mll_h2e_kernelILi7E": 40,                    # wave-per-episode kernel at its 256-VGPR cap (two waves per SIMD)
+    r"mll_h2_kernelILi7ELb1ELb1": 32,              # <NT = 7, GRAD, 5 waves per episode>: the bench kernel (f16-split default since round 3)
+    r"mll_h2_kernelILi[67]E": 32,
     r"mll_mfma_kernelILi7ELb1ELb0ELb1": 16,        # <NT = 7, GRAD, !CHOL, 5 waves per episode>: the bench kernel
     r"mll_mfma_kernelILi[78]E": 260,               # other NT >= 7 instantiations (Cholesky output, odd class counts): not on a hot path
     r"mll_mfma_kernelILi[56]E": 120,

@@ -406,3 +406,116 @@ extern "C" int dkt_diag_overlap_ubench(float* out, int nblocks, int iters, int r
     hipLaunchKernelGGL(overlap_ubench_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, out, iters, role);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- the f16-split tile primitives of dkt_h2_tiles.h in isolation (tests/test_gpu_parity.py::test_h2_tile_primitives) ----
+// in: X[16][16], Y[16][16] row-major, sx, sy.  out (row-major 16 x 16 each): 0: join(split(X, sx)) = sx X;
+// 1: split(X, sx)^T split(Y, sy) (three plane products) = sx sy X^T Y;  2: join(neg_transpose(split(X, sx))) = -sx X^T;
+// 3: the h plane of split(X, sx) as fp32;  4: the m plane.
+#include "dkt_h2_tiles.h"
+namespace {
+__global__ __launch_bounds__(64) void h2_primitives_kernel(const float* in, float* out, float sx, float sy) {
+    using namespace dkt_mfma;
+    const int l = threadIdx.x, g4 = (l >> 2) & 12, c = l & 15;
+    f32x4 X, Y;
+    for (int q = 0; q < 4; ++q) { X[q] = in[(g4 + q) * 16 + c]; Y[q] = in[256 + (g4 + q) * 16 + c]; }
+    sx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sx)));
+    sy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sy)));
+    const f32x4 xs = split_h2(X, sx), ys = split_h2(Y, sy);
+    const f32x4 j = join_h2(xs);
+    const f32x4 p = xtyh0(xs, ys);
+    h4 negI;
+    for (int q = 0; q < 4; ++q) negI[q] = (g4 + q == c) ? (_Float16)-1.0f : (_Float16)0.0f;
+    const f32x4 t = join_h2(neg_transpose_h2(xs, negI));
+    const Sp sp = as_sp(xs);
+    for (int q = 0; q < 4; ++q) {
+        out[0 * 256 + (g4 + q) * 16 + c] = j[q];
+        out[1 * 256 + (g4 + q) * 16 + c] = p[q];
+        out[2 * 256 + (g4 + q) * 16 + c] = t[q];
+        out[3 * 256 + (g4 + q) * 16 + c] = (float)sp.h[q];
+        out[4 * 256 + (g4 + q) * 16 + c] = (float)sp.m[q];
+    }
+}
+
+// issue rates of the f16 matrix instructions next to VALU work (tools/ubench_valu.py): role 0: all 8 waves v_mfma_f32_16x16x16_f16
+// (4 chains); 1: all waves v_mfma_f32_16x16x32_f16; 2: waves 0-3 16x16x16 f16, waves 4-7 v_fmac_f32; 3: every wave alternates
+// one 16x16x16 f16 MFMA with 4 v_fmac_f32; 4: every wave alternates one fp32 16x16x4 MFMA with 4 v_fmac_f32; 5: every wave alternates one
+// 16x16x16 f16 MFMA with 4 v_fma_mixlo_f16.  out[wave] = ticks per MFMA (VALU-only waves: per v_fmac).
+__global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters, int role) {
+    using namespace dkt_mfma;
+    const int wave = threadIdx.x >> 6;
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = 1.0f + threadIdx.x * 1e-3f + i;
+    float t = 1e-6f;
+    f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    h4 x, y;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 x8, y8;
+    for (int e = 0; e < 4; ++e) { x[e] = (_Float16)a[e]; y[e] = (_Float16)a[4 + e]; }
+    for (int e = 0; e < 8; ++e) { x8[e] = (_Float16)a[e]; y8[e] = (_Float16)a[8 + e]; }
+    __syncthreads();
+    float per = 16.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (role == 0 || (role == 2 && wave < 4)) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, c3, 0, 0, 0);
+            }
+        }
+    } else if (role == 1) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x8, y8, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x8, y8, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x8, y8, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x8, y8, c3, 0, 0, 0);
+            }
+        }
+    } else if (role == 2) {
+        for (int it = 0; it < iters; ++it) {
+#define DG_X(k) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t));
+            DG_REP16(DG_X)
+#undef DG_X
+        }
+    } else if (role == 3 || role == 5) {
+        per = 4.f;
+        for (int it = 0; it < iters; ++it) {
+#define DG_M(cc) cc = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, cc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define DG_V(k) if (role == 3) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t)); else asm volatile("v_fma_mixlo_f16 %0, %1, %1, 0" : "+v"(a[k]) : "v"(t)); 
+            DG_M(c0) DG_V(0) DG_V(1) DG_V(2) DG_V(3) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c1) DG_V(4) DG_V(5) DG_V(6) DG_V(7) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c2) DG_V(8) DG_V(9) DG_V(10) DG_V(11) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c3) DG_V(12) DG_V(13) DG_V(14) DG_V(15) __builtin_amdgcn_sched_barrier(0);
+#undef DG_M
+        }
+    } else {
+        per = 4.f;
+        for (int it = 0; it < iters; ++it) {
+#define DG_M(cc) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], cc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            DG_M(c0) DG_V(2) DG_V(3) DG_V(4) DG_V(5) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c1) DG_V(6) DG_V(7) DG_V(8) DG_V(9) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c2) DG_V(10) DG_V(11) DG_V(12) DG_V(13) __builtin_amdgcn_sched_barrier(0);
+            DG_M(c3) DG_V(14) DG_V(15) DG_V(2) DG_V(3) __builtin_amdgcn_sched_barrier(0);
+#undef DG_M
+#undef DG_V
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = c0[0] + c1[1] + c2[2] + c3[3];
+    for (int i = 0; i < 16; ++i) s += a[i];
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + wave] = (float)(t1 - t0) / (per * iters);
+    if (s == 123.456f) out[0] = s;
+}
+}  // namespace
+extern "C" int dkt_diag_h2_primitives(const float* in, float* out, float sx, float sy, void* stream) {
+    hipLaunchKernelGGL(h2_primitives_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out, sx, sy);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+extern "C" int dkt_diag_h2_ubench(float* out, int nblocks, int iters, int role, void* stream) {
+    hipLaunchKernelGGL(h2_ubench_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, out, iters, role);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -31,7 +31,11 @@ struct MllArgs {
 
 constexpr float DKT_HALF_LOG_2PI = 0.91893853320467274178f;
 
-// Wave-per-class-matrix MFMA path (dkt_mll_mfma.hip): the default for N + 1 <= 128.  Returns false when N is out of range.
+// Wave-per-class-matrix path on the f16 matrix pipe (dkt_mll_h2.hip): the default for N + 1 <= 128 unless the Cholesky factors are
+// requested.  Returns false when it does not apply.
+bool dkt_mll_h2_launch(const MllArgs& a, hipStream_t st);
+// The same structure on the exact-fp32 matrix instruction (dkt_mll_mfma.hip): DKT_MLL_FORCE_F32MFMA twin, and DKT_MLL_WANT_CHOL.
+// Returns false when N is out of range.
 bool dkt_mll_mfma_launch(const MllArgs& a, hipStream_t st);
 // Register-resident sweep (dkt_mll_reg.hip; the round-1 default, kept as the DKT_MLL_FORCE_REG validation twin): N + 1 <= 128.
 bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st);

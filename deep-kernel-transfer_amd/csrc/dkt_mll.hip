@@ -227,6 +227,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags) && workspace &&

@@ -31,6 +31,7 @@ MLL_WANT_CHOL = 2
 MLL_FORCE_GENERIC = 4
 MLL_FORCE_REG = 8
 MLL_FORCE_BLOCKED = 16
+MLL_FORCE_F32MFMA = 32
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -105,7 +106,7 @@ class _timed:
 # raw (non-differentiable) entry points
 # ------------------------------------------------------------------------------------------------
 _ENV_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_EP_MINB", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR",
-                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND")
+                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_H2E_MINB")
 _env_seen = None
 
 
@@ -145,8 +146,9 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
 def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
         jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False,
-        force_blocked: bool = False) -> dict:
-    """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N]."""
+        force_blocked: bool = False, force_f32mfma: bool = False) -> dict:
+    """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N].
+    force_*: the parity-tested twins of the default kernels (DKT_MLL_FORCE_* of include/dkt_abi.h)."""
     e = _req(e, "e", 3)
     b_, n, n2 = e.shape
     if n != n2:
@@ -170,7 +172,8 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
-    flags = (MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0)
+    flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
+             (MLL_FORCE_F32MFMA if force_f32mfma else 0))
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL
@@ -184,6 +187,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     if cls_weight is not None:
         cls_weight = _req(cls_weight.reshape(-1), "cls_weight", 1)
     lib = _lib.load()
+    _sync_env(lib)
     ws_bytes = int(lib.dkt_mll_workspace_bytes(b_, c_, n))
     ws = torch.empty((max(ws_bytes, 4) + 3) // 4, device=dev, dtype=torch.float32) if ws_bytes else None
     with _timed("dkt_mll_f32"):

@@ -57,6 +57,7 @@ extern "C" {
 #define DKT_MLL_FORCE_GENERIC 4u /* validation aid: take the generic LDS/global path for any N  */
 #define DKT_MLL_FORCE_REG 8u     /* validation aid: the register-sweep kernel instead of the MFMA wave-per-matrix kernel (N <= 127) */
 #define DKT_MLL_FORCE_BLOCKED 16u /* validation aid: the blocked batched-GEMM path instead of the tile-array kernels (N > 127) */
+#define DKT_MLL_FORCE_F32MFMA 32u /* validation aid: the exact-fp32 MFMA wave-per-matrix kernel instead of the f16-split one (N <= 127) */
 
 int dkt_abi_version(void);
 

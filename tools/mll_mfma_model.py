@@ -280,3 +280,197 @@ def main_tiled():
 
 if __name__ == "__main__" and "tiled" in __import__("sys").argv:
     main_tiled()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Scaled 2-way f16 split variant (csrc/dkt_mll_h2.hip): the same three phases with every tile product on
+# v_mfma_f32_16x16x16_f16.  A tile in the accumulator layout is, with its four registers converted to f16 and packed, a legal A
+# operand (lane (g, c), element e  <->  A[c][4g + e] = X[4g + e][c], i.e. A = X^T) AND a legal B operand (B[4g + e][c] = Y[4g + e][c])
+# of that instruction, so D += X^T Y is ONE instruction per pair of f16 planes; a stored tile is the pair (h, m) = (f16(x s),
+# f16(x s - h)) -- 4 VGPRs, like the fp32 tile -- and a product is hm + mh + hh (the m m term, 2^-22 relative, is dropped).
+# Every scale is a power of two and rigorous: Schur complements and R are bounded by 1 after the kappa scaling (s = 2^15),
+# |M| = |R^-T| <= mu = sqrt(kappa / (noise + jitter)) (s = 2^15 / mu2), the augmented column is scaled by rho <= 1 / (|r_s| mu2).
+# f16 is a FLOATING format: an element keeps 22 significand bits as long as it is within 2^-18 of the bound, so a loose bound
+# costs nothing.  float32 arithmetic everywhere the GPU uses it (sweeps, accumulators); `trunc` models an MFMA whose final
+# rounding truncates.
+F32 = np.float32
+
+
+def _f16_in(v):
+    """an MFMA input: f16 subnormals are flushed"""
+    v = np.asarray(v, dtype=np.float16)
+    return np.where(np.abs(v.astype(F32)) < 2.0 ** -14, np.float16(0), v)
+
+
+def mfma16(a4, b4, c, trunc=False):
+    """v_mfma_f32_16x16x16_f16: a4 / b4 = [4][64] f16 (lane (g, c), element e: A[c][4g + e], B[4g + e][c]); c = [4][64] f32."""
+    A = np.zeros((16, 16)); Bm = np.zeros((16, 16))
+    a4 = _f16_in(a4).astype(np.float64); b4 = _f16_in(b4).astype(np.float64)
+    for e in range(4):
+        A[Cc, 4 * G + e] = a4[e]
+        Bm[4 * G + e, Cc] = b4[e]
+    D = A @ Bm
+    out = np.empty((4, 64), dtype=F32)
+    for r in range(4):
+        s = c[r].astype(np.float64) + D[4 * G + r, Cc]
+        if trunc:
+            f = s.astype(F32)
+            f = np.where(np.abs(f.astype(np.float64)) > np.abs(s), np.nextafter(f, F32(0)), f)
+            out[r] = f
+        else:
+            out[r] = s.astype(F32)
+    return out
+
+
+def split2(x, scale):
+    xs = (np.asarray(x, dtype=F32) * F32(scale)).astype(F32)
+    h = xs.astype(np.float16)
+    m = (xs - h.astype(F32)).astype(F32).astype(np.float16)
+    assert np.all(np.isfinite(h.astype(F32))), "f16 overflow: a scale bound is violated"
+    return h, m
+
+
+def xtyh(X, Y, C=None, trunc=False):
+    """C + X^T Y on split tiles, small terms first"""
+    out = np.zeros((4, 64), dtype=F32) if C is None else C
+    out = mfma16(X[0], Y[1], out, trunc)
+    out = mfma16(X[1], Y[0], out, trunc)
+    return mfma16(X[0], Y[0], out, trunc)
+
+
+def sweep32(S, pn=None, om2_min=1.0):
+    """the diagonal-tile sweep in float32 (the GPU's arithmetic).  The augmented pivot is forced to omega^2 = the power of 4 above
+    max(|raw pivot|, om2_min) -- the raw value is rho^2 |w|^2 -- which lifts row N of M (-rho alpha_s^T / omega, M_NN = 1 / omega) to
+    within |M|'s bound: |rho alpha_s| / omega <= mu rho |w| / omega <= mu, 1 / omega <= mu2."""
+    x = to_columns(S).astype(F32)
+    dv = np.ones(64, dtype=F32)
+    one = F32(1.0)
+    for p in range(16):
+        d = -bcast(x[p], p)
+        eq = Cc == p
+        dv = np.where(eq, d, dv)
+        if pn is not None and p == pn:
+            ex = int(np.frexp(max(abs(float(d[0])), om2_min))[1])
+            om2 = 4.0 ** ((ex + 1) >> 1)
+            d = np.full(64, om2, dtype=F32)
+        rs = (one / np.sqrt(d)).astype(F32)
+        rs2 = rs * rs
+        t = np.where(eq, (one - d) * rs2, x[p] * rs2).astype(F32)
+        x[p] = np.where(eq, rs, x[p] * rs).astype(F32)
+        for i in range(p + 1, 16):
+            x[i] = (x[i] + bcast(x[i], p) * t).astype(F32)
+    M = np.zeros((4, 64), dtype=F32)
+    for r in range(4):
+        v = np.choose(G, [x[r], x[4 + r], x[8 + r], x[12 + r]])
+        M[r] = np.where(Cc <= 4 * G + r, v, 0.0)
+    return M, dv, (np.sqrt(om2) if pn is not None else 1.0)
+
+
+def run_h2(N, K, rvec, lam_lb, trunc=False):
+    """K (float64, symmetric positive definite with lambda_min >= lam_lb = noise + jitter), r -> logdet, quad, alpha, K^-1 - alpha alpha^T."""
+    NT = (N + 1 + 15) // 16
+    NP = 16 * NT
+    pN = N - 16 * (NT - 1)
+    K = K.astype(F32).astype(np.float64)
+    e = int(np.frexp(np.diag(K).max())[1])
+    msc = max(0, (e + 1) // 2)
+    kappa = 4.0 ** msc
+    e_mu = (int(np.frexp(kappa / lam_lb)[1]) + 1) >> 1                 # mu2 = 2^e_mu >= sqrt(kappa / lam_lb)
+    sM = 2.0 ** (15 - e_mu)
+    r2 = float(np.sum(rvec ** 2)) / kappa * 4.0 ** e_mu
+    e_r = (int(np.frexp(r2)[1]) + 1) >> 1 if r2 > 0 else 0              # rho = 2^-e_r <= 1 / (|r_s| mu2)
+    rho = 2.0 ** -e_r
+    T30, S15 = 2.0 ** 30, 2.0 ** 15
+    Sfull = np.zeros((NP, NP))
+    Sfull[:N, :N] = -K / kappa
+    Sfull[:N, N] = -rvec / 2.0 ** msc * rho
+    Sfull[N, :N] = -rvec / 2.0 ** msc * rho
+    for p in range(N + 1, NP):
+        Sfull[p, p] = -1.0
+    Sfull = (Sfull * T30).astype(F32)                                    # tiles hold 2^30 S
+    T = {(i, j): tile_to_acc(Sfull[16 * i:16 * i + 16, 16 * j:16 * j + 16]).astype(F32) for i in range(NT) for j in range(i, NT)}
+    negI = np.stack([np.where(4 * G + r == Cc, -1.0, 0.0) for r in range(4)]).astype(np.float16)
+    zero16 = np.zeros((4, 64), dtype=np.float16)
+    Md = {}
+    logdet, quad, alast = 0.0, None, None
+
+    def transpose_neg(Msp):           # -M^T, plane by plane, through the matrix pipe (exact: one non-zero term per element)
+        return tuple(mfma16(Msp[pl], negI, np.zeros((4, 64), dtype=F32)).astype(np.float16) for pl in range(2))
+
+    # ---- phase 1 ----
+    for k in range(NT):
+        last = k == NT - 1
+        M, dv, om = sweep32((T[(k, k)] * F32(2.0 ** -30)).astype(F32), pN if last else None, 4.0 ** -e_mu)
+        valid = (16 * k + Cc) < N
+        logdet += np.sum(np.log(dv[:16].astype(np.float64))[valid[:16]])
+        if last:
+            quad = -float(dv[pN]) / rho ** 2
+            alast = -acc_to_tile(M)[pN, :] * om                           # alpha_s rho, last segment (fp32, before the split)
+        Md[k] = split2(M, sM)
+        nV = transpose_neg(Md[k])
+        for j in range(k + 1, NT):
+            acc = xtyh(nV, split2(T[(k, j)], 2.0 ** -15), None, trunc)     # sM 2^15 R_kj
+            T[(k, j)] = split2(acc, 1.0 / sM)                              # R_kj 2^15, stored split
+        for i in range(k + 1, NT):
+            for j in range(i, NT):
+                T[(i, j)] = xtyh(T[(k, i)], T[(k, j)], T[(i, j)], trunc)   # 2^30 S_ij += (2^15 R_ki)^T (2^15 R_kj)
+    # ---- phase 2 ----
+    alpha = np.zeros(NP)
+    for j in range(1, NT):
+        nV = transpose_neg(Md[j])
+        for i in range(j):
+            Q = xtyh(T[(i, j)], Md[i], None, trunc)
+            for k in range(i + 1, j):
+                Q = xtyh(T[(k, j)], T[(i, k)], Q, trunc)                   # 2^15 sM Q
+            acc = xtyh(nV, split2(Q, 2.0 ** -19), None, trunc)             # sM (sM / 16) M_ji
+            if j == NT - 1:
+                alpha[16 * i:16 * i + 16] = -acc_to_tile(acc)[pN, :] * (16.0 / sM ** 2) * om
+            T[(i, j)] = split2(acc, 16.0 / sM)                             # sM M_ji, stored split
+    alpha[16 * (NT - 1):] = alast
+    alpha_s = alpha[:N] / rho                                              # alpha of the kappa-scaled system
+    # ---- phase 3: row N of M (the augmented row) is zeroed, P = M^T M is K_s^-1; the rank-one term is added in fp32 ----
+    rowmask = np.stack([np.where(4 * G + r == pN, 0.0, 1.0) for r in range(4)]).astype(np.float16)
+    for i in range(NT - 1):
+        T[(i, NT - 1)] = tuple(pl * rowmask for pl in T[(i, NT - 1)])
+    Md[NT - 1] = tuple(pl * rowmask for pl in Md[NT - 1])
+    Mt = lambda k, i: Md[k] if k == i else T[(i, k)]
+    for j in range(NT):
+        for i in list(range(j)) + [j]:
+            acc = None
+            for k in range(j, NT):
+                acc = xtyh(Mt(k, i), Mt(k, j), acc, trunc)
+            if i == j:
+                Md[j] = acc
+            else:
+                T[(i, j)] = acc
+    P = np.zeros((NP, NP))
+    for j in range(NT):
+        P[16 * j:16 * j + 16, 16 * j:16 * j + 16] = acc_to_tile(Md[j])
+        for i in range(j):
+            P[16 * i:16 * i + 16, 16 * j:16 * j + 16] = acc_to_tile(T[(i, j)])
+            P[16 * j:16 * j + 16, 16 * i:16 * i + 16] = acc_to_tile(T[(i, j)]).T
+    Pk = P[:N, :N] / sM ** 2 - np.outer(alpha_s, alpha_s)
+    return logdet + N * np.log(kappa), quad, alpha_s / 2.0 ** msc, Pk / kappa
+
+
+def main_h2():
+    rng = np.random.default_rng(2)
+    cases = [(105, 1600, 0.69, 0.1, 1.0), (105, 64, 0.69, 0.1, 1.0), (85, 512, 0.69, 0.1, 1.0), (25, 64, 0.69, 0.1, 1.0), (19, 2916, 0.69, 0.69, 30.0),
+             (105, 64, 0.69, 1e-4, 1.0), (105, 1600, 30.0, 1e-2, 1.0), (60, 40, 0.7, 1e-6, 1.0), (31, 10, 5.0, 0.1, 100.0), (127, 200, 1.0, 0.05, 1.0)]
+    for trunc in (False, True):
+        for (N, D, s, nz, ysc) in cases:
+            Z = rng.standard_normal((N, D)); Z /= np.linalg.norm(Z, axis=1, keepdims=True)
+            K = s * (Z @ Z.T) + nz * np.eye(N)
+            K = K.astype(F32).astype(np.float64)
+            r = np.where(rng.random(N) < 0.2, 1.0, -1.0) * ysc - 0.03
+            logdet, quad, alpha, P = run_h2(N, K, r, nz, trunc)
+            Ki = np.linalg.inv(K); a_ref = Ki @ r
+            logp = -0.5 * quad - 0.5 * logdet; logp_ref = -0.5 * r @ a_ref - 0.5 * np.linalg.slogdet(K)[1]
+            Pref = Ki - np.outer(a_ref, a_ref)
+            print("h2%s N=%3d D=%4d s=%.2f nz=%.0e y=%g: logp rel %.1e  logdet %.1e  quad rel %.1e  alpha rel %.1e  P rel-F %.1e" % (
+                " trunc" if trunc else "", N, D, s, nz, ysc, abs(logp - logp_ref) / abs(logp_ref), abs(logdet - np.linalg.slogdet(K)[1]),
+                abs(quad - r @ a_ref) / abs(r @ a_ref), np.abs(alpha - a_ref).max() / np.abs(a_ref).max(), np.linalg.norm(P - Pref) / np.linalg.norm(Pref)))
+
+
+if __name__ == "__main__" and "h2" in __import__("sys").argv:
+    main_h2()

@@ -20,6 +20,7 @@ from dkt_amd import ops  # noqa: E402
 lib = dkt_amd._lib.load()
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 c = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+flags = 1 | (32 if len(sys.argv) > 3 and sys.argv[3] == "f32mfma" else 0)      # WANT_GRAD [| FORCE_F32MFMA: the exact-fp32 twin]
 n, d = (105 // c) * c if c > 1 else 105, 64
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
@@ -38,7 +39,7 @@ outs = dict(logp=torch.empty(b, c, device=dev), alpha=torch.empty(b, c, n, devic
             dmean=torch.empty(b, c, device=dev), dnoise=torch.empty(b, c, device=dev))
 p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 for it in range(3):
-    st = lib.dkt_mll_f32(p(e), p(y), 0, p(sv), p(mean), p(noise), b, c, n, 1e-6, 3, 1, p(cw), p(outs["logp"]), p(outs["alpha"]), None,
+    st = lib.dkt_mll_f32(p(e), p(y), 0, p(sv), p(mean), p(noise), b, c, n, 1e-6, 3, flags, p(cw), p(outs["logp"]), p(outs["alpha"]), None,
                          p(outs["w"]), p(outs["dsv"]), p(outs["dmean"]), p(outs["dnoise"]), p(outs["jit"]), p(outs["info"]), p(ws),
                          ws.numel() * 8, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0
@@ -48,7 +49,7 @@ t = raw.astype(np.float64)
 names = ["start->row0 issued", "phase 1 (factorisation)", "phase 2 (inverse)", "alpha", "phase 3 (M^T M)", "reductions + scalars",
          "LDS accumulate (turns + barriers)", "store W"]
 dt = np.diff(t[:, :, :9], axis=2)
-print("C = %d, N = %d" % (c, n))
+print("C = %d, N = %d, kernel %s" % (c, n, "f32mfma twin" if flags & 32 else "h2 (default)"))
 print("waves %d; mean / p10 / p90 shader clocks per phase (s_memtime ticks = 100 MHz constant clock? see total)" % (nwg * 10))
 for i, nm in enumerate(names):
     v = dt[:, :, i].ravel()
@@ -67,7 +68,8 @@ for sh in sorted(set(share.ravel().tolist())):
     print("waves sharing their SIMD with %d of the workgroup: %d   phase 1 mean %.0f" % (sh, m.sum(), (t[:, :, 2] - t[:, :, 1])[m].mean()))
     print("   sweeps (k = 0 plain; k >= 1 interleaved with step k-1's updates): " + " ".join("%.0f" % v for v in sw))
     print("   panel + next tile row bursts:                                     " + " ".join("%.0f" % v for v in bu))
-    pv = [(t[:, :, 32] - t[:, :, 12])[m].mean()] + [(t[:, :, 32 + q] - t[:, :, 31 + q])[m].mean() for q in range(1, 16)]
-    print("   sweep 0 by pivot (first: P1 start -> pivot 0's head done):         " + " ".join("%.0f" % v for v in pv))
+    if raw[:, :, 32].any():
+        pv = [(t[:, :, 32] - t[:, :, 12])[m].mean()] + [(t[:, :, 32 + q] - t[:, :, 31 + q])[m].mean() for q in range(1, 16)]
+        print("   sweep 0 by pivot (first: P1 start -> pivot 0's head done):         " + " ".join("%.0f" % v for v in pv))
 tot = (t[:, :, 8] - t[:, :, 0]).ravel()
 print("%-36s mean %9.0f   p10 %9.0f   p90 %9.0f" % ("wave total", tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
