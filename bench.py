@@ -41,6 +41,9 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA
 
 # name -> (n_way, n_support, n_query, D, description, floats in the backbone + bn_out gradient bucket)
 CONFIGS = {
+    # QMUL head-pose regression (the reference's CPU-runnable case, train_regression.py): ONE GP per task, 19 frames, Conv3 features,
+    # RBF kernel, learned noise (DKT_regression.py:45-64, qmul_loader.py); bucket = Conv3 (24 408) + 4 GP hyper-parameters
+    "cfg0": (1, 5, 14, 2916, "QMUL regression, Conv3 features, RBF kernel: one task = one (19, 2916) GP", 24408),
     "cfg1": (5, 5, 16, 64, "Omniglot 5-way 5-shot, Conv4S features", 112064),
     "cfg2": (5, 5, 16, 1600, "CUB 5-way 5-shot, Conv4 features (headline)", 116288),
     "cfg3": (5, 1, 16, 512, "miniImagenet 5-way 1-shot, ResNet10 features", 4906816),
@@ -169,61 +172,44 @@ def gpytorch_baseline(z_cpu, n_way, raw_s, mean, episodes=50):
     return dict(value=round(episodes / (time.perf_counter() - t0), 2), unit="episodes/s", cores=1, version=gpytorch.__version__, loss_episode0=loss0)
 
 
-def run(args):
-    import dkt_amd
-    from dkt_amd import ops, distributed
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    selftest = args.selftest_collective
-    backend = "gloo" if selftest else "nccl"
-    local = distributed.init_from_env(backend) if world > 1 else 0
-    c, s, q, d, desc, n_backbone = CONFIGS[args.config]
+def _workload(cfg, b, dev, rank, unit_rows):
+    """Resident inputs + the step closure of one BASELINE config.  Returns (step, state): step() runs one pass of the hot path
+    (forward + backward) and returns (loss, logp, info); state holds the tensors the checks and the collective need."""
+    from dkt_amd import ops
+    c, s, q, d, desc, n_backbone = CONFIGS[cfg]
     n = c * (s + q)
-
-    if selftest:
-        # CPU-only check of the multi-rank plumbing (spawn / rendezvous / flat bucket / timing protocol); no kernels, no GPU
-        dev = torch.device("cpu")
-        raw_s = torch.full((c,), float(rank + 1), requires_grad=True)
-        mean = torch.zeros(c, requires_grad=True)
-        backbone = torch.zeros(n_backbone, requires_grad=True)
-        bucket = distributed.GradBucket([backbone, raw_s, mean])
-        raw_s.grad = torch.full((c,), float(rank + 1))
-        mean.grad = torch.zeros(c)
-        backbone.grad = torch.full((n_backbone,), float(rank))
-        bucket.allreduce_mean()
-        expect = sum(range(1, world + 1)) / world
-        ok = bool(torch.allclose(raw_s.grad, torch.full((c,), expect))) and bool(torch.allclose(backbone.grad, torch.full((n_backbone,), (world - 1) / 2.0)))
-        if rank == 0:
-            print(json.dumps({"selftest": True, "n_gpus": distributed.world_size(), "bucket_floats": bucket.numel, "valid": ok}))
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the DKT hot path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if dkt_amd._lib.needs_build() and rank == 0:
-        dkt_amd._lib.build()
-    if world > 1:
-        torch.distributed.barrier()
-
-    b = args.episodes or (8192 if n <= 128 else 1024)
-    z = synthetic_batch(b, n, d, 1234 + rank, dev).requires_grad_(True)
     raw_s, mean = perturbed_hypers(c, 99, dev)
     raw_s.requires_grad_(True)
     mean.requires_grad_(True)
+    if cfg == "cfg0":
+        # QMUL regression head (DKT_regression.py:45-64): one GP per task on Conv3 features [19, 2916], RBF kernel, learned noise;
+        # features ~ ReLU-like non-negative activations, targets = head-pose angles scaled to [-1, 1] per task ([B, 1, N])
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        z = (torch.randn(b, n, d, generator=g, device=dev).abs() * 0.3).contiguous().requires_grad_(True)
+        y = (torch.rand(b, 1, n, generator=g, device=dev) * 2.0 - 1.0).contiguous()
+        raw_ls = torch.tensor([2.5], device=dev, requires_grad=True)           # lengthscale = softplus(raw) ~ 2.58
+        raw_nz = torch.tensor([0.0], device=dev, requires_grad=True)           # GaussianLikelihood default: noise = softplus(0) + 1e-4
+        cw = torch.full((1,), -1.0 / n, device=dev)
+        params = [raw_s, mean, raw_ls, raw_nz]
+
+        def step():
+            z.grad = None
+            for p_ in params:
+                p_.grad = None
+            sv = torch.nn.functional.softplus(raw_s)
+            ls = torch.nn.functional.softplus(raw_ls)
+            nz = torch.nn.functional.softplus(raw_nz) + 1e-4
+            e = ops.base_matrix(z, "rbf", ls)
+            obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, nz, cw)
+            loss = obj.mean()
+            loss.backward()
+            return loss, logp, info
+        return step, dict(z=z, y=y, raw_s=raw_s, mean=mean, params=params, c=c, s=s, q=q, n=n, d=d, desc=desc, n_backbone=n_backbone, kernel="rbf")
+    z = synthetic_batch(b, n, d, 1234 + rank, dev).requires_grad_(True)
     noise = torch.full((c,), 0.1, device=dev)
     cls = torch.arange(c, device=dev).repeat_interleave(s + q)
     y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
     cw = torch.full((c,), -1.0 / (c * n), device=dev)
-    # the flat bucket of the step's one collective: [backbone + bn_out gradient (config size) | d raw_s | d mean]
-    backbone = torch.zeros(n_backbone, device=dev, requires_grad=True)
-    backbone.grad = torch.full((n_backbone,), 1e-3, device=dev)
-    bucket = distributed.GradBucket([backbone, raw_s, mean])
-
-    UNIT_ROWS = os.environ.get("DKT_BENCH_UNIT", "1") != "0"
 
     def step():
         z.grad = None
@@ -232,11 +218,42 @@ def run(args):
         sv = torch.nn.functional.softplus(raw_s)
         # the features are bn_out'ed + L2-normalised rows (the cossim / bncossim contract): unit_rows lets the Gram kernels
         # take the scaled 2-way f16 split; DKT_BENCH_UNIT=0 runs the range-agnostic 3-way bf16 split instead
-        obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=UNIT_ROWS)
+        obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=unit_rows)
         loss = obj.mean()
         loss.backward()
-        bucket.allreduce_mean()          # the path's only exchange: the shared-parameter gradient bucket (no-op at world 1)
         return loss, logp, info
+    return step, dict(z=z, y=y, raw_s=raw_s, mean=mean, noise=noise, params=[raw_s, mean], c=c, s=s, q=q, n=n, d=d, desc=desc,
+                      n_backbone=n_backbone, kernel="bncossim")
+
+
+def _algorithmic(cfg, n, d, c, unit_rows):
+    """Algorithmic bytes / flops per EPISODE, per ABI kernel of the step; `exec_f16`: the f16 MFMA flops the split Gram
+    kernels actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split)."""
+    nt16 = (n + 15) // 16
+    nprod = 3 if unit_rows else 6
+    alg = {
+        "dkt_gram_f32": dict(bytes=4 * (n * d + n * n), flops=2 * n * n * d,
+                             exec_f16=(nt16 * (nt16 + 1) // 2) * nprod * 2 * 256 * d if (n <= 128 and cfg != "cfg0") else None),
+        "dkt_mll_f32": dict(bytes=4 * (2 * n * n + 3 * c * n), flops=c * (n ** 3 // 3 + 2 * n * n + n ** 3), exec_f16=None),
+        "dkt_gram_bwd_f32": dict(bytes=4 * (n * n + 2 * n * d), flops=2 * n * n * d,
+                                 exec_f16=nt16 * nt16 * nprod * 2 * 256 * d if (n <= 128 and cfg != "cfg0") else None),
+        "dkt_rbf_bwd_f32": dict(bytes=4 * 3 * n * n, flops=6 * n * n, exec_f16=None),      # reads W and E, writes W' (+ the d lengthscale reduction)
+    }
+    return alg
+
+
+def _measure(cfg, b, args, dev, rank, world, bucket_fn, unit_rows, min_blocks, min_total, steps):
+    """Warm-up, then blocks of EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (MAX over ranks), at least
+    `min_blocks` blocks and `min_total` seconds; per-kernel HIP-event times from the same blocks.  Returns the measurement dict."""
+    from dkt_amd import ops
+    step0, st = _workload(cfg, b, dev, rank, unit_rows)
+    bucket = bucket_fn(st)
+
+    def step():
+        out = step0()
+        if bucket is not None:
+            bucket.allreduce_mean()      # the path's only exchange: the shared-parameter gradient bucket (no-op at world 1)
+        return out
 
     def sync():
         torch.cuda.synchronize()
@@ -247,13 +264,12 @@ def run(args):
     for _ in range(args.warmup):
         step()
     sync()
-    blocks, total = [], 0.0
-    ktimes_all = {}
-    while len(blocks) < 3 or (total < 1.0 and len(blocks) < 50):
+    blocks, total, ktimes_all = [], 0.0, {}
+    while len(blocks) < min_blocks or (total < min_total and len(blocks) < 50):
         ops.kernel_timing(True)
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             loss, logp, info = step()
         sync()
         dt = time.perf_counter() - t0
@@ -272,85 +288,181 @@ def run(args):
     # same inputs -> bitwise the same outputs (no atomics, fixed reduction orders): a hand-off race in a kernel would
     # show up here as a handful of differing episodes
     _, logp_a, _ = step()
-    grad_a = z.grad.clone()
+    grad_a = st["z"].grad.clone()
     _, logp_b, _ = step()
-    deterministic = bool(torch.equal(logp_a, logp_b)) and bool(torch.equal(grad_a, z.grad))
-    ok = ok and deterministic
+    deterministic = bool(torch.equal(logp_a, logp_b)) and bool(torch.equal(grad_a, st["z"].grad))
+    return dict(st=st, bucket=bucket, step=step, dt=dt, blocks=blocks, total=total, ktimes=ktimes, valid=ok and deterministic,
+                deterministic=deterministic, logp=logp, steps=steps, b=b)
+
+
+def _traffic_table():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot profile itself), per config
+    (profiles/pmc_traffic.json, written by tools/make_traffic_json.py from tools/prof_all.sh's summaries)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+    if "configs" in tj:
+        return tj["configs"]
+    return {tj.get("config", "cfg2"): tj}
+
+
+def _kernel_report(cfg, m, unit_rows, traffic):
+    st, b = m["st"], m["b"]
+    n, d, c = st["n"], st["d"], st["c"]
+    alg = _algorithmic(cfg, n, d, c, unit_rows)
+    kernels = {}
+    for name, (cnt, ms) in m["ktimes"].items():
+        a = alg[name]
+        kernels[name] = dict(launches=cnt, ms=round(ms, 4), gbs=round(a["bytes"] * b / ms / 1e6, 1), tflops=round(a["flops"] * b / ms / 1e9, 2))
+    tj = traffic.get(cfg)
+
+    def roof(name):
+        """Both roofs for one kernel.  The Gram kernels stream Z once: HBM binds them (their contraction runs on the f16 pipe,
+        `executed_f16_mfma`).  The marginal-likelihood kernel has no HBM pressure: its algorithmic fp32 flops against the fp32 matrix
+        peak (N <= 127: the factorisation and the K^-1 product themselves run as 2-way f16 splits on the f16 pipe since round 3)."""
+        k = kernels[name]
+        tr, src = None, None
+        if tj and name in tj.get("kernels", {}):
+            tr = round(tj["kernels"][name]["hbm_bytes"] * b / tj["episodes_per_launch"])
+            src = tj["source"]
+        hbm = dict(bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(k["gbs"] / HBM_PEAK_GBS, 4))
+        mat = dict(bound="mfma", achieved=k["tflops"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / MFMA_F32_PEAK_TFLOPS, 4),
+                   note="algorithmic fp32 flops / fp32 MFMA peak")
+        first, other = (mat, hbm) if name == "dkt_mll_f32" else (hbm, None)
+        r = dict(kernel=name, **first, traffic=tr, traffic_unit="bytes/launch (PMC: FETCH_SIZE + WRITE_SIZE at L2<->fabric)",
+                 traffic_source=src, algorithmic_bytes_per_launch=alg[name]["bytes"] * b,
+                 algorithmic_flops_per_launch=alg[name]["flops"] * b, avg_launch_ms=k["ms"], episodes_per_launch=b)
+        if other:
+            r["other_roof"] = other
+        if alg[name]["exec_f16"]:
+            ex = alg[name]["exec_f16"] * b / k["ms"] / 1e9
+            r["executed_f16_mfma"] = dict(achieved=round(ex, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ex / MFMA_F16_PEAK_TFLOPS, 4),
+                                          note="executed v_mfma_f32_16x16x32_f16 flops (split products, computed tiles only) / dense f16 peak")
+        return r
+    return kernels, {name: roof(name) for name in kernels}
+
+
+def _default_batch(cfg):
+    c, s, q = CONFIGS[cfg][:3]
+    return 8192 if c * (s + q) <= 128 else 1024
+
+
+def run(args):
+    import dkt_amd
+    from dkt_amd import ops, distributed
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    selftest = args.selftest_collective
+    backend = "gloo" if selftest else "nccl"
+    local = distributed.init_from_env(backend) if world > 1 else 0
+    c, s, q, d, desc, n_backbone = CONFIGS[args.config]
+    n = c * (s + q)
+
+    if selftest:
+        # CPU-only check of the multi-rank plumbing (spawn / rendezvous / flat bucket / timing + attribution protocol); no kernels, no GPU
+        dev = torch.device("cpu")
+        raw_s = torch.full((c,), float(rank + 1), requires_grad=True)
+        mean = torch.zeros(c, requires_grad=True)
+        backbone = torch.zeros(n_backbone, requires_grad=True)
+        bucket = distributed.GradBucket([backbone, raw_s, mean])
+        raw_s.grad = torch.full((c,), float(rank + 1))
+        mean.grad = torch.zeros(c)
+        backbone.grad = torch.full((n_backbone,), float(rank))
+        bucket.allreduce_mean()
+        expect = sum(range(1, world + 1)) / world
+        ok = bool(torch.allclose(raw_s.grad, torch.full((c,), expect))) and bool(torch.allclose(backbone.grad, torch.full((n_backbone,), (world - 1) / 2.0)))
+        # second round on the views the first one attached: no pack copies any more
+        backbone.grad.fill_(float(rank))
+        bucket.allreduce_mean()
+        ok = ok and bucket.copies_last == 0 and bool(torch.allclose(backbone.grad, torch.full((n_backbone,), (world - 1) / 2.0)))
+        ar_ms = _allreduce_ms(bucket, world, None)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": distributed.world_size(), "bucket_floats": bucket.numel, "valid": ok,
+                              "collective": _collective_info(bucket, world, ar_ms, backend)}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DKT hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dkt_amd._lib.needs_build() and rank == 0:
+        dkt_amd._lib.build()
+    if world > 1:
+        torch.distributed.barrier()
+
+    UNIT_ROWS = os.environ.get("DKT_BENCH_UNIT", "1") != "0"
+    traffic = _traffic_table()
+
+    def bucket_fn(st):
+        # the flat bucket of the step's one collective: [backbone + bn_out gradient (config size) | hyper-parameter gradients]
+        backbone = torch.zeros(st["n_backbone"], device=dev, requires_grad=True)
+        bkt = distributed.GradBucket([backbone] + st["params"])
+        bkt.attach()
+        backbone.grad.fill_(1e-3)
+        st["backbone"] = backbone
+        return bkt
+
+    b = args.episodes or _default_batch(args.config)
+    m = _measure(args.config, b, args, dev, rank, world, bucket_fn, UNIT_ROWS, 3, 1.0, args.steps)
+    st, bucket, dt, blocks, total = m["st"], m["bucket"], m["dt"], m["blocks"], m["total"]
+    z, raw_s, mean, logp, step = st["z"], st["raw_s"], st["mean"], m["logp"], m["step"]
+    ar_ms = _allreduce_ms(bucket, world, dev) if world > 1 else 0.0
 
     if rank == 0:
         eps = world * b * args.steps / dt
-        nt16 = (n + 15) // 16
-        # algorithmic bytes / flops per EPISODE, per kernel; `exec_f16`: the f16 MFMA flops the split Gram kernels
-        # actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split)
-        nprod = 3 if UNIT_ROWS else 6
-        alg = {
-            "dkt_gram_f32": dict(bytes=4 * (n * d + n * n), flops=2 * n * n * d, exec_f16=(nt16 * (nt16 + 1) // 2) * nprod * 2 * 256 * d if n <= 128 else None),
-            "dkt_mll_f32": dict(bytes=4 * (2 * n * n + 3 * c * n), flops=c * (n ** 3 // 3 + 2 * n * n + n ** 3), exec_f16=None),
-            "dkt_gram_bwd_f32": dict(bytes=4 * (n * n + 2 * n * d), flops=2 * n * n * d, exec_f16=nt16 * nt16 * nprod * 2 * 256 * d if n <= 128 else None),
-        }
-        kernels = {}
-        for name, (cnt, ms) in ktimes.items():
-            a = alg[name]
-            kernels[name] = dict(launches=cnt, ms=round(ms, 4), gbs=round(a["bytes"] * b / ms / 1e6, 1),
-                                 tflops=round(a["flops"] * b / ms / 1e9, 2))
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot
-        # profile itself); linear in the episode count, so scaled when --episodes differs from the profiled run.
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        except (OSError, ValueError):
-            tj = None
-
-        def roof(name):
-            """Both roofs for one kernel.  The Gram kernels stream Z once: HBM binds them (their contraction runs on the f16 pipe,
-            `executed_f16_mfma`).  The marginal-likelihood kernel is fp32 MFMA work with no HBM pressure: the fp32 matrix roof."""
-            k = kernels[name]
-            traffic, src = None, None
-            if tj and args.config == tj.get("config", "cfg2") and name in tj.get("kernels", {}):
-                traffic = round(tj["kernels"][name]["hbm_bytes"] * b / tj["episodes_per_launch"])
-                src = tj["source"]
-            f_hbm = k["gbs"] / HBM_PEAK_GBS
-            f_f32 = k["tflops"] / MFMA_F32_PEAK_TFLOPS
-            hbm = dict(bound="hbm", achieved=k["gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=round(f_hbm, 4))
-            mat = dict(bound="mfma", achieved=k["tflops"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(f_f32, 4),
-                       note="algorithmic fp32 flops / fp32 MFMA peak")
-            first, other = (mat, hbm) if name == "dkt_mll_f32" else (hbm, None)
-            r = dict(kernel=name, **first, traffic=traffic, traffic_unit="bytes/launch (PMC: FETCH_SIZE + WRITE_SIZE at L2<->fabric)",
-                     traffic_source=src, algorithmic_bytes_per_launch=alg[name]["bytes"] * b,
-                     algorithmic_flops_per_launch=alg[name]["flops"] * b, avg_launch_ms=k["ms"], episodes_per_launch=b)
-            if other:
-                r["other_roof"] = other
-            if alg[name]["exec_f16"]:
-                ex = alg[name]["exec_f16"] * b / k["ms"] / 1e9
-                r["executed_f16_mfma"] = dict(achieved=round(ex, 1), peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ex / MFMA_F16_PEAK_TFLOPS, 4),
-                                              note="executed v_mfma_f32_16x16x32_f16 flops (split products, computed tiles only) / dense f16 peak")
-            return r
-
+        kernels, roofline_all = _kernel_report(args.config, m, UNIT_ROWS, traffic)
         dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
-        roofline = roof(dom) if dom else None
-        roofline_all = {name: roof(name) for name in kernels}
+        roofline = roofline_all.get(dom)
+        mll_arith = ("the factorisations and the K^-1 products as scaled 2-way f16 splits too (v_mfma_f32_16x16x16_f16, fp32 accumulate), "
+                     "the triangular inverse on v_mfma_f32_16x16x4_f32" if n + 1 <= 128 else "the factorisations / inverses on v_mfma_f32_16x16x4_f32")
         arith = ("f32 (results fp32-faithful; the two Gram contractions run as a scaled 2-way f16 split of every fp32 operand -- "
-                 "22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16 products, fp32 accumulate; the factorisations / inverses on "
-                 "v_mfma_f32_16x16x4_f32)" if UNIT_ROWS else
-                 "f32 (the two Gram contractions as an exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate; "
-                 "the factorisations / inverses on v_mfma_f32_16x16x4_f32)")
+                 "22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16 products, fp32 accumulate; " + mll_arith + ")" if UNIT_ROWS else
+                 "f32 (the two Gram contractions as an exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate; " + mll_arith + ")")
         out = {
             "metric": "episodes/sec", "value": round(eps, 1), "unit": "episodes/s", "n_gpus": distributed.world_size(),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f16x2-split", "data": "synthetic",
             "config": {"workload": "%s: %s; N=%d D=%d C=%d; training episode fwd+bwd (Gram + %d jittered Cholesky/"
                                    "solve/logdet + MLL + backward)" % (args.config, desc, n, d, c, c),
-                       "episodes_per_step_per_gpu": b, "kernel": "bncossim", "parallelism": "episode-dp%d" % world,
+                       "episodes_per_step_per_gpu": b, "kernel": st["kernel"], "parallelism": "episode-dp%d" % world,
                        "collective": "one all-reduce per step over a flat fp32 bucket of %d floats (%.1f KB: backbone + bn_out of the "
-                                     "config + 2C hyper-parameter gradients)" % (bucket.numel, bucket.numel * 4 / 1024.0),
+                                     "config + the GP hyper-parameter gradients)" % (bucket.numel, bucket.numel * 4 / 1024.0),
                        "arithmetic": arith},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_s_median": round(dt, 6),
                        "block_s_min": round(min(blocks), 6), "block_s_max": round(max(blocks), 6), "timed_s_total": round(total, 4)},
-            "valid": ok, "deterministic": deterministic, "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
+            "valid": m["valid"], "deterministic": m["deterministic"], "roofline": roofline, "roofline_gram_build": roofline_all.get("dkt_gram_f32"),
             "roofline_by_kernel": roofline_all, "kernels": kernels,
+            "collective": _collective_info(bucket, world, ar_ms, backend),
         }
-        if world == 1 and not args.no_test_time:
+    if world == 1 and not args.no_other_configs:
+        # every other BASELINE config under the same clock (3 blocks each): value, ms_per_step, per-kernel rooflines
+        others = {}
+        for cfg in sorted(CONFIGS):
+            if cfg == args.config:
+                continue
+            del m
+            torch.cuda.empty_cache()
+            bo = _default_batch(cfg)
+            so = max(2, min(args.steps, 10 if CONFIGS[cfg][0] * (CONFIGS[cfg][1] + CONFIGS[cfg][2]) <= 128 else 4))
+            m = _measure(cfg, bo, args, dev, rank, world, lambda st_: None, UNIT_ROWS, 3, 0.0, so)
+            ko, ro = _kernel_report(cfg, m, UNIT_ROWS, traffic)
+            so_ = m["st"]
+            others[cfg] = {"value": round(bo * so / m["dt"], 1), "unit": "episodes/s", "ms_per_step": round(1e3 * m["dt"] / so, 4),
+                           "episodes_per_step": bo, "steps_per_block": so, "blocks": len(m["blocks"]), "valid": m["valid"],
+                           "workload": "%s; N=%d D=%d C=%d, kernel %s" % (so_["desc"], so_["n"], so_["d"], so_["c"], so_["kernel"]),
+                           "kernels": ko, "roofline_by_kernel": ro}
+        out["other_configs"] = others
+        del m
+        torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_test_time and args.config != "cfg0":
             # SURVEY.md 8d: the forward-only test-time episode (`correct`, DKT.py:199-272) reported separately:
             # condition on the 25 support features, predict the 75 queries (Gram, MLL without gradients, cross Gram, mean + arg-max)
+            noise = st["noise"]
             bt = min(b, 4096)
             z_te = synthetic_batch(bt, n, d, 77, dev)        # [support; query] features of a test episode, support rows first
             ns = c * s
@@ -377,10 +489,10 @@ def run(args):
                                         "ms_per_step": round(1e3 * dt_t, 4),
                                         "workload": "N_support=%d, N_query=%d, D=%d, C=%d: Gram + MLL (no grad) + cross Gram + posterior mean/arg-max"
                                                     % (c * s, c * q, d, c)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config != "cfg0":
             import numpy as np
             from oracle import dkt_oracle as O
-            nchk = 4
+            nchk = 32                                         # marginal log-likelihood of 32 bench episodes against the float64 oracle
             zc = z[:nchk].detach().cpu()
             sv64 = torch.nn.functional.softplus(raw_s.detach().cpu().double()).numpy()
             hyp = O.GPHypers(sv64, mean.detach().cpu().double().numpy(), np.full(c, 0.1))
@@ -389,6 +501,7 @@ def run(args):
                 ref = O.train_episode(zc[i].double().numpy(), c, hyp)
                 rel = max(rel, float(np.abs((logp[i].cpu().numpy() - ref["logp"]) / ref["logp"]).max()))
             out["mll_rel_err"] = rel
+            out["mll_rel_err_episodes"] = nchk
             zs_cpu = z[:32].detach().cpu()
             res = cpu_baseline(zs_cpu, c, raw_s.detach().cpu(), mean.detach().cpu())
             best = max(res, key=lambda k: res[k][0])
@@ -409,6 +522,44 @@ def run(args):
         torch.distributed.destroy_process_group()
 
 
+def _allreduce_ms(bucket, world, dev, iters=10):
+    """The step's collective alone: `iters` all-reduces of the flat bucket bracketed by synchronize (+ barrier), MAX over ranks."""
+    if world <= 1 or bucket is None:
+        return 0.0
+    cuda = dev is not None and dev.type == "cuda"
+
+    def sync():
+        if cuda:
+            torch.cuda.synchronize()
+        torch.distributed.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+    for _ in range(2):
+        bucket.allreduce_mean()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        bucket.allreduce_mean()
+    sync()
+    t = torch.tensor([(time.perf_counter() - t0) / iters * 1e3], dtype=torch.float64, device=dev if cuda else "cpu")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _collective_info(bucket, world, ar_ms, backend):
+    """Attribution of the multi-GPU step: what the one collective is, how long it takes alone, what RCCL was told."""
+    info = {"op": "all_reduce(SUM) of one flat fp32 bucket, then / world", "bytes": (bucket.numel + 1) * 4 if bucket is not None else 0,
+            "allreduce_ms": round(ar_ms, 4), "backend": backend if world > 1 else "none (world 1: no collective is issued)", "ranks": world,
+            "NCCL_ALGO": os.environ.get("NCCL_ALGO", "unset (RCCL picks)"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "unset (RCCL picks)"),
+            "pack_copies_last_step": bucket.copies_last if bucket is not None else 0}
+    try:
+        if world > 1 and backend == "nccl":
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return info
+
+
 def _child(local_rank, args, world, port):
     os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -424,6 +575,9 @@ def main():
                     help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192}); default 8192, 1024 for the 20-way shapes")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="only the --config workload (default: the headline config in full, then every other BASELINE config for 3 "
+                         "short blocks each, reported under `other_configs`)")
     ap.add_argument("--no-test-time", action="store_true",
                     help="skip the separately reported forward-only test-time episode (profiling runs: keeps the per-kernel "
                          "averages of the trace to the training step's launches)")

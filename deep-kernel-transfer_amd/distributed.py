@@ -56,7 +56,12 @@ def shard_episodes(n_episodes: int, rank_: Optional[int] = None, world: Optional
 
 class GradBucket:
     """Flat fp32 bucket over the parameters that require grad (each tensor once, aliases de-duplicated).
-    `allreduce_mean()` averages the gradients over ranks with ONE collective."""
+    `allreduce_mean()` averages the gradients over ranks with ONE collective.
+
+    The parameters' `.grad` tensors are VIEWS of the flat buffer: autograd accumulates into an existing `.grad` in place, so a
+    backward pass writes straight into the bucket and the collective needs no pack / unpack copies.  A caller that drops the views
+    (`p.grad = None`, `optimizer.zero_grad(set_to_none=True)`) is still served: such a gradient is copied in once and the view is
+    re-attached after the collective.  `zero_()` clears every gradient without dropping the views."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         seen, self.params = set(), []
@@ -66,12 +71,41 @@ class GradBucket:
                 self.params.append(p)
         self.numel = sum(p.numel() for p in self.params)
         self._flat: Optional[torch.Tensor] = None
+        self.copies_last = 0           # gradients that had to be packed by a copy in the last allreduce_mean (0 once the views persist)
 
     def _buffer(self) -> torch.Tensor:
         p0 = self.params[0]
         if self._flat is None or self._flat.device != p0.device:
-            self._flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
+            self._flat = torch.zeros(self.numel + 1, device=p0.device, dtype=torch.float32)      # [gradients | flag]
         return self._flat
+
+    def _view(self, p: torch.nn.Parameter, off: int) -> torch.Tensor:
+        return self._flat[off:off + p.numel()].view(p.shape)
+
+    def _is_view(self, p: torch.nn.Parameter, off: int) -> bool:
+        g = p.grad
+        return (g is not None and g.dtype == torch.float32 and g.device == self._flat.device and g.is_contiguous()
+                and g.data_ptr() == self._flat.data_ptr() + 4 * off)
+
+    def attach(self) -> None:
+        """Make every parameter's .grad a view of the flat buffer (existing gradients are kept)."""
+        if not self.params:
+            return
+        self._buffer()
+        off = 0
+        for p in self.params:
+            if not self._is_view(p, off) and p.dtype == torch.float32:
+                v = self._view(p, off)
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+                p.grad = v
+            off += p.numel()
+
+    def zero_(self) -> None:
+        if self._flat is not None:
+            self._flat.zero_()
 
     def allreduce_mean(self, flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """Average the gradients over the ranks.  `flag` (a 0-dim / 1-element tensor, e.g. max |info| of the step) rides in the
@@ -80,30 +114,32 @@ class GradBucket:
         if not is_distributed() or not self.params:
             return flag
         flat = self._buffer()
-        if flag is not None:
-            if self._flat.numel() != self.numel + 1:
-                self._flat = torch.zeros(self.numel + 1, device=self.params[0].device, dtype=torch.float32)
-                flat = self._flat
-            flat[self.numel] = flag.reshape(-1)[0].to(torch.float32)
-        off = 0
+        flat[self.numel] = flag.reshape(-1)[0].to(torch.float32) if flag is not None else 0.0
+        off, copies = 0, 0
         for p in self.params:
             n = p.numel()
-            if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
+            if not self._is_view(p, off):
+                if p.grad is None:
+                    flat[off:off + n].zero_()
+                else:
+                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                    copies += 1
             off += n
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        self.copies_last = copies
+        red = flat if flag is not None else flat[:self.numel]
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
         out_flag = flat[self.numel].clone() if flag is not None else None
-        flat.div_(dist.get_world_size())
+        flat[:self.numel].div_(dist.get_world_size())
         off = 0
         for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = flat[off:off + n].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(flat[off:off + n].reshape(p.shape))
-            off += n
+            if not self._is_view(p, off):
+                if p.dtype == torch.float32:
+                    p.grad = self._view(p, off)
+                elif p.grad is None:                                   # (non-fp32 parameters cannot alias the fp32 bucket: copied back)
+                    p.grad = self._view(p, off).to(p.dtype)
+                else:
+                    p.grad.copy_(self._view(p, off))
+            off += p.numel()
         return out_flag
 
 

@@ -231,7 +231,9 @@ def rbf_bwd(w: torch.Tensor, e: torch.Tensor, lengthscale: torch.Tensor):
     wp = torch.empty_like(e)
     dl = torch.empty((b_,), device=e.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.dkt_rbf_bwd_f32(_p(w), _p(e), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream()), "dkt_rbf_bwd_f32")
+    with _timed("dkt_rbf_bwd_f32"):
+        st = lib.dkt_rbf_bwd_f32(_p(w), _p(e), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream())
+    _lib.check(st, "dkt_rbf_bwd_f32")
     return wp, dl
 
 

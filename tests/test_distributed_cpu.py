@@ -107,7 +107,7 @@ def test_shard_episodes_partitions():
 
 def test_bench_spawns_its_own_ranks_and_reduces_the_config_sized_bucket():
     """`bench.py --gpus 2` without a launcher spawns one process per rank itself; the step's one collective carries the
-    config's backbone + bn_out bucket plus the 2C hyper-parameter gradients (cfg2: 116 288 + 10 floats).  CPU / gloo selftest
+    config's backbone + bn_out bucket plus the 2C hyper-parameter gradients (cfg2: 116 288 + 10 floats, + the failure flag).  CPU / gloo selftest
     of that plumbing -- the kernels themselves need the GPU."""
     import json
     import subprocess
@@ -119,4 +119,9 @@ def test_bench_spawns_its_own_ranks_and_reduces_the_config_sized_bucket():
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
+    coll = out.pop("collective")
     assert out == {"selftest": True, "n_gpus": 2, "bucket_floats": 116288 + 10, "valid": True}
+    # attribution of the multi-GPU step: the bucket alone is timed, the collective's size / backend / rank count and what RCCL was told
+    # are reported, and the second step ran on gradient VIEWS of the flat buffer (no pack copies)
+    assert coll["bytes"] == 4 * (116288 + 10 + 1) and coll["ranks"] == 2 and coll["backend"] == "gloo"
+    assert coll["allreduce_ms"] > 0.0 and coll["pack_copies_last_step"] == 0 and "NCCL_ALGO" in coll and "NCCL_PROTO" in coll
