@@ -75,6 +75,8 @@ class _MetaBatched:
 
     def __init__(self, loader, nb):
         self.loader, self.nb = loader, nb
+        if len(loader) // nb == 0:
+            raise ValueError("meta_batch = %d exceeds the %d episodes of the loader: no optimizer step would be taken" % (nb, len(loader)))
 
     def __len__(self):
         return len(self.loader) // self.nb
@@ -265,7 +267,14 @@ class DKT(MetaTemplate):
             if bn is not None and bn.track_running_stats:
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item() + 1)
                 nb = xb.shape[0]
-                if nb == 1:
+                if bn.momentum is None and nb > 1:
+                    # cumulative moving average: the factor changes with every episode, 1 / (num_batches_tracked + 1) -- the episodes one by one
+                    nbt = int(bn.num_batches_tracked.item())
+                    for bi in range(nb):
+                        f_ = 1.0 / float(nbt + bi + 1)
+                        bn.running_mean.mul_(1.0 - f_).add_(bmean[bi], alpha=f_)
+                        bn.running_var.mul_(1.0 - f_).add_(bvar[bi], alpha=f_)
+                elif nb == 1:
                     bn.running_mean.mul_(1.0 - mom).add_(bmean[0], alpha=mom)
                     bn.running_var.mul_(1.0 - mom).add_(bvar[0], alpha=mom)
                 else:       # nb sequential momentum updates in closed form: r <- (1-m)^nb r + m sum_b (1-m)^(nb-1-b) x_b
@@ -329,7 +338,9 @@ class DKT(MetaTemplate):
             mus.append(m); outs.append(o)
         mu = torch.cat(mus, 1)
         out = {key: torch.cat([o[key] for o in outs], 1) for key in ("logp", "alpha", "jitter", "info")}
-        labels = mu.argmax(1).to(torch.int32)                 # first maximum wins, as np.argmax
+        # first maximum wins, as np.argmax (torch.argmax does not promise which of several equal maxima it returns on the GPU)
+        cidx = torch.arange(mu.shape[1], device=mu.device, dtype=torch.int32).view(1, -1, 1)
+        labels = torch.where(mu == mu.max(1, keepdim=True).values, cidx, torch.full_like(cidx, mu.shape[1])).min(1).values
         return mu[0], labels[0], out
 
     def _posterior_fused_eval(self, x_support, x_query, y):
@@ -458,6 +469,14 @@ class DKT(MetaTemplate):
                 self._bad_steps = bad if self._bad_steps is None else self._bad_steps + bad
                 if fused_adam:
                     optimizer.found_inf = (bad != 0).to(torch.float32).reshape(())    # no NaN ever reaches the weights or Adam's moments
+                else:
+                    # the default (foreach) implementation has no device-side skip: zero the poisoned gradients instead -- the step then
+                    # only decays Adam's moments, no NaN reaches the weights -- (one [1]-sized mask multiply per tensor, no host sync)
+                    keep = (bad == 0).to(torch.float32)
+                    for group in optimizer.param_groups:
+                        for p_ in group['params']:
+                            if p_.grad is not None:
+                                p_.grad = torch.where(keep.bool(), p_.grad, torch.zeros_like(p_.grad))
                 optimizer.step()
             x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
 
@@ -502,6 +521,10 @@ class DKT(MetaTemplate):
                 print('Epoch [{:d}] [{:d}/{:d}] | Outscale {:f} | Lenghtscale {:f} | Noise {:f} | Loss {:f} | Supp. {:f} | Query {:f}'.format(
                     epoch, i, len(train_loader), log_outputscale.item(), log_lengthscale.item(), log_noise.item(),
                     loss.item(), acc_support.item(), acc_query.item()))
+        # failures after the last print point of the epoch (the flag is reset by the next call): raise here, on every rank alike
+        if self._bad_steps is not None and float(self._bad_steps.item()) != 0.0:
+            raise RuntimeError("DKT: kernel matrix not positive definite after jitter retries "
+                               "(GPyTorch raises NotPSDError here)")
 
     # ------------------------------------------------------------------ evaluation
     def _upload(self, x):

@@ -139,7 +139,7 @@ class DKT(nn.Module):
             ref = {"model.models.0." + k: v for k, v in gp.items()}
             for k, v in (ckpt.get('likelihood') or {}).items():           # 'noise_covar.raw_noise'
                 ref.setdefault("model.models.0.likelihood." + k, v)
-            if self.model.load_reference_state_dict(ref) == 0:
+            if self.model.load_reference_state_dict(ref, strict_gp_keys=True) == 0:
                 raise RuntimeError("reference regression checkpoint without known GP keys")
         else:
             self.model.load_state_dict(gp)

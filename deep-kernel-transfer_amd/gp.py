@@ -142,12 +142,19 @@ class ExactGPHypers(nn.Module):
         "covar_module.base_kernel.raw_offset": "raw_offset",
     }
 
-    def load_reference_state_dict(self, state: dict, prefix: str = "model.") -> int:
+    # SpectralMixtureKernel sits directly under covar_module in the reference (DKT_regression.py:121-122: no ScaleKernel around it)
+    REFERENCE_SPECTRAL_KEYS = {
+        "covar_module.raw_mixture_weights": "raw_mixture_weights",
+        "covar_module.raw_mixture_means": "raw_mixture_means",
+        "covar_module.raw_mixture_scales": "raw_mixture_scales",
+    }
+
+    def load_reference_state_dict(self, state: dict, prefix: str = "model.", strict_gp_keys: bool = False) -> int:
         """Copy hyper-parameters out of a reference DKT `state_dict()` (GPyTorch 1.0.1 key names:
         `model.models.{c}.mean_module.constant`, `.covar_module.raw_outputscale`,
         `.covar_module.base_kernel.raw_variance|raw_lengthscale|raw_offset`, `.likelihood.noise_covar.raw_noise`), every class.
         Returns the number of tensors consumed.  Key names could not be diffed against GPyTorch here."""
-        used = 0
+        used, consumed = 0, set()
         with torch.no_grad():
             for c in range(self.n_models):
                 base = "%smodels.%d." % (prefix, c)
@@ -156,6 +163,22 @@ class ExactGPHypers(nn.Module):
                     if base + key in state and dst is not None:
                         dst[c] = state[base + key].reshape(-1)[0].to(dst)
                         used += 1
+                        consumed.add(base + key)
+                for key, name in self.REFERENCE_SPECTRAL_KEYS.items():        # whole tensors (one model: the regression head)
+                    dst = getattr(self, name, None)
+                    if base + key in state and dst is not None:
+                        src = state[base + key]
+                        if src.numel() != dst.numel():
+                            raise RuntimeError("%s: checkpoint shape %s does not fit %s" % (key, tuple(src.shape), tuple(dst.shape)))
+                        dst.copy_(src.reshape(dst.shape).to(dst))
+                        used += 1
+                        consumed.add(base + key)
+        if strict_gp_keys:
+            # a GP tensor of the checkpoint that nothing here took would be dropped silently (e.g. a kernel this head was not built with)
+            left = [k for k in state if k.startswith(prefix + "models.") and k not in consumed
+                    and any(t in k for t in (".mean_module.", ".covar_module.", ".likelihood."))]
+            if left:
+                raise RuntimeError("reference checkpoint holds GP tensors this model has no parameter for: %s" % ", ".join(sorted(left)))
         return used
 
     @staticmethod

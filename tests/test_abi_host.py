@@ -141,6 +141,21 @@ def test_reference_format_checkpoints_load_through_the_drivers_entry_points(tmp_
     own_path = str(tmp_path / "own_ckpt")
     reg.save_checkpoint(own_path)
     reg.load_checkpoint(own_path)
+    # the spectral-mixture head (DKT_regression.py:121-122: SpectralMixtureKernel(num_mixtures=4, ard_num_dims=2916), no ScaleKernel):
+    # its three raw tensors load too; a GP tensor nothing consumes raises instead of being dropped
+    sp = dkt_amd.DKTRegression(dkt_amd.backbone.Conv3(), "spectral")
+    q, dd = sp.model.raw_mixture_weights.shape[0], sp.model.raw_mixture_means.shape[-1]
+    gp = {"likelihood.noise_covar.raw_noise": torch.tensor([0.3]), "mean_module.constant": torch.tensor([-0.2]),
+          "covar_module.raw_mixture_weights": torch.linspace(-1.0, 1.0, q), "covar_module.raw_mixture_means": torch.full((q, 1, dd), 0.25),
+          "covar_module.raw_mixture_scales": torch.full((q, 1, dd), -0.75)}
+    sp_path = str(tmp_path / "ref_spectral_ckpt")
+    torch.save({"gp": gp, "likelihood": {"noise_covar.raw_noise": torch.tensor([0.3])}, "net": sp.feature_extractor.state_dict()}, sp_path)
+    sp.load_checkpoint(sp_path)
+    assert torch.allclose(sp.model.raw_mixture_weights, torch.linspace(-1.0, 1.0, q))
+    assert torch.allclose(sp.model.raw_mixture_means, torch.full((q, 1, dd), 0.25)) and torch.allclose(sp.model.raw_mixture_scales, torch.full((q, 1, dd), -0.75))
+    assert abs(sp.model.mean_constant.item() + 0.2) < 1e-7 and abs(sp.model.raw_noise.item() - 0.3) < 1e-7
+    with pytest.raises(RuntimeError):
+        reg.load_checkpoint(sp_path)                       # an RBF head must not swallow a spectral checkpoint silently
 
 
 def test_backbone_shapes():
