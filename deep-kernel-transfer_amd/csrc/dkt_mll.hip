@@ -227,6 +227,12 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & DKT_MLL_E_PER_CLASS) {
+        // one base matrix per class model: served by the wave-per-matrix form of the f16-split kernel only (training call, N <= 111)
+        if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
+        if (N + 1 > 112) return DKT_ERR_TOO_LARGE;
+        return dkt_mll_h2_launch(a, st) ? (hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH) : DKT_ERR_BAD_ARG;
+    }
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

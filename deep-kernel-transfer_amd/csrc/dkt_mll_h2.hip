@@ -739,8 +739,13 @@ void mll_h2e_kernel(MllArgs a) {
     __shared__ f32x4 wl[WLDS * 64];                              // W accumulators, tiles 0 .. WLDS-1
     __shared__ f32x4 yst[NT * 4];                                // the targets of the class; later alpha
 
-    const int b = blockIdx.x;
+    // DKT_MLL_E_PER_CLASS: one workgroup per (episode, class) matrix -- its own E[b, c], its own W[b, c], a class "loop" of one
+    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    const bool want_grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;          // without it (test-time conditioning on per-class matrices): phases 1 - 2 only
     const int C = a.C;
+    const int b = epc ? (int)(blockIdx.x / (unsigned)C) : (int)blockIdx.x;
+    const int c_first = epc ? (int)(blockIdx.x % (unsigned)C) : 0, c_end = epc ? c_first + 1 : C;
+    const size_t mat = epc ? (size_t)b * C + c_first : (size_t)b;          // index of the [N, N] matrices E / W of this workgroup
     const float qnan = __int_as_float(0x7fc00000);
     int tq = threadIdx.x;
     DKT_OPAQUE_V(tq);
@@ -766,7 +771,7 @@ void mll_h2e_kernel(MllArgs a) {
     // psd_safe_cholesky's ladder.  (A retry loop AROUND the factorisation keeps everything it might need alive across its back edge:
     // +70 VGPRs at NT = 7, measured.)
     int attempt = 0;
-    for (int c = 0; c < C;) {
+    for (int c = c_first; c < c_end;) {
         // lane coordinates and sizes made opaque per class (and again per phase): keeps the compiler from hoisting -- and then spilling --
         // every mask and address of the loop body into the kernel prologue
         tq = threadIdx.x;
@@ -806,7 +811,7 @@ void mll_h2e_kernel(MllArgs a) {
         int fail_at = 0;
         float jit = 0.f, lsum = 0.f, quad = 0.f, aug_unscale = 1.f;
         int msc = 0;
-        const brsrc Er = mk_rsrc(a.E + (size_t)b * N * N, (unsigned)(N * N * 4));
+        const brsrc Er = mk_rsrc(a.E + mat * N * N, (unsigned)(N * N * 4));
         {
             if (attempt > 0) {
                 jit = a.jitter0;
@@ -935,7 +940,7 @@ void mll_h2e_kernel(MllArgs a) {
         }
         mx = wave_reduce_dpp<true>(mx) * gsc;
         mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));
-        const bool live = (fail_at == 0) && (wmag > 0.f) && (mx > 0.f) && (mx < 3.0e38f);     // a zero-weight class contributes nothing
+        const bool live = want_grad && (fail_at == 0) && (wmag > 0.f) && (mx > 0.f) && (mx < 3.0e38f);     // a zero-weight class contributes nothing
         poison = poison || (fail_at != 0);
         float trk = 0.f;
         if (live) {
@@ -1018,7 +1023,7 @@ void mll_h2e_kernel(MllArgs a) {
         asum = wave_reduce_dpp<false>(asum);
         aa = wave_reduce_dpp<false>(aa);
         trk = wave_reduce_dpp<false>(trk);
-        if (!live && fail_at == 0) {
+        if (want_grad && !live && fail_at == 0) {
             // zero-weight class: the trace is still wanted for the hyper-gradients -- tr K^-1 = |M|_F^2 (row N is zero by now)
             float fro = 0.f;
 #pragma unroll
@@ -1037,24 +1042,26 @@ void mll_h2e_kernel(MllArgs a) {
             a.logp[bc] = ok ? (-0.5f * quad - 0.34657359027997264f * lsum - (float)N * DKT_HALF_LOG_2PI) : qnan;
             a.jitter_used[bc] = jit;
             a.info[bc] = fail_at;
-            const float nz_eff = nzc + jit;
-            a.dmean[bc] = ok ? asum : qnan;
-            a.dnoise[bc] = ok ? -0.5f * trk : qnan;                                     // 0.5 (alpha.alpha - tr K^-1)
-            a.dsv[bc] = ok ? 0.5f * ((quad - (float)N) + nz_eff * trk) / svc : qnan;
+            if (want_grad) {
+                const float nz_eff = nzc + jit;
+                a.dmean[bc] = ok ? asum : qnan;
+                a.dnoise[bc] = ok ? -0.5f * trk : qnan;                                     // 0.5 (alpha.alpha - tr K^-1)
+                a.dsv[bc] = ok ? 0.5f * ((quad - (float)N) + nz_eff * trk) / svc : qnan;
+            }
         }
         DKT_PH(5);
         attempt = 0;
         ++c;
     }
     // ---- W[b] = sigma unit^-2 accumulators, stored once (a failed class poisons it) ----
-    {
+    if (want_grad) {
         tq = threadIdx.x;
         DKT_OPAQUE_V(tq);
         c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63; N = a.N;
         DKT_OPAQUE_S(N);
         const int pN = N - 16 * (NT - 1);
         const float fin = poison ? qnan : ((sigma == 0.f) ? 0.f : sigma * ldexpf(1.0f, -2 * (15 - e_acc)));
-        const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)(N * N * 4));
+        const brsrc Wr = mk_rsrc(a.W + mat * N * N, (unsigned)(N * N * 4));
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const bool col_ok = (j < NT - 1) || (c16 < pN);
@@ -1089,7 +1096,7 @@ void mll_h2e_kernel(MllArgs a) {
 #ifdef DKT_MFMA_CLOCKS
     DKT_PH(6);
     if (lane == 0 && a.ws) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + (size_t)b * 8;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws) + (size_t)blockIdx.x * 8;
         for (int i = 0; i < 7; ++i) o[i] = ph[i];
         o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     }
@@ -1108,6 +1115,10 @@ template <int NT>
 void launch_h2(const MllArgs& a, hipStream_t st) {
     const bool g = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     if constexpr (NT <= 7) {
+        if (a.flags & DKT_MLL_E_PER_CLASS) {               // per-class base matrices: always one wave per matrix, nothing shared
+            hipLaunchKernelGGL((mll_h2e_kernel<NT>), dim3(a.B * a.C), dim3(64), 0, st, a);
+            return;
+        }
         if (g && a.B >= h2e_min_batch()) {
             hipLaunchKernelGGL((mll_h2e_kernel<NT>), dim3(a.B), dim3(64), 0, st, a);
             return;
@@ -1130,6 +1141,7 @@ void dkt_mll_h2_reload_env() { g_h2e_minb = -1; }        // dkt_reload_env(): te
 bool dkt_mll_h2_launch(const MllArgs& a, hipStream_t st) {
     if (a.flags & DKT_MLL_WANT_CHOL) return false;
     const int nt = (a.N + 1 + 15) / 16;
+    if ((a.flags & DKT_MLL_E_PER_CLASS) && nt > 7) return false;
     switch (nt) {
         case 1: launch_h2<1>(a, st); return true;
         case 2: launch_h2<2>(a, st); return true;

@@ -300,16 +300,23 @@ class DKT(MetaTemplate):
                                                                      unit_rows=bool(self.normalize))
         else:
             # rbf / matern / polynomial: every class model owns its lengthscale / offset (one ExactGPLayer per class,
-            # DKT.py:63-66), so the base matrix differs per class: one Gram + one single-model MLL launch per class
+            # DKT.py:63-66), so the base matrix differs per class
             ls, off = self.model.lengthscale, self.model.offset
-            objs, logps, alphas, infos, jits = [], [], [], [], []
-            for k in range(c):
-                e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
-                yk = y[..., k:k + 1, :].contiguous()
-                o, lp, al, inf, jt = ops.mll_objective(e, yk, sv[k:k + 1], mean[k:k + 1], noise[k:k + 1], cw[k:k + 1], self.jitter0, self.max_tries)
-                objs.append(o); logps.append(lp); alphas.append(al); infos.append(inf); jits.append(jt)
-            obj = torch.stack(objs, 0).sum(0)
-            logp, alpha, info, jit = torch.cat(logps, 1), torch.cat(alphas, 1), torch.cat(infos, 1), torch.cat(jits, 1)
+            if n + 1 <= 112:
+                # ONE contraction per episode (squared distances / Gram), the per-class map element-wise, ONE marginal-likelihood
+                # launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS)
+                e = ops.base_matrix_per_class(zb, self.kernel_type, ls, off)
+                obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+            else:
+                # larger episodes: one Gram + one single-model launch per class
+                objs, logps, alphas, infos, jits = [], [], [], [], []
+                for k in range(c):
+                    e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
+                    yk = y[..., k:k + 1, :].contiguous()
+                    o, lp, al, inf, jt = ops.mll_objective(e, yk, sv[k:k + 1], mean[k:k + 1], noise[k:k + 1], cw[k:k + 1], self.jitter0, self.max_tries)
+                    objs.append(o); logps.append(lp); alphas.append(al); infos.append(inf); jits.append(jt)
+                obj = torch.stack(objs, 0).sum(0)
+                logp, alpha, info, jit = torch.cat(logps, 1), torch.cat(alphas, 1), torch.cat(infos, 1), torch.cat(jits, 1)
         aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
         return obj.mean(), aux
 
@@ -329,6 +336,15 @@ class DKT(MetaTemplate):
             mu, labels = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type), out["alpha"], sv, mean)
             return mu[0], labels[0], out
         # per-class base matrices (E depends on the class model's own, post-step, lengthscale / offset)
+        if zc.shape[1] + 1 <= 112:
+            # one contraction for the conditioning set, one for the cross kernel; the class maps element-wise; one launch for all classes
+            e_c = ops.kernel_matrix_per_class(zc, None, self.kernel_type, ls, off)               # [1, C, N, N]
+            out = ops.mll(e_c, y, sv, mean, noise, jitter0=self.jitter0, max_tries=self.max_tries)
+            ex_c = ops.kernel_matrix_per_class(zs, zc, self.kernel_type, ls, off)                # [1, C, M, N]
+            mu = mean.reshape(1, -1, 1) + sv.reshape(1, -1, 1) * torch.einsum("bcmn,bcn->bcm", ex_c, out["alpha"])
+            cidx = torch.arange(mu.shape[1], device=mu.device, dtype=torch.int32).view(1, -1, 1)
+            labels = torch.where(mu == mu.max(1, keepdim=True).values, cidx, torch.full_like(cidx, mu.shape[1])).min(1).values
+            return mu[0], labels[0], {key: out[key] for key in ("logp", "alpha", "jitter", "info")}
         mus, outs = [], []
         for k in range(y.shape[-2]):
             lk, ok = (None if ls is None else ls[k:k + 1]), (None if off is None else off[k:k + 1])

@@ -32,6 +32,7 @@ MLL_FORCE_GENERIC = 4
 MLL_FORCE_REG = 8
 MLL_FORCE_BLOCKED = 16
 MLL_FORCE_F32MFMA = 32
+MLL_E_PER_CLASS = 64
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -147,12 +148,14 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
         jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False,
         force_blocked: bool = False, force_f32mfma: bool = False) -> dict:
-    """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N]; y:[C,N] (shared) or [B,C,N].
+    """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N] (one base matrix shared by the class models) or
+    [B,C,N,N] (one per class model: DKT_MLL_E_PER_CLASS -- then w is [B,C,N,N] too); y:[C,N] (shared) or [B,C,N].
     force_*: the parity-tested twins of the default kernels (DKT_MLL_FORCE_* of include/dkt_abi.h)."""
-    e = _req(e, "e", 3)
-    b_, n, n2 = e.shape
+    per_class = e.dim() == 4
+    e = _req(e, "e", 4 if per_class else 3)
+    b_, n, n2 = e.shape[0], e.shape[-2], e.shape[-1]
     if n != n2:
-        raise RuntimeError("mll: e must be [B,N,N]")
+        raise RuntimeError("mll: e must be [B,N,N] or [B,C,N,N]")
     y = _req(y, "y")
     if y.dim() == 2:
         c_, y_bstride = y.shape[0], 0
@@ -167,20 +170,22 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     noise = _req(noise.reshape(-1), "noise", 1)
     if not (sv.numel() == mean.numel() == noise.numel() == c_):
         raise RuntimeError("mll: sv/mean/noise must have C=%d elements" % c_)
+    if per_class and e.shape[1] != c_:
+        raise RuntimeError("mll: per-class e must be [B,C=%d,N,N]" % c_)
     dev = e.device
     logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
     flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
-             (MLL_FORCE_F32MFMA if force_f32mfma else 0))
+             (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0))
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL
         chol = torch.empty((b_, c_, n, n), device=dev, dtype=torch.float32)
     if want_grad:
         flags |= MLL_WANT_GRAD
-        w = torch.empty((b_, n, n), device=dev, dtype=torch.float32)
+        w = torch.empty((b_, c_, n, n) if per_class else (b_, n, n), device=dev, dtype=torch.float32)
         dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
         dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
         dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
@@ -421,6 +426,37 @@ def spectral_mixture_matrix(z: torch.Tensor, weights: torch.Tensor, means: torch
     return _SpectralMixtureFn.apply(z, weights, means, scales)
 
 
+def base_matrix_per_class(z: torch.Tensor, kernel: str, lengthscale: Optional[torch.Tensor] = None,
+                          offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable E[B,C,N,N] for the kernels whose class models own their base-kernel parameter (one ExactGPLayer per class,
+    reference DKT.py:63-66, 352-365): rbf / matern (lengthscale [C]), poli1 / poli2 (offset [C]).  The O(N^2 D) contraction -- the
+    squared distances or the Gram -- is built ONCE per episode (dkt_gram_f32); the per-class map is element-wise."""
+    one = torch.ones(1, device=z.device, dtype=torch.float32)
+    if kernel in POLY_KINDS:
+        g = _BaseMatrixFn.apply(z, torch.zeros(1, device=z.device, dtype=torch.float32), KERNEL_LINEAR)
+        return (g.unsqueeze(1) + offset.reshape(1, -1, 1, 1)) ** POLY_KINDS[kernel]
+    u = _SqDistFn.apply(z, one).unsqueeze(1) / (lengthscale.reshape(1, -1, 1, 1) ** 2)         # |z_i - z_j|^2 / l_c^2
+    if kernel in MATERN_KINDS:
+        return _matern25(u)
+    if kernel in RBF_KINDS:
+        return torch.exp(-0.5 * u)
+    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' has no per-class base-kernel parameter")
+
+
+def kernel_matrix_per_class(a: torch.Tensor, bm: Optional[torch.Tensor], kernel: str, lengthscale: Optional[torch.Tensor] = None,
+                            offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """k_c(a, bm) for every class model, [B,C,M,N] (no autograd): one contraction, C element-wise maps."""
+    one = torch.ones(1, device=a.device, dtype=torch.float32)
+    if kernel in POLY_KINDS:
+        return (gram(a, bm, KERNEL_LINEAR).unsqueeze(1) + offset.reshape(1, -1, 1, 1)) ** POLY_KINDS[kernel]
+    u = gram(a, bm, KERNEL_SQDIST, one).unsqueeze(1) / (lengthscale.reshape(1, -1, 1, 1) ** 2)
+    if kernel in MATERN_KINDS:
+        return _matern25(u)
+    if kernel in RBF_KINDS:
+        return torch.exp(-0.5 * u)
+    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' has no per-class base-kernel parameter")
+
+
 def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None,
                 offset: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Differentiable symmetric base kernel matrix E[B,N,N] of z[B,N,D] for every kernel type of the reference's
@@ -457,7 +493,7 @@ class _MllObjectiveFn(torch.autograd.Function):
             return (None,) * 8
         w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        ge = w * gobj.reshape(-1, 1, 1) if ctx.needs_input_grad[0] else None
+        ge = w * gobj.reshape([-1] + [1] * (w.dim() - 1)) if ctx.needs_input_grad[0] else None      # w: [B,N,N] or [B,C,N,N] (per-class E)
         gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)          # [B,C]
         gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
         gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None

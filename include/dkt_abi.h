@@ -58,6 +58,7 @@ extern "C" {
 #define DKT_MLL_FORCE_REG 8u     /* validation aid: the register-sweep kernel instead of the MFMA wave-per-matrix kernel (N <= 127) */
 #define DKT_MLL_FORCE_BLOCKED 16u /* validation aid: the blocked batched-GEMM path instead of the tile-array kernels (N > 127) */
 #define DKT_MLL_FORCE_F32MFMA 32u /* validation aid: the exact-fp32 MFMA wave-per-matrix kernel instead of the f16-split one (N <= 127) */
+#define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */
 
 int dkt_abi_version(void);
 
@@ -99,6 +100,10 @@ size_t dkt_mll_workspace_bytes(int B, int C, int N);
  *        dsv[b,c]  = sum_ij M_c,ij E_ij   dmean[b,c] = sum_i alpha_i   dnoise[b,c] = tr M_c
  *        (raw d logp[b,c] / d theta_c; the caller applies cls_weight / upstream grads)
  *        cls_weight: [C] device or NULL (= 1).
+ *   flags & DKT_MLL_E_PER_CLASS : the class models do not share a base matrix (rbf / matern / polynomial kernels with per-class
+ *        lengthscale / offset: one ExactGPLayer per class, methods/DKT.py:63-66, 352-365):  K_c = sv[c] * E[b,c] + noise[c] * I with
+ *        E:[B,C,N,N], and W:[B,C,N,N] holds W[b,c] = cls_weight[c] * sv[c] * M_c = d obj_b / d E[b,c] per class.  One launch for all
+ *        classes; N <= 111, without DKT_MLL_WANT_CHOL / DKT_MLL_FORCE_* (DKT_ERR_TOO_LARGE / DKT_ERR_BAD_ARG otherwise).
  * Replaces: `loss = -self.mll(output, self.model.train_targets)` and its autograd backward
  *   (methods/DKT.py:161-163, 252-254; methods/DKT_regression.py:53-56): GPyTorch
  *   GaussianLikelihood.marginal + MultivariateNormal.log_prob + psd_safe_cholesky +

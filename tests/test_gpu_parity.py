@@ -511,6 +511,57 @@ def test_mll_wave_per_episode_class_weights_signs_and_units(cuda, monkeypatch):
             assert rel_l2(out["dnoise"][i].cpu().numpy(), dnoise) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("c,per,d", [(5, 21, 48), (5, 5, 32), (3, 37, 24), (7, 9, 16)])
+def test_mll_per_class_base_matrices_one_launch(cuda, c, per, d):
+    """DKT_MLL_E_PER_CLASS: rbf / matern / polynomial class models own their lengthscale / offset (one ExactGPLayer per class,
+    methods/DKT.py:63-66, 352-365), so K_c = sv_c E[b, c] + noise_c I with a base matrix per class.  One launch over all (episode,
+    class) matrices must reproduce the oracle per class -- log-likelihood, alpha, W[b, c] = d obj / d E[b, c], hyper-gradients -- with
+    and without the gradient outputs, and the C single-model launches it replaces."""
+    n = c * per
+    rng = np.random.default_rng(c * 100 + per)
+    z = O.synthetic_features(2, n, d, 300 + c, 0)
+    y = O.one_vs_rest_targets(c, per)
+    ls = np.linspace(0.8, 1.9, c)
+    sv = np.linspace(0.5, 2.0, c)
+    mean = 0.05 * rng.standard_normal(c)
+    noise = np.linspace(0.08, 0.3, c)
+    cw = np.full(c, -1.0 / (c * n))
+    e64 = np.stack([np.stack([O.gram_rbf(z[i], None, ls[k]) for k in range(c)]) for i in range(2)])      # [2, C, N, N]
+    args = (dev_t(e64, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda))
+    out = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    fwd = ops.mll(*args)
+    torch.cuda.synchronize()
+    assert out["w"].shape == (2, c, n, n) and int(out["info"].abs().max().item()) == 0 and int(fwd["info"].abs().max().item()) == 0
+    for key in ("logp", "alpha"):
+        assert rel_l2(fwd[key].cpu().numpy(), out[key].cpu().numpy()) < 2e-6, key
+    for i in range(2):
+        for k in range(c):
+            e = e64[i, k].astype(np.float32).astype(np.float64)
+            res = O.mll_terms(e, y[k:k + 1], sv[k:k + 1], mean[k:k + 1], noise[k:k + 1])
+            assert abs((out["logp"][i, k].item() - res.logp[0]) / res.logp[0]) < MLL_RTOL
+            assert rel_l2(out["alpha"][i, k].cpu().numpy(), res.alpha[0]) < 5e-4
+            w_ref, dsv, dmean, dnoise = O.mll_grads(e, res, sv[k:k + 1], noise[k:k + 1], cw[k:k + 1])
+            _, dsv1, dmean1, dnoise1 = O.mll_grads(e, res, sv[k:k + 1], noise[k:k + 1], np.ones(1))
+            wk = out["w"][i, k].cpu().numpy()
+            assert rel_l2(wk, w_ref) < GRAD_RTOL and (wk == wk.T).all()
+            assert abs(out["dsv"][i, k].item() - dsv1[0]) < GRAD_RTOL * abs(dsv1[0]) + 1e-5
+            assert abs(out["dmean"][i, k].item() - dmean1[0]) < GRAD_RTOL * abs(dmean1[0]) + 1e-6
+            assert abs(out["dnoise"][i, k].item() - dnoise1[0]) < GRAD_RTOL * abs(dnoise1[0]) + 1e-5
+            # the single-model launch this replaces (per-class Python loop of rounds 1 - 2)
+            one = ops.mll(dev_t(e64[i:i + 1, k], cuda), dev_t(y[k:k + 1], cuda), dev_t(sv[k:k + 1], cuda), dev_t(mean[k:k + 1], cuda),
+                          dev_t(noise[k:k + 1], cuda), want_grad=True, cls_weight=dev_t(cw[k:k + 1], cuda))
+            assert rel_l2(out["w"][i, k].cpu().numpy(), one["w"][0].cpu().numpy()) < 2e-5
+            assert abs(out["logp"][i, k].item() - one["logp"][0, 0].item()) < 5e-6 * abs(one["logp"][0, 0].item())
+    # argument errors: the Cholesky output and the validation twins do not exist for per-class matrices; N > 111 is too large
+    with pytest.raises(RuntimeError):
+        ops.mll(*args, want_chol=True)
+    with pytest.raises(RuntimeError):
+        ops.mll(*args, want_grad=True, force_reg=True)
+    big = torch.eye(120, device=cuda).repeat(1, 2, 1, 1)
+    with pytest.raises(RuntimeError):
+        ops.mll(big, torch.ones(2, 120, device=cuda), torch.ones(2, device=cuda), torch.zeros(2, device=cuda), torch.full((2,), 0.1, device=cuda), want_grad=True)
+
+
 def n_hash(*a):
     return int(sum((i + 1) * v for i, v in enumerate(a)))
 
