@@ -13,11 +13,15 @@
 // Replaces ExactGPLayer.forward -> covar_module(x) (reference methods/DKT.py:375-378,
 // methods/DKT_regression.py:126-129) and autograd through it (DKT.py:163).
 #include "dkt_common.h"
+#include <cstdlib>
 #include "../../include/dkt_abi.h"
 
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st);
 bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
+// wave-per-episode kernels for N <= 32 (dkt_gram_small.hip): every kind, symmetric; DKT_GRAM_SMALL=0 keeps the generic kernels
+bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st);
+bool dkt_gram_small_bwd_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st);
 bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st);
 
 namespace {
@@ -361,6 +365,10 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     const bool sym = (Bm == nullptr);
     if (sym && M != N) return DKT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const char* sm = getenv("DKT_GRAM_SMALL");
+    const bool small_ok = !(sm && sm[0] == '0');
+    if (sym && small_ok && dkt_gram_small_launch(A, E, B, N, D, kind, lengthscale, st))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, unit, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_big_launch(A, E, B, N, D, unit, st))
@@ -383,6 +391,11 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
 extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, int D,
                                 const float* ep_scale, unsigned flags, void* stream) {
     if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0 || (flags & ~(DKT_GRAM_UNIT_ROWS | DKT_GRAM_W_SYMMETRIC))) return DKT_ERR_BAD_ARG;
+    {
+        const char* sm = getenv("DKT_GRAM_SMALL");
+        if (!(sm && sm[0] == '0') && dkt_gram_small_bwd_launch(W, Z, dZ, B, N, D, ep_scale, (hipStream_t)stream))
+            return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    }
     if (dkt_gram_bwd_ep_launch(W, Z, dZ, B, N, D, ep_scale, (flags & DKT_GRAM_UNIT_ROWS) != 0, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (dkt_gram_bwd_big_launch(W, Z, dZ, B, N, D, ep_scale, flags, (hipStream_t)stream))

@@ -1,0 +1,221 @@
+// dkt_gram_small.hip -- Gram build and Gram backward for SMALL conditioning sets (N <= 32): one WAVE per episode / task, no LDS
+// staging, no barrier.  The regression head of the reference works on 19 frames of one person (methods/DKT_regression.py:45-64,
+// qmul_loader.py: Z is [19, 2916]) and a 5-way 5-shot test episode conditions on 25 support features (methods/DKT.py:224-240): a
+// 64 x 64 output tile per 256-thread workgroup (dkt_gram.hip) fills a third of its MFMA tile and a tenth of the HBM roof there.
+//
+// Replaces ExactGPLayer.forward -> covar_module(x) (reference methods/DKT.py:375-378, methods/DKT_regression.py:126-129:
+// LinearKernel / RBFKernel evaluation) and autograd through it (DKT.py:163, DKT_regression.py:56) at these sizes.
+//
+// Forward, E = k(Z, Z): v_mfma_f32_16x16x4_f32 takes ONE float per lane for A (lane (g, r): A[r][k = g]) and for B (B[k = g][r]), so
+// the float4 a lane loads from row 16 blk + r at features 16 s + 4 g .. + 3 is four A operands AND four B operands of the episode's
+// own Gram (a k-permutation: the t-th MFMA of the step contracts the features 16 s + 4 g + t) -- the operands go from the global
+// load straight into the matrix instruction, coalesced as 64-byte row segments.  Exact fp32 (bitwise a k-ordered fmaf chain).  RBF /
+// squared distances as in dkt_gram.hip: rows shifted by row 0 (the role of GPyTorch's mean-centring), d2 = G_ii + G_jj - 2 G_ij from
+// the Gram's own diagonal (exactly 0 on the diagonal), clamped at 0.
+// Backward, dZ = s (W + W^T) Z: the contraction runs over the rows j of Z, which a lane reads as float4 of row 4 kk + g at columns
+// d0 + 4 c .. + 3: element e is the B operand of output tile e, whose column c therefore stands for the feature d0 + 4 c + e -- the
+// four accumulators of a lane are four consecutive features of one row: one 16-byte store.  (W + W^T) sits in 2 x 8 registers.
+// HBM traffic = the algorithmic bytes: Z once (forward), Z + dZ once (backward).
+#include "dkt_common.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t brsrc;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SM_OOB = 0x7ffffff0;      // an offset every descriptor rejects: the load returns 0, the store is dropped
+
+__device__ __forceinline__ brsrc sm_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 sm_load4(brsrc r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+
+constexpr int SM_PF = 4;                 // 16-feature steps in flight
+
+template <int KIND, int NB>              // NB = 1: N <= 16, NB = 2: N <= 32
+__global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
+                                                         const float* __restrict__ lengthscale) {
+    __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;                  // (no workgroup barrier below: the LDS scratch is per wave)
+    const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
+    int voff[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) voff[blk] = (16 * blk + r < N) ? ((16 * blk + r) * D + 4 * g) * 4 : SM_OOB;
+    const int nstep = (D + 15) >> 4;
+    f32x4 x[SM_PF][NB], ref[SM_PF];
+    auto load = [&](const int slot, const int s) {
+        const bool in = s < nstep && 16 * s + 4 * g < D;             // D % 4 == 0: a float4 is inside the row or wholly beyond it
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) x[slot][blk] = sm_load4(zr, in ? voff[blk] : SM_OOB, s * 64);
+        if (KIND != DKT_KERNEL_LINEAR) ref[slot] = sm_load4(zr, in ? 16 * g : SM_OOB, s * 64);
+    };
+    f32x4 acc[NB * (NB + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < SM_PF; ++p) load(p, p);
+    for (int s0 = 0; s0 < nstep; s0 += SM_PF) {
+#pragma unroll
+        for (int p = 0; p < SM_PF; ++p) {
+            f32x4 xb[NB];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                xb[blk] = x[p][blk];
+                if (KIND != DKT_KERNEL_LINEAR) {
+                    // rows beyond N loaded as 0 and must stay 0 (not -ref): the mask rides on the row test
+                    const bool row_ok = 16 * blk + r < N;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xb[blk][t] = row_ok ? xb[blk][t] - ref[p][t] : 0.f;
+                }
+            }
+            load(p, s0 + p + SM_PF);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[0][t], xb[0][t], acc[0], 0, 0, 0);
+                if constexpr (NB == 2) {
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[1][t], xb[0][t], acc[1], 0, 0, 0);      // rows 16.., columns 0..15
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[1][t], xb[1][t], acc[2], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue.  C / D layout: lane (g, c = r), register q  <->  element [4 g + q][c] ----
+    float* Eb = E + (size_t)b * N * N;
+    float inv_l2 = 0.f;
+    if (KIND != DKT_KERNEL_LINEAR) {
+        const float l = lengthscale[0];
+        inv_l2 = 1.0f / (l * l);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const f32x4 dg = acc[blk == 0 ? 0 : 2];
+            const float dv = ((r & 3) == 0) ? dg[0] : ((r & 3) == 1) ? dg[1] : ((r & 3) == 2) ? dg[2] : dg[3];
+            if ((r >> 2) == g) dvec[wave][16 * blk + r] = dv;          // element [r][r] lives in lane (g = r / 4, c = r), register r % 4
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): the wave's own LDS writes have landed
+    }
+    auto emit = [&](const f32x4 v, const int bi, const int bj) {      // tile (bi, bj), bi >= bj; the mirror for bi > bj
+        const int col = 16 * bj + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * bi + 4 * g + q;
+            if (row >= N || col >= N) continue;
+            float o = v[q];
+            if (KIND != DKT_KERNEL_LINEAR) {
+                float d2 = dvec[wave][row] + dvec[wave][col] - 2.0f * o;
+                d2 = d2 > 0.f ? d2 : 0.f;
+                if (row == col) d2 = 0.f;
+                o = (KIND == DKT_KERNEL_RBF) ? expf(-0.5f * d2 * inv_l2) : d2 * inv_l2;
+            }
+            if (bi == bj) {
+                if (col > row) continue;                               // lower triangle + its mirror: bitwise symmetric
+                Eb[(size_t)row * N + col] = o;
+                if (col != row) Eb[(size_t)col * N + row] = o;
+            } else {
+                Eb[(size_t)row * N + col] = o;
+                Eb[(size_t)col * N + row] = o;
+            }
+        }
+    };
+    emit(acc[0], 0, 0);
+    if constexpr (NB == 2) {
+        emit(acc[1], 1, 0);
+        emit(acc[2], 1, 1);
+    }
+}
+
+// dZ[b] = s_b (W[b] + W[b]^T) Z[b], N <= 32
+__global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z, float* __restrict__ dZ,
+                                                             int B, int N, int D, const float* __restrict__ ep_scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float sc = ep_scale ? ep_scale[b] : 1.0f;
+    const float* Wb = W + (size_t)b * N * N;
+    const int nq = (N + 3) >> 2;                                       // k-quads: rows j = 4 kk + g of Z
+    // A operands: lane (g, r = c): s (W + W^T)[16 ib + r][4 kk + g]
+    float a[2][8];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int i = 16 * ib + c, j = 4 * kk + g;
+            a[ib][kk] = (i < N && j < N) ? sc * (Wb[(size_t)i * N + j] + Wb[(size_t)j * N + i]) : 0.f;
+        }
+    const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
+    const brsrc dr = sm_rsrc(dZ + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
+    const bool two = N > 16;
+    const int nchunk = (D + 63) >> 6;
+    f32x4 z0[8], z1[8];
+    auto load = [&](f32x4 (&zb)[8], const int ch) {
+        const bool in = ch < nchunk && 64 * ch + 4 * c < D;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            zb[kk] = (kk < nq) ? sm_load4(zr, (in && 4 * kk + g < N) ? ((4 * kk + g) * D + 4 * c) * 4 : SM_OOB, ch * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto chunk = [&](const f32x4 (&zb)[8], const int ch) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ib][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk < nq) {                                             // uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kk], zb[kk][e], acc[0][e], 0, 0, 0);
+                    if (two) acc[1][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kk], zb[kk][e], acc[1][e], 0, 0, 0);
+                }
+            }
+        }
+        // element [4 g + q][c] of tile e is dZ[16 ib + 4 g + q][64 ch + 4 c + e]: the four tiles of a lane are one float4
+        const bool col_ok = 64 * ch + 4 * c < D;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            if (ib == 1 && !two) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * ib + 4 * g + q;
+                const u32x4 v = {__float_as_uint(acc[ib][0][q]), __float_as_uint(acc[ib][1][q]), __float_as_uint(acc[ib][2][q]), __float_as_uint(acc[ib][3][q])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, dr, (row < N && col_ok) ? (row * D + 4 * c) * 4 : SM_OOB, ch * 256, 0);
+            }
+        }
+    };
+    load(z0, 0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        load(z1, ch + 1);
+        chunk(z0, ch);
+        load(z0, ch + 2);
+        if (ch + 1 < nchunk) chunk(z1, ch + 1);
+    }
+}
+
+}  // namespace
+
+// Symmetric Gram of small episodes (N <= 32, D % 4 == 0, 16-byte aligned Z); returns false when it does not apply.
+bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
+    if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
+    const dim3 grid((B + 3) / 4), block(256);
+#define DKT_SM_LAUNCH(K)                                                                                              \
+    do {                                                                                                              \
+        if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1>), grid, block, 0, st, Z, E, B, N, D, lengthscale);   \
+        else hipLaunchKernelGGL((gram_small_kernel<K, 2>), grid, block, 0, st, Z, E, B, N, D, lengthscale);           \
+    } while (0)
+    if (kind == DKT_KERNEL_LINEAR) DKT_SM_LAUNCH(DKT_KERNEL_LINEAR);
+    else if (kind == DKT_KERNEL_RBF) DKT_SM_LAUNCH(DKT_KERNEL_RBF);
+    else if (kind == DKT_KERNEL_SQDIST) DKT_SM_LAUNCH(DKT_KERNEL_SQDIST);
+    else return false;
+#undef DKT_SM_LAUNCH
+    return true;
+}
+
+bool dkt_gram_small_bwd_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
+    if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
+    hipLaunchKernelGGL(gram_small_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
+    return true;
+}

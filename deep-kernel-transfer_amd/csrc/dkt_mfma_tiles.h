@@ -65,19 +65,24 @@ struct Lane {
 // read: 2 wait states" hazard for whatever the compiler placed just before the block; inside it every instruction reads a register
 // written at least one pivot earlier.
 #define DKT_FMD(k) "v_fmac_f32_dpp %" #k ", %" #k ", %[t] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
+#ifdef DKT_SWEEP_NO_NOP          // experiment: no wait states in front of a piece (every x[i] it reads was written a pivot earlier)
+#define DKT_PIECE_NOP ""
+#else
+#define DKT_PIECE_NOP "s_nop 1\n\t"
+#endif
 template <int P, int I0, int CNT>
 __device__ __forceinline__ void sweep_rows_piece(float (&x)[16], const float t) {
     static_assert(CNT >= 0 && CNT <= 5 && I0 + CNT <= 16, "piece");
     if constexpr (CNT == 1)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) : "+v"(x[I0 + 0]) : [t] "v"(t), [p] "n"(P));
+        asm volatile(DKT_PIECE_NOP DKT_FMD(0) : "+v"(x[I0 + 0]) : [t] "v"(t), [p] "n"(P));
     else if constexpr (CNT == 2)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]) : [t] "v"(t), [p] "n"(P));
+        asm volatile(DKT_PIECE_NOP DKT_FMD(0) DKT_FMD(1) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]) : [t] "v"(t), [p] "n"(P));
     else if constexpr (CNT == 3)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]) : [t] "v"(t), [p] "n"(P));
+        asm volatile(DKT_PIECE_NOP DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]) : [t] "v"(t), [p] "n"(P));
     else if constexpr (CNT == 4)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]) : [t] "v"(t), [p] "n"(P));
+        asm volatile(DKT_PIECE_NOP DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]) : [t] "v"(t), [p] "n"(P));
     else if constexpr (CNT == 5)
-        asm volatile("s_nop 1\n\t" DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]), "+v"(x[I0 + 4]) : [t] "v"(t), [p] "n"(P));
+        asm volatile(DKT_PIECE_NOP DKT_FMD(0) DKT_FMD(1) DKT_FMD(2) DKT_FMD(3) DKT_FMD(4) : "+v"(x[I0 + 0]), "+v"(x[I0 + 1]), "+v"(x[I0 + 2]), "+v"(x[I0 + 3]), "+v"(x[I0 + 4]) : [t] "v"(t), [p] "n"(P));
 }
 #undef DKT_FMD
 
