@@ -27,6 +27,7 @@ struct MllArgs {
     float jitter0;
     int max_tries;
     unsigned flags;
+    int p2_guard;                 // wave-per-episode kernel: binades of head room of the f16 scale of M over the diagonal tiles (DKT_MLL_P2_GUARD, default 1)
 };
 
 constexpr float DKT_HALF_LOG_2PI = 0.91893853320467274178f;

@@ -19,6 +19,7 @@
 // (reference methods/DKT.py:161-163, 177, 187, 252-254, 265, 330; methods/DKT_regression.py:53-56, 92),
 // i.e. GPyTorch psd_safe_cholesky / inv_quad_logdet / cholesky_solve.
 #include "dkt_mll.h"
+#include <cstdlib>
 
 namespace {
 
@@ -226,6 +227,10 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.dmean = dmean; a.dnoise = dnoise; a.jitter_used = jitter_used; a.info = info;
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
+    {
+        const char* pg = getenv("DKT_MLL_P2_GUARD");      // validation aid: a negative guard forces the grow-on-demand path of dkt_mll_h2.hip
+        a.p2_guard = pg ? atoi(pg) : 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (flags & DKT_MLL_E_PER_CLASS) {
         // one base matrix per class model: served by the wave-per-matrix form of the f16-split kernel only (training call, N <= 111)

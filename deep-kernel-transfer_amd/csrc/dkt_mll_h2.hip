@@ -38,6 +38,10 @@ namespace {
 
 using namespace dkt_mfma;
 
+// Phase 2 of the wave-per-episode kernel on the f16 pipe too (1, default) or on v_mfma_f32_16x16x4_f32 with M re-split for phase 3 (0)
+#ifndef DKT_H2E_P2H
+#define DKT_H2E_P2H 1
+#endif
 #ifndef DKT_H2_SWEEP_PRIO
 #define DKT_H2_SWEEP_PRIO 1
 #endif
@@ -867,6 +871,159 @@ void mll_h2e_kernel(MllArgs a) {
         tq = threadIdx.x;
         DKT_OPAQUE_V(tq);
         c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63;
+#if DKT_H2E_P2H
+        // ---- phase 2 on the f16 pipe: M~ = g_c R^-T with g_c = sqrt(0.5 |cw_c| sv_c / kappa_c) folded in, so that phase 3 -- (M~)^T M~ =
+        // |coefficient of K_c^-1 in W| K_c^-1 -- accumulates straight into the episode's W tiles.  Every finished tile of M~ is stored
+        // as an f16 split at ONE scale 2^(15 - e2) for the whole matrix: e2 starts from the largest element of the diagonal tiles (all
+        // known after phase 1) plus a guard binade and GROWS when a tile row comes out larger -- the stored tiles are then re-scaled by
+        // an exact power of two (v_pk_mul_f16), a wave-uniform, rare branch.  M_ji = (-V_jj)^T Q_ji, Q_ji = sum_k R_kj^T M~_ki: R is used
+        // as it was stored in phase 1 (2^15 R), the diagonal tiles serve twice -- without g_c as -V_jj (split on the fly), with g_c as
+        // M~_ii -- and Q is split 2^-8 below M~'s scale (|Q| <= 4 max |M~_ji|: only a row that comes out 128 x above the scale overflows
+        // the f16 range -- reported as a failed matrix, loudly).
+        const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
+        const float wmag = 0.5f * fabsf(cw) * svc;                          // |coefficient| of (K^-1 - alpha alpha^T) in W
+        const float gsc = (wmag > 0.f) ? __builtin_sqrtf(wmag) * ldexpf(1.0f, -msc) : ldexpf(1.0f, -msc);       // g_c (a zero-weight class: any value)
+        const bool arow = (ln.g == (pN >> 2));
+        const int qn = pN & 3;
+        const float asc = ldexpf(aug_unscale, -msc);
+        float asum = 0.f, aa = 0.f;
+        const brsrc ar = mk_rsrc(a.alpha + bc * N, (unsigned)(N * 4));
+        float* ysf = reinterpret_cast<float*>(yst);
+        auto emit_alpha = [&](const float v, const int i) {               // alpha[16 i + c16] = v on the lanes of row N's row group
+            const bool ok = arow && ((i < NT - 1) || (c16 < pN));
+            bstore1(ar, (fail_at != 0) ? qnan : v, ok ? (16 * i + c16) * 4 : OOB, 0);
+            if (arow) ysf[16 * i + c16] = ok ? v : 0.f;
+            asum += ok ? v : 0.f;
+            aa += ok ? v * v : 0.f;
+        };
+        {   // the last segment of alpha = -(row N of M_dd) / rho / sqrt(kappa): from the fp32 diagonal tile, before it is split
+            const f32x4 m = T.t[NT - 1][NT - 1];
+            emit_alpha(-(qn == 0 ? m[0] : qn == 1 ? m[1] : qn == 2 ? m[2] : m[3]) * asc, NT - 1);
+        }
+        float mx = 0.f, mxt0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const f32x4 v = T.t[j][j];
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            if (j == 0) mxt0 = mx;
+        }
+        mx = wave_reduce_dpp<true>(mx);
+        const float mx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));       // max |M_kk|: the -V_jj operands (no g_c) take their scale from it
+        // validation aid (DKT_MLL_P2_GUARD < 0): start from the FIRST diagonal tile only, so that ordinary matrices -- whose M grows along
+        // the diagonal -- exercise the grow-on-demand path row after row
+        if (a.p2_guard < 0) mx = wave_reduce_dpp<true>(mxt0);
+        mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx * gsc)));
+        const bool sane = (fail_at == 0) && (mx > 0.f) && (mx < 3.0e38f) && (mx0 < 3.0e38f);
+        const float unitX = sane ? ldexpf(1.0f, 15 - ((int)((__float_as_uint(mx0) >> 23) & 0xffu) - 126)) : 1.0f;      // unitX max |M_kk| < 2^15
+        int e2 = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 126 + max(a.p2_guard, 0);      // g_c max |M_kk| = f 2^e, 0.5 <= f < 1
+        if (sigma != 0.f) e2 = max(e2, e_acc);                              // never below the accumulators' unit: only THEY are re-scaled in phase 3
+        e2 = sane ? min(max(e2, -100), 100) : 0;
+        float unit2 = ldexpf(1.0f, 15 - e2);
+        bool ovf = false;
+        auto zero_aug_row = [&](f32x4 v) {                                 // the augmented row (-rho alpha_s^T, M_NN = 1) takes no part in K^-1
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (g4 + q == pN) ? 0.f : v[q];
+            return v;
+        };
+        auto scale_planes = [&](const f32x4 raw, const _Float16 f) {      // exact: a power of two on both f16 planes
+            Sp sp = as_sp(raw);
+            sp.h = sp.h * f;
+            sp.m = sp.m * f;
+            return __builtin_bit_cast(f32x4, sp);
+        };
+#pragma unroll
+        for (int j = 1; j < NT; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 nV = neg_transpose_h2(split_h2(T.t[j][j], unitX), negIh);             // -unitX V_jj (no g_c)
+            T.t[j - 1][j - 1] = split_h2(T.t[j - 1][j - 1], gsc * unit2);                       // M~_(j-1)(j-1): its -V has been taken a row ago
+            float mrow = 0.f;
+#pragma unroll
+            for (int i = 0; i < j; i += 2) {
+                if (i + 1 < j) {
+                    f32x4 QA = xtyh0(T.t[i][j], T.t[i][i]);
+                    f32x4 QB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = i + 1; k < j; ++k) xtyh2(T.t[k][j], T.t[i][k], QA, T.t[k][j], T.t[i + 1][k], QB);      // (k == i + 1: the diagonal slot)
+                    f32x4 RA = {0.f, 0.f, 0.f, 0.f}, RB = {0.f, 0.f, 0.f, 0.f};
+                    xtyh2(nV, split_h2(QA, 1.1920928955078125e-07f), RA, nV, split_h2(QB, 1.1920928955078125e-07f), RB);     // 2^-23: Q at M~'s scale / 2^8
+                    T.t[i][j] = RA;
+                    T.t[i + 1][j] = RB;
+                    mrow = fmaxf(mrow, fmaxf(fmaxf(fmaxf(fabsf(RA[0]), fabsf(RA[1])), fmaxf(fabsf(RA[2]), fabsf(RA[3]))),
+                                             fmaxf(fmaxf(fabsf(RB[0]), fabsf(RB[1])), fmaxf(fabsf(RB[2]), fabsf(RB[3])))));
+                } else {
+                    f32x4 Q = xtyh0(T.t[i][j], T.t[i][i]);
+#pragma unroll
+                    for (int k = i + 1; k < j; ++k) Q = xtyh(T.t[k][j], T.t[i][k], Q);
+                    const f32x4 RA = xtyh0(nV, split_h2(Q, 1.1920928955078125e-07f));
+                    T.t[i][j] = RA;
+                    mrow = fmaxf(mrow, fmaxf(fmaxf(fabsf(RA[0]), fabsf(RA[1])), fmaxf(fabsf(RA[2]), fabsf(RA[3]))));
+                }
+            }
+            // the row's tiles hold acc = unitX (g unit2 M_ji) / 2^8; largest element of the row -- its diagonal tile included, which is
+            // split a row later -- at M~'s scale:
+            {
+                const f32x4 v = T.t[j][j];
+                const float md = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                mrow = fmaxf(mrow * (256.0f / unitX), md * gsc * unit2);
+            }
+            mrow = wave_reduce_dpp<true>(mrow);
+            const float ymax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mrow)));
+            float fac = 256.0f / unitX;                                     // acc -> g unit2 M_ji
+            ovf = ovf || !(ymax < 3.0e38f);
+            if (sane && ymax >= 32768.0f && ymax < 3.0e38f) {
+                // this row is larger than everything before it: grow the matrix' scale, re-scale what is stored (exact)
+                const int dgrow = (int)((__float_as_uint(ymax) >> 23) & 0xffu) - 126 - 15;       // ymax 2^-dgrow < 2^15
+                const _Float16 fh = (_Float16)ldexpf(1.0f, -dgrow);
+#pragma unroll
+                for (int k = 0; k < j; ++k) {
+#pragma unroll
+                    for (int i = 0; i <= k; ++i) T.t[i][k] = scale_planes(T.t[i][k], fh);
+                }
+                e2 += dgrow;
+                unit2 = ldexpf(unit2, -dgrow);
+                fac = ldexpf(fac, -dgrow);
+            }
+            if (j == NT - 1) {
+                // alpha = -(row N of M) / rho / sqrt(kappa): M_ji = acc 2^8 / (g unitX unit2_old) = acc fac / (g unit2)
+                const float aun = fac / (gsc * unit2) * asc;
+#pragma unroll
+                for (int i = 0; i < NT - 1; ++i) {
+                    const f32x4 m = T.t[i][NT - 1];
+                    emit_alpha(-(qn == 0 ? m[0] : qn == 1 ? m[1] : qn == 2 ? m[2] : m[3]) * aun, i);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < j; ++i) T.t[i][j] = split_h2((j == NT - 1) ? zero_aug_row(T.t[i][j]) : T.t[i][j], fac);
+        }
+        T.t[NT - 1][NT - 1] = split_h2(zero_aug_row(T.t[NT - 1][NT - 1]), gsc * unit2);
+        if (ovf && fail_at == 0) fail_at = N + 1;                          // f16 range exceeded inside phase 2 (see above): the matrix is reported as failed
+        DKT_PH(2);
+        DKT_PH(3);
+        tq = threadIdx.x;
+        DKT_OPAQUE_V(tq);
+        c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63;
+        // ---- phase 3 on the f16 pipe, accumulated into the episode's W tiles: M~ is already split at the scale 2^(15 - e2) ----
+        const bool live = want_grad && (fail_at == 0) && (wmag > 0.f) && sane;     // a zero-weight class contributes nothing
+        poison = poison || (fail_at != 0);
+        float trk = 0.f;
+        if (live) {
+            const int e_c = e2;
+            const float sg = (cw > 0.f) ? -1.0f : 1.0f;                     // sign of the K^-1 part of W_c
+            const bool first = sigma == 0.f;
+            const bool flip = !first && sg != sigma;
+            const bool grow = !first && e_c > e_acc;
+            if (flip || grow) {
+                // the accumulators change sign and / or unit: a class of the other sign, or one whose M needs a larger bound
+                const float fac = (flip ? -1.0f : 1.0f) * (grow ? ldexpf(1.0f, -2 * (e_c - e_acc)) : 1.0f);
+#pragma unroll
+                for (int n = 0; n < WREG; ++n) wr[n] *= fac;
+#pragma unroll
+                for (int n = 0; n < WLDS; ++n) wl[n * 64 + lane] = wl[n * 64 + lane] * fac;
+            }
+            e_acc = e_c;                                                    // (e2 was chosen >= e_acc)
+            sigma = sg;
+            const float unit = ldexpf(1.0f, 15 - e_acc);                    // accumulators hold sigma unit^2 W
+#else
         // ---- phase 2 (fp32 matrix instruction): M = R^-T; M_ji (j > i) overwrites slot (i, j); M_kk sits in slot (k, k) ----
         f32x4 negI2;
 #pragma unroll
@@ -966,6 +1123,7 @@ void mll_h2e_kernel(MllArgs a) {
 #pragma unroll
                 for (int i = 0; i <= j; ++i) T.t[i][j] = split_h2(T.t[i][j], qsc);
             }
+#endif
             // rank-one term: sigma unit^2 * (+0.5 cw sv) alpha alpha^T = -wmag unit^2 alpha_i alpha_j, into the chains' C operands
             const float* alf = reinterpret_cast<const float*>(yst);
             const float ca = -wmag * unit * unit;
@@ -1030,12 +1188,20 @@ void mll_h2e_kernel(MllArgs a) {
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
                 for (int i = 0; i <= j; ++i) {
+#if DKT_H2E_P2H
+                    const f32x4 u = join_h2(T.t[i][j]);                     // the tiles hold g unit2 M as f16 splits
+#else
                     const f32x4 u = T.t[i][j];
+#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q) fro += (j < NT - 1 || g4 + q < pN) ? u[q] * u[q] : 0.f;
                 }
             }
+#if DKT_H2E_P2H
+            trk = wave_reduce_dpp<false>(fro) * ldexpf(1.0f, -2 * msc) / (gsc * gsc * unit2 * unit2) - aa;
+#else
             trk = wave_reduce_dpp<false>(fro) * ldexpf(1.0f, -2 * msc) - aa;
+#endif
         }
         if (lane == 0) {
             const bool ok = fail_at == 0;

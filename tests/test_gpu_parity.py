@@ -249,16 +249,19 @@ def _episode_case(c, per, d, seed, corr=0, b=2):
                                           # block-column boundaries of the two-pivots-per-barrier sweep (even / odd tails)
                                           (1, 3, 8, 0), (1, 31, 16, 0), (1, 32, 16, 0), (1, 33, 16, 0), (2, 32, 16, 0), (1, 65, 16, 0),
                                           (2, 48, 16, 0), (1, 97, 16, 0), (1, 113, 16, 0), (1, 126, 16, 0)])
-@pytest.mark.parametrize("path", ["default", "h2e", "f32mfma", "reg", "generic"])
+@pytest.mark.parametrize("path", ["default", "h2e", "h2e_grow", "f32mfma", "reg", "generic"])
 def test_mll_forward_and_gradients_vs_oracle(cuda, c, per, d, corr, path, monkeypatch):
     """default: the wave-per-matrix kernel on the f16 matrix pipe (scaled 2-way splits) for N <= 127 -- the training call, i.e. without
     the Cholesky output, at a small batch --, the tile-array / blocked / generic kernels above;  h2e: the wave-per-episode kernel that
-    serves the same call from 1024 episodes per launch (DKT_MLL_H2E_MINB=1 selects it for any batch; N <= 111);  f32mfma: the exact-fp32
+    serves the same call from 1024 episodes per launch (DKT_MLL_H2E_MINB=1 selects it for any batch; N <= 111);  h2e_grow: the same with
+    DKT_MLL_P2_GUARD=-1 -- the f16 scale of M = R^-T then starts from the first diagonal tile alone, so that every matrix walks through
+    the grow-on-demand re-scaling of the stored tiles that production meets only when a tile row jumps above the diagonal;  f32mfma: the exact-fp32
     MFMA twin (DKT_MLL_FORCE_F32MFMA, also what serves want_chol);  reg: the register-sweep twin (DKT_MLL_FORCE_REG);  generic: the
     generic LDS / global kernel for every N."""
     force_generic, force_reg, force_f32 = path == "generic", path == "reg", path == "f32mfma"
-    want_chol = path not in ("default", "h2e")
-    monkeypatch.setenv("DKT_MLL_H2E_MINB", "1" if path == "h2e" else "1000000000")
+    want_chol = path not in ("default", "h2e", "h2e_grow")
+    monkeypatch.setenv("DKT_MLL_H2E_MINB", "1" if path.startswith("h2e") else "1000000000")
+    monkeypatch.setenv("DKT_MLL_P2_GUARD", "-1" if path == "h2e_grow" else "1")
     z, hyp, n = _episode_case(c, per, d, 17 + n_hash(c, per, d), corr)
     y = O.one_vs_rest_targets(c, per)
     sv = hyp.outputscale
@@ -473,12 +476,15 @@ def test_mll_large_and_small_magnitude_base_matrices(cuda, scale, monkeypatch):
             assert errs["h2e"][k] < split_tol[k], (k, errs["h2e"][k], errs["mfma"][k])
 
 
-def test_mll_wave_per_episode_class_weights_signs_and_units(cuda, monkeypatch):
+@pytest.mark.parametrize("guard", ["1", "0", "-1"])
+def test_mll_wave_per_episode_class_weights_signs_and_units(cuda, monkeypatch, guard):
     """The wave-per-episode kernel (csrc/dkt_mll_h2.hip, mll_h2e_kernel) accumulates W over the classes inside the phase-3 products: the
     class weight is folded into the split scale, the accumulators carry one sign and one power-of-two unit.  Class weights of both signs,
     a zero weight, output scales three orders of magnitude apart (the unit grows from class to class) and C = 1 / 7 must reproduce the
-    oracle, bitwise symmetrically and reproducibly."""
+    oracle, bitwise symmetrically and reproducibly -- at the default head room of the f16 scale of M (guard 1), without head room (0) and
+    through the grow-on-demand path on every matrix (-1)."""
     monkeypatch.setenv("DKT_MLL_H2E_MINB", "1")
+    monkeypatch.setenv("DKT_MLL_P2_GUARD", guard)
     rng = np.random.default_rng(11)
     for (c, per, d) in ((5, 21, 64), (7, 9, 32), (1, 40, 16), (3, 37, 24)):
         n = c * per
