@@ -283,7 +283,9 @@ def _measure(cfg, b, args, dev, rank, world, bucket_fn, unit_rows, min_blocks, m
         blocks.append(dt)
         total += dt
     dt = statistics.median(blocks)
-    ktimes = {name: (sum(cn for cn, _ in v), sum(cn * ms for cn, ms in v) / max(sum(cn for cn, _ in v), 1)) for name, v in ktimes_all.items()}
+    # per kernel: launches over all blocks, and the MEDIAN over the blocks of the block's average launch duration (a one-off stall in
+    # one block -- an allocation, a clock ramp after the previous config -- does not leak into the reported kernel time)
+    ktimes = {name: (sum(cn for cn, _ in v), statistics.median(ms for _, ms in v)) for name, v in ktimes_all.items()}
     ok = int(info.abs().max().item()) == 0 and bool(torch.isfinite(loss))
     # same inputs -> bitwise the same outputs (no atomics, fixed reduction orders): a hand-off race in a kernel would
     # show up here as a handful of differing episodes

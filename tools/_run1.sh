@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3a
-timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "mll or jitter or golden or kernel_type or per_class" > gpurun_out/r3a/pytest_p2h.log 2>&1; tail -4 gpurun_out/r3a/pytest_p2h.log
-DKT_MLL_P2_GUARD=-1 timeout 900 python tools/time_mll_h2.py 3 2>&1 | grep -v amdgpu.ids > gpurun_out/r3a/time_mll_p2h_grow.log; cat gpurun_out/r3a/time_mll_p2h_grow.log
+for i in 1 2; do timeout 600 python bench.py --config cfg1 --no-other-configs --no-cpu-baseline --no-test-time 2>&1 | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print({k: d[k] for k in ('value', 'ms_per_step', 'valid')}, {k: v['ms'] for k, v in d['kernels'].items()})
+"; done
+cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $GRAFT_REPO_ROOT/bench.py --config cfg1 --no-other-configs --no-cpu-baseline --no-test-time > /tmp/p1.log 2>&1; find /tmp/p1 -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-200
