@@ -440,7 +440,8 @@ __global__ __launch_bounds__(64) void h2_primitives_kernel(const float* in, floa
 // (4 chains); 1: all waves v_mfma_f32_16x16x32_f16; 2: waves 0-3 16x16x16 f16, waves 4-7 v_fmac_f32; 3: every wave alternates
 // one 16x16x16 f16 MFMA with 4 v_fmac_f32; 4: every wave alternates one fp32 16x16x4 MFMA with 4 v_fmac_f32; 5: every wave alternates one
 // 16x16x16 f16 MFMA with 4 v_fma_mixlo_f16.  out[wave] = ticks per MFMA (VALU-only waves: per v_fmac).
-__global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters, int role) {
+template <int ROLE>
+__global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters) {
     using namespace dkt_mfma;
     const int wave = threadIdx.x >> 6;
     float a[16];
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters, i
     __syncthreads();
     float per = 16.f;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (role == 0 || (role == 2 && wave < 4)) {
+    if (ROLE == 0 || (ROLE == 2 && wave < 4)) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters, i
                 c3 = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, c3, 0, 0, 0);
             }
         }
-    } else if (role == 1) {
+    } else if (ROLE == 1) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -475,27 +476,23 @@ __global__ __launch_bounds__(512) void h2_ubench_kernel(float* out, int iters, i
                 c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x8, y8, c3, 0, 0, 0);
             }
         }
-    } else if (role == 2) {
+    } else if (ROLE == 2) {
         for (int it = 0; it < iters; ++it) {
 #define DG_X(k) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t));
             DG_REP16(DG_X)
 #undef DG_X
         }
-    } else if (role == 3 || role == 5) {
-        per = 4.f;
-        for (int it = 0; it < iters; ++it) {
-#define DG_M(cc) cc = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, cc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-#define DG_V(k) if (role == 3) asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t)); else asm volatile("v_fma_mixlo_f16 %0, %1, %1, 0" : "+v"(a[k]) : "v"(t)); 
-            DG_M(c0) DG_V(0) DG_V(1) DG_V(2) DG_V(3) __builtin_amdgcn_sched_barrier(0);
-            DG_M(c1) DG_V(4) DG_V(5) DG_V(6) DG_V(7) __builtin_amdgcn_sched_barrier(0);
-            DG_M(c2) DG_V(8) DG_V(9) DG_V(10) DG_V(11) __builtin_amdgcn_sched_barrier(0);
-            DG_M(c3) DG_V(12) DG_V(13) DG_V(14) DG_V(15) __builtin_amdgcn_sched_barrier(0);
-#undef DG_M
-        }
     } else {
+        // one matrix instruction, then four VALU instructions, four times per iteration: per = groups per iteration
         per = 4.f;
         for (int it = 0; it < iters; ++it) {
-#define DG_M(cc) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], cc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define DG_M(cc)                                                                                    \
+    if (ROLE == 4) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], cc, 0, 0, 0);              \
+    else cc = __builtin_amdgcn_mfma_f32_16x16x16f16(x, y, cc, 0, 0, 0);                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define DG_V(k)                                                                                     \
+    if (ROLE == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %1, 0" : "+v"(a[k]) : "v"(t));            \
+    else asm volatile("v_fmac_f32 %0, %0, %1" : "+v"(a[k]) : "v"(t));
             DG_M(c0) DG_V(2) DG_V(3) DG_V(4) DG_V(5) __builtin_amdgcn_sched_barrier(0);
             DG_M(c1) DG_V(6) DG_V(7) DG_V(8) DG_V(9) __builtin_amdgcn_sched_barrier(0);
             DG_M(c2) DG_V(10) DG_V(11) DG_V(12) DG_V(13) __builtin_amdgcn_sched_barrier(0);
@@ -516,6 +513,15 @@ extern "C" int dkt_diag_h2_primitives(const float* in, float* out, float sx, flo
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 extern "C" int dkt_diag_h2_ubench(float* out, int nblocks, int iters, int role, void* stream) {
-    hipLaunchKernelGGL(h2_ubench_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, out, iters, role);
+    const dim3 g(nblocks), b(512);
+    hipStream_t st = (hipStream_t)stream;
+    switch (role) {
+        case 0: hipLaunchKernelGGL(h2_ubench_kernel<0>, g, b, 0, st, out, iters); break;
+        case 1: hipLaunchKernelGGL(h2_ubench_kernel<1>, g, b, 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL(h2_ubench_kernel<2>, g, b, 0, st, out, iters); break;
+        case 3: hipLaunchKernelGGL(h2_ubench_kernel<3>, g, b, 0, st, out, iters); break;
+        case 4: hipLaunchKernelGGL(h2_ubench_kernel<4>, g, b, 0, st, out, iters); break;
+        default: hipLaunchKernelGGL(h2_ubench_kernel<5>, g, b, 0, st, out, iters); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
