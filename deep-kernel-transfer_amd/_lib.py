@@ -44,6 +44,7 @@ SIGNATURES = {
     "dkt_predict_var_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_bn_stats_f32": (_c_i, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_gram_bn_f32": (_c_i, [_c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_gram_bn_train_f32": (_c_i, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_gram_bn_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                    _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),

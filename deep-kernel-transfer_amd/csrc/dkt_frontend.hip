@@ -73,13 +73,26 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if (var_unbiased) *reinterpret_cast<float4*>(var_unbiased + o) = make_float4(vu[0], vu[1], vu[2], vu[3]);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct BnTrainOut {                // train-mode statistics written by the STATS variant of the fused forward (each [B, D])
+    float *mean, *rstd, *a, *s, *var_unbiased;
+    float eps;
+    int has_gamma, has_beta;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Fused forward: one 256-thread workgroup per episode, the structure of gram_sym_ep_split_kernel<NT, 1, 1> (bf16 split).
-template <int NT>
+// STATS (round 3; dkt_gram_bn_train_f32): the train-mode batch statistics are taken INSIDE the staging path -- all N rows of a
+// 32-feature slice pass through the workgroup's registers at once, so the column sums (about row 0: shifted data, as
+// bn_stats_kernel) are reduced over the 32 threads that hold a feature (three lane exchanges + a 1-KB table in LDS that rides on
+// the slab loop's two existing barriers), folded into a = gamma rstd, s = beta - mean a, and applied to the same registers.
+// X is read ONCE; A / S are then gamma / beta [D].
+template <int NT, bool STATS>
 __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_sym_ep_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                                               const float* __restrict__ S, long ab_bstride,
                                                                               float* __restrict__ E, float* __restrict__ rnorm,
-                                                                              int N, int D) {
+                                                                              int N, int D, BnTrainOut bo) {
     constexpr int NP = 16 * NT;
     constexpr int BK = 32;
     constexpr int SPLD = BK + 16;
@@ -90,6 +103,9 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
     constexpr int PLANE = NPL * SPLD;
     __shared__ __attribute__((aligned(16))) __bf16 zp[3 * PLANE];
     __shared__ float rho[NP];
+    __shared__ __attribute__((aligned(16))) float red[STATS ? 4 * V4_PER_ROW * 8 : 4];     // [wave][c4][s1 x 4, s2 x 4]
+    __shared__ __attribute__((aligned(16))) float redx0[STATS ? BK : 4];                   // row 0 of the slice: the shift of the sums
+    __shared__ __attribute__((aligned(16))) float fold_as[STATS ? 4 * 2 * BK : 4];         // [wave][a x 32, s x 32]: wave-private
 
     const int b = blockIdx.x;
     float* Eb = E + (size_t)b * N * N;
@@ -106,13 +122,96 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
         rowok[i] = row < N;
         voff[i] = rowok[i] ? (row * D + 4 * c4) * 4 : OOB;
     }
-    float4 rg[NLD], av, sv;
+    float4 rg[NLD], av, sv, x0;
+    float gsc = 1.0f, bsc = 0.0f;                        // STATS: gamma / beta of feature k0 + lane % 32
+    int kcur = 0;                                        // first feature of the slice held in rg (STATS: where its statistics go)
     auto gload = [&](int k0) {
         const bool in = k0 + 4 * c4 < D;                 // ragged last slice: features past D read as zeros (a = s = 0 too)
-        av = bload4(ar, in ? 16 * c4 : OOB, k0 * 4);
-        sv = bload4(sr, in ? 16 * c4 : OOB, k0 * 4);
+        if constexpr (STATS) {
+            const int f = lane & (BK - 1);
+            const int fo = (k0 + f < D) ? 4 * f : OOB;
+            if (bo.has_gamma) gsc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, fo, k0 * 4, 0));
+            if (bo.has_beta) bsc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, fo, k0 * 4, 0));
+            x0 = bload4(xr, in ? 16 * c4 : OOB, k0 * 4); // row 0 of the thread's features: the shift of the sums
+            kcur = k0;
+        } else {
+            av = bload4(ar, in ? 16 * c4 : OOB, k0 * 4);
+            sv = bload4(sr, in ? 16 * c4 : OOB, k0 * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) rg[i] = bload4(xr, in ? voff[i] : OOB, k0 * 4);
+    };
+    // STATS, step 1 (before the barrier): the thread's partial sums about row 0 (packed fp32 math), reduced over the 8 lanes of the wave
+    // that hold the same features with a reduce-scatter (row_ror:8, then v_permlane32_swap / v_permlane16_swap on PAIRS of values: one
+    // swap + one add halves the number of live values), published per wave
+    auto stats_partial = [&]() {
+        const f32x2 xa = {x0.x, x0.y}, xb = {x0.z, x0.w};
+        f32x2 s1a = {0.f, 0.f}, s1b = s1a, s2a = s1a, s2b = s1a;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            // padded rows were loaded as zeros (e = -x0): multiplied out exactly (a subtract-afterwards correction leaves the rounding
+            // residue of x0^2 per padded row in the sum of squares -- measured 1e-4 relative in the variance at N = 19)
+            const f32x2 mk = {rowok[i] ? 1.0f : 0.0f, rowok[i] ? 1.0f : 0.0f};
+            const f32x2 ea = ((f32x2){rg[i].x, rg[i].y} - xa) * mk, eb = ((f32x2){rg[i].z, rg[i].w} - xb) * mk;
+            s1a += ea;
+            s1b += eb;
+            s2a += ea * ea;
+            s2b += eb * eb;
+        }
+        float v[8] = {s1a.x, s1a.y, s1b.x, s1b.y, s2a.x, s2a.y, s2b.x, s2b.y};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[t]), 0x128, 0xf, 0xf, false));   // lane ^ 8
+        float u[4], w2[2];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {                 // lanes 0..31: v[2 p2] summed over lane ^ 32, lanes 32..63: v[2 p2 + 1]
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * p2]), __float_as_uint(v[2 * p2 + 1]), false, false);
+            u[p2] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {                 // 16-lane rows: [u[2 p2] lower, u[2 p2 + 1] lower, u[2 p2] upper, u[2 p2 + 1] upper] completed
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * p2]), __float_as_uint(u[2 * p2 + 1]), false, false);
+            w2[p2] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        // row r of w2[0] holds v[{0, 2, 1, 3}[r]] (the s1 of feature ...), of w2[1] v[4 + ...] (the s2)
+        if ((lane & 8) == 0) {
+            const int r = lane >> 4, idx = ((r & 1) << 1) | (r >> 1);
+            red[(wave * V4_PER_ROW + c4) * 8 + idx] = w2[0];
+            red[(wave * V4_PER_ROW + c4) * 8 + 4 + idx] = w2[1];
+        }
+        if (tid < V4_PER_ROW) *reinterpret_cast<float4*>(&redx0[4 * c4]) = x0;
+    };
+    // STATS, step 2 (after the barrier): lane f % 32 of every wave folds feature f of the slice (the four waves do the same work: no
+    // second barrier), the a / s of the slice go through a wave-private table back to the threads that stage those features
+    auto stats_fold = [&]() {
+        const int f = lane & (BK - 1), fc = f >> 2, ft = f & 3;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s1 += red[(w * V4_PER_ROW + fc) * 8 + ft];
+            s2 += red[(w * V4_PER_ROW + fc) * 8 + 4 + ft];
+        }
+        const float inv_n = 1.0f / (float)N;
+        const float m1 = s1 * inv_n;
+        const float var = fmaxf(__builtin_fmaf(-m1, m1, s2 * inv_n), 0.f);      // biased variance (normalisation)
+        const float mu = redx0[f] + m1;
+        const float ve = var + bo.eps;
+        float rs = __builtin_amdgcn_rsqf(ve);
+        rs = rs * __builtin_fmaf(-0.5f * ve * rs, rs, 1.5f);                     // one Newton step: v_rsq_f32 is ~1 ulp
+        const float aa = gsc * rs;
+        const float ss = __builtin_fmaf(-mu, aa, bsc);
+        float* tab = &fold_as[wave * 2 * BK];
+        tab[f] = aa;
+        tab[BK + f] = ss;
+        if (wave == 0 && lane < BK && kcur + f < D) {
+            const size_t o = (size_t)b * D + kcur + f;
+            bo.mean[o] = mu;
+            bo.rstd[o] = rs;
+            bo.a[o] = aa;
+            bo.s[o] = ss;
+            if (bo.var_unbiased) bo.var_unbiased[o] = (N > 1) ? var * (float)N / (float)(N - 1) : var;      // what torch feeds the running variance
+        }
+        av = *reinterpret_cast<const float4*>(&tab[4 * c4]);
+        sv = *reinterpret_cast<const float4*>(&tab[BK + 4 * c4]);
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -137,6 +236,11 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
     for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (D + BK - 1) / BK;
     gload(0);
+    if constexpr (STATS) {
+        stats_partial();
+        __syncthreads();
+        stats_fold();
+    }
     lstore();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -150,8 +254,14 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
         } else {
             if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, SPLD, PLANE>(acc, zp, r16, q);
         }
+        if constexpr (STATS) {
+            if (kt + 1 < nk) stats_partial();            // the table was last read before the previous barrier
+        }
         __syncthreads();
-        if (kt + 1 < nk) lstore();
+        if (kt + 1 < nk) {
+            if constexpr (STATS) stats_fold();
+            lstore();
+        }
         __syncthreads();
     }
 
@@ -471,8 +581,25 @@ void launch_gram_bn_bwd(const float* W, const float* E, const float* X, const fl
 }
 
 template <int NT>
-void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st) {
-    hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D);
+void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
+                    const BnTrainOut* bo) {
+    if (bo) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo);
+    else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{});
+}
+
+int gram_bn_dispatch(const float* X, const float* a, const float* s, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
+                     const BnTrainOut* bo) {
+    switch ((N + 15) / 16) {
+        case 1: launch_gram_bn<1>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 2: launch_gram_bn<2>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 3: launch_gram_bn<3>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 4: launch_gram_bn<4>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 5: launch_gram_bn<5>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 6: launch_gram_bn<6>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        case 7: launch_gram_bn<7>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+        default: launch_gram_bn<8>(X, a, s, abs, E, rnorm, B, N, D, st, bo); break;
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -492,18 +619,20 @@ extern "C" int dkt_gram_bn_f32(const float* X, const float* a, const float* s, l
     if (!X || !a || !s || !E || !rnorm || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
     if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || (ab_bstride & 3)) return DKT_ERR_BAD_ARG;
     if (N > 128) return DKT_ERR_TOO_LARGE;
-    hipStream_t st = (hipStream_t)stream;
-    switch ((N + 15) / 16) {
-        case 1: launch_gram_bn<1>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 2: launch_gram_bn<2>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 3: launch_gram_bn<3>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 4: launch_gram_bn<4>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 5: launch_gram_bn<5>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 6: launch_gram_bn<6>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        case 7: launch_gram_bn<7>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-        default: launch_gram_bn<8>(X, a, s, ab_bstride, E, rnorm, B, N, D, st); break;
-    }
-    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    return gram_bn_dispatch(X, a, s, ab_bstride, E, rnorm, B, N, D, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int dkt_gram_bn_train_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                     float* a, float* s, float* var_unbiased, float* E, float* rnorm, int B, int N, int D, void* stream) {
+    if (!X || !mean || !rstd || !a || !s || !E || !rnorm || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
+    if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return DKT_ERR_BAD_ARG;
+    if (((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || ((uintptr_t)var_unbiased & 15)) return DKT_ERR_BAD_ARG;
+    if (N > 128) return DKT_ERR_TOO_LARGE;
+    BnTrainOut bo;
+    bo.mean = mean; bo.rstd = rstd; bo.a = a; bo.s = s; bo.var_unbiased = var_unbiased;
+    bo.eps = eps; bo.has_gamma = gamma != nullptr; bo.has_beta = beta != nullptr;
+    // absent gamma / beta: any valid pointer keeps the descriptor legal, the values are ignored (has_* = 0)
+    return gram_bn_dispatch(X, gamma ? gamma : X, beta ? beta : X, 0, E, rnorm, B, N, D, (hipStream_t)stream, &bo);
 }
 
 extern "C" int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const float* a, const float* s, long ab_bstride,

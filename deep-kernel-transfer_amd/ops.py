@@ -586,6 +586,26 @@ def gram_bn(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
     return e, rnorm
 
 
+def gram_bn_train(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5):
+    """bn_stats + gram_bn in one pass over x (train-mode BatchNorm1d statistics taken inside the Gram kernel's staging path).
+    Returns (E [B,N,N], rnorm [B,N], stats dict as bn_stats)."""
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    if n > 128 or d % 4:
+        raise RuntimeError("gram_bn_train: needs N <= 128 and D %% 4 == 0 (got N=%d, D=%d)" % (n, d))
+    gamma = None if gamma is None else _req(gamma.reshape(-1), "gamma", 1)
+    beta = None if beta is None else _req(beta.reshape(-1), "beta", 1)
+    out = {k: torch.empty((b_, d), device=x.device, dtype=torch.float32) for k in ("mean", "rstd", "a", "s", "var_unbiased")}
+    e = torch.empty((b_, n, n), device=x.device, dtype=torch.float32)
+    rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_gram_bn_train_f32"):
+        st = lib.dkt_gram_bn_train_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(out["mean"]), _p(out["rstd"]), _p(out["a"]),
+                                       _p(out["s"]), _p(out["var_unbiased"]), _p(e), _p(rnorm), b_, n, d, _stream())
+    _lib.check(st, "dkt_gram_bn_train_f32")
+    return e, rnorm, out
+
+
 def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
     """Backward of gram_bn (+ train-mode batch statistics when mean/rstd are given): returns (dX, dgamma_part, dbeta_part);
     the last two are [B,D] per-episode parts (None in eval mode)."""
@@ -616,20 +636,24 @@ def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
 
 class _EpisodeLossBnFn(torch.autograd.Function):
     """Training episode straight from the trunk output X: [BatchNorm1d(train) +] F.normalize + linear Gram
-    (dkt_bn_stats_f32, dkt_gram_bn_f32) -> MLL (dkt_mll_f32) ; backward dkt_gram_bn_bwd_f32.  The normalised features are
+    (dkt_gram_bn_train_f32; DKT_FUSED_STATS=0: dkt_bn_stats_f32 + dkt_gram_bn_f32) -> MLL (dkt_mll_f32) ; backward dkt_gram_bn_bwd_f32.  The normalised features are
     never written to memory.  use_bn=False is the plain cossim kernel (no bn_out: affine map = identity)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries):
         b_, n, d = x.shape
-        if use_bn:
-            st = bn_stats(x, gamma, beta, eps)
+        if use_bn and os.environ.get("DKT_FUSED_STATS", "1") != "0":
+            e, rnorm, st = gram_bn_train(x, gamma, beta, eps)               # statistics + Gram in one pass over x
             a, s, bmean, rstd, bvar = st["a"], st["s"], st["mean"], st["rstd"], st["var_unbiased"]
         else:
-            a = torch.ones(d, device=x.device, dtype=torch.float32)
-            s = torch.zeros(d, device=x.device, dtype=torch.float32)
-            bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
-        e, rnorm = gram_bn(x, a, s)
+            if use_bn:
+                st = bn_stats(x, gamma, beta, eps)
+                a, s, bmean, rstd, bvar = st["a"], st["s"], st["mean"], st["rstd"], st["var_unbiased"]
+            else:
+                a = torch.ones(d, device=x.device, dtype=torch.float32)
+                s = torch.zeros(d, device=x.device, dtype=torch.float32)
+                bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
+            e, rnorm = gram_bn(x, a, s)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
         obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
         ctx.use_bn = bool(use_bn)

@@ -184,6 +184,16 @@ int dkt_gram_bn_f32(const float* X, const float* a, const float* s, long ab_bstr
                     int B, int N, int D, void* stream);
 
 /*
+ * dkt_gram_bn_train_f32 -- dkt_bn_stats_f32 + dkt_gram_bn_f32 in ONE pass over X (round 3): the train-mode batch statistics of a
+ *   32-feature slice are taken while all N rows of the slice sit in the workgroup's registers on their way into LDS, folded into
+ *   a / s and applied to the same registers.  Outputs as dkt_bn_stats_f32 (mean, rstd, a, s, var_unbiased: each [B,D];
+ *   var_unbiased may be NULL) and dkt_gram_bn_f32 (E, rnorm).  gamma / beta: [D] or NULL (1 / 0).  N <= 128, D % 4 == 0.
+ *   Replaces bn_out in train mode + F.normalize + LinearKernel (methods/DKT.py:48, 141-142, 375-378) of a training episode.
+ */
+int dkt_gram_bn_train_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                          float* a, float* s, float* var_unbiased, float* E, float* rnorm, int B, int N, int D, void* stream);
+
+/*
  * dkt_gram_bn_bwd_f32 -- backward of dkt_gram_bn_f32 (+ the batch-statistics dependence of train-mode BatchNorm1d):
  *   given W[b] = d obj / d E[b] and the per-episode upstream scale ep_scale[b] (NULL: 1), returns
  *   dX[B,N,D] = d obj / d X and, when mean/rstd are given (train mode), the per-episode parts

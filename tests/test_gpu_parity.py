@@ -1296,6 +1296,45 @@ def test_bn_stats_and_fused_gram_train_mode(cuda, b, n, d):
     assert torch.equal(e, e.transpose(1, 2))
 
 
+@pytest.mark.parametrize("affine", [True, False])
+@pytest.mark.parametrize("b,n,d", [(2, 5, 12), (3, 25, 64), (2, 85, 512), (2, 105, 1600), (1, 128, 100), (2, 19, 2916), (5, 1, 36), (2, 33, 8)])
+def test_one_pass_statistics_and_gram_train_mode(cuda, b, n, d, affine):
+    """dkt_gram_bn_train_f32: the batch statistics taken inside the Gram kernel's staging path (X read once) against the float64 oracle of
+    bn_out(train) -> F.normalize -> Gram, and against the two-launch route it replaces (dkt_bn_stats_f32 + dkt_gram_bn_f32)."""
+    rng = np.random.default_rng(n * 37 + d)
+    x = _relu_like(rng, b, n, d)
+    gamma = rng.uniform(0.5, 1.5, d).astype(np.float32) if affine else None
+    beta = rng.normal(0.0, 0.2, d).astype(np.float32) if affine else None
+    gd = None if gamma is None else dev_t(gamma, cuda)
+    bd = None if beta is None else dev_t(beta, cuda)
+    e, rnorm, st = ops.gram_bn_train(dev_t(x, cuda), gd, bd, 1e-5)
+    st2 = ops.bn_stats(dev_t(x, cuda), gd, bd, 1e-5)
+    e2, rnorm2 = ops.gram_bn(dev_t(x, cuda), st2["a"], st2["s"])
+    g64 = np.ones(d) if gamma is None else gamma.astype(np.float64)
+    b64 = np.zeros(d) if beta is None else beta.astype(np.float64)
+    for i in range(b):
+        y, mu, var_u = O.batchnorm1d_train(x[i].astype(np.float64), g64, b64)
+        assert np.abs(st["mean"][i].cpu().numpy() - mu).max() < 1e-5 * (1.0 + np.abs(mu).max())
+        if n > 1:
+            assert rel_l2(st["var_unbiased"][i].cpu().numpy(), var_u) < 2e-5
+        a64 = g64 / np.sqrt(x[i].astype(np.float64).var(0) + 1e-5)
+        assert rel_l2(st["a"][i].cpu().numpy(), a64) < 2e-5
+        assert rel_l2(st["rstd"][i].cpu().numpy(), 1.0 / np.sqrt(x[i].astype(np.float64).var(0) + 1e-5)) < 2e-5
+        assert np.abs(st["s"][i].cpu().numpy() - (b64 - mu * a64)).max() < 2e-5 * (1.0 + np.abs(mu * a64).max())
+        if n > 1:                                      # a batch of one: y = beta exactly, its direction is rounding noise unless beta != 0
+            zn = O.l2_normalize(y)
+            ref = zn @ zn.T
+            assert np.abs(e[i].cpu().numpy() - ref).max() < 2e-5, np.abs(e[i].cpu().numpy() - ref).max()
+            assert rel_l2(rnorm[i].cpu().numpy(), 1.0 / np.linalg.norm(y, axis=1)) < 2e-5
+    assert torch.equal(e, e.transpose(1, 2))
+    if n > 1:
+        assert (e - e2).abs().max().item() < 2e-5 and rel_l2(rnorm.cpu().numpy(), rnorm2.cpu().numpy()) < 2e-5
+    for k in ("mean", "rstd", "a", "s", "var_unbiased"):
+        assert rel_l2(st[k].cpu().numpy(), st2[k].cpu().numpy()) < 1e-5, k
+    e3, _, st3 = ops.gram_bn_train(dev_t(x, cuda), gd, bd, 1e-5)          # fixed reduction order: bitwise reproducible
+    assert torch.equal(e, e3) and torch.equal(st["a"], st3["a"])
+
+
 @pytest.mark.parametrize("b,n,d", [(3, 25, 64), (2, 105, 1600), (2, 75, 512)])
 def test_fused_gram_eval_mode_and_plain_cossim(cuda, b, n, d):
     rng = np.random.default_rng(n + d)
