@@ -321,12 +321,21 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
 //   dY_i = rho_i (dZn_i - zn_i t_i),  t_i = zn_i . dZn_i = sum_j A_ij E_ij      (F.normalize backward; t needs no D-loop)
 //   dbeta_d = sum_i dY_id,  dgamma_d = sum_i dY_id xh_id,  xh = (x - mean) rstd  (BatchNorm1d backward, batch statistics)
 //   dX_id = a_d (dY_id - dbeta_d / N - xh_id dgamma_d / N)
-// Structure of gram_bwd_ep_bf16x3_kernel<NT, 1, 1>: NT waves, wave w owns output rows [16w, 16w+16), its A fragments
+// Structure of gram_bwd_ep_f16x2_kernel<NT, 1, 1> (round 3; bf16 x 3 before): the rows of Zn are unit-norm BY CONSTRUCTION here --
+// rho comes from the forward -- so the staged operand takes the scaled 2-way f16 split (2^15, two planes, 3 MFMAs per product), and the A
+// operand g (W + W^T) the per-row power-of-two scale of that kernel.  NT waves, wave w owns output rows [16w, 16w+16), its A fragments
 // stay in registers; per 64-feature slab the MFMA result dZn is finished IN REGISTERS: the column sums over the N rows
 // are reduced over the 4 row groups of a wave with shuffles and over the waves through a small LDS table that rides on
-// the slab loop's two existing barriers.  X is read once for staging and once (L2-hot) for the epilogue; dX is written once.
+// the slab loop's barrier (image and table are double-buffered: ONE barrier per slab).  X is read once for staging and once (L2-hot) for
+// the epilogue; dX is written once.
+// Register budget: ~190 VGPRs = ONE workgroup of 7 waves per CU at N = 105.  Measured in round 3 (profiles/r03/v2_frontend_bwd_variants.log): forcing
+// 128 VGPRs for two workgroups per CU spills 51 registers and is 1.7 x slower; moving the epilogue's operand loads behind the MFMA loop to save
+// registers costs more than it gains at one workgroup per CU.
+#ifndef DKT_FE_BWD_WPE
+#define DKT_FE_BWD_WPE 2
+#endif
 template <int NT, bool TRAIN_BN>
-__global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float* __restrict__ W, const float* __restrict__ Eg,
+__global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel(const float* __restrict__ W, const float* __restrict__ Eg,
                                                                     const float* __restrict__ X, const float* __restrict__ Aa,
                                                                     const float* __restrict__ Ss, long ab_bstride,
                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -341,12 +350,12 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
     constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);
     constexpr int RS = 8 * SU;
     constexpr int PLANE = BD * RS;
-    constexpr int IMG = 3 * PLANE * 2;                   // bytes of the [d][j] image
-    constexpr int STG = (IMG > NP * NP * 4) ? IMG : NP * NP * 4;     // the image region also stages W, then E (N x N fp32)
+    constexpr int IMG = 2 * PLANE * 2;                   // bytes of the [d][j] image (two f16 planes)
+    constexpr int STG = (2 * IMG > NP * NP * 4) ? 2 * IMG : NP * NP * 4;     // two image buffers; the region also stages W, then E (N x N fp32)
     __shared__ __attribute__((aligned(16))) unsigned char smem[STG];
-    __shared__ float rl[NP], tl[NP];
-    __shared__ __attribute__((aligned(16))) float cs[NT][BD][2];
-    __bf16* zt = reinterpret_cast<__bf16*>(smem);
+    __shared__ __attribute__((aligned(16))) float rl[NP], tl[NP], rowinv[NP];
+    __shared__ __attribute__((aligned(16))) float cs[2][NT][BD][2];          // double-buffered like the image: ONE barrier per slab
+    _Float16* zt = reinterpret_cast<_Float16*>(smem);
     float* wl = reinterpret_cast<float*>(smem);
 
     const int b = blockIdx.x;
@@ -378,25 +387,41 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
     gload(0);                                            // flies while W and E are staged
 
     // ---- A fragments from W (as in gram_bwd_ep_bf16x3_kernel), then t_i = sum_k A_ik E_ik with E staged the same way ----
-    bf16x8 ah[KS], am[KS], al[KS];
+    f16x8 ah[KS], am[KS];
     const int nn = N * N;
     const int row = wave * 16 + r16;
+    float rsinv;                                         // 1 / (row scale of A)
     {
         const float* Wb = W + (size_t)b * nn;
         for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
         __syncthreads();
+        float v[KS][8];
+        float rmax = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = 32 * ks + 8 * q + e;
-                float v = 0.f;
-                if (row < N && k < N) v = g * (wl[row * N + k] + wl[k * N + row]);
-                __bf16 h, m, l;
-                split3s(v, h, m, l);
-                ah[ks][e] = h;
-                am[ks][e] = m;
-                al[ks][e] = l;
+                v[ks][e] = (row < N && k < N) ? g * (wl[row * N + k] + wl[k * N + row]) : 0.f;
+                rmax = fmaxf(rmax, fabsf(v[ks][e]));
+            }
+        }
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 16, DKT_WAVE));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, DKT_WAVE));
+        // power-of-two row scale: row maximum -> [2^14, 2^15); clamped so that its inverse (times 2^-15) stays normal
+        const int eb = (int)((__float_as_uint(rmax) >> 23) & 0xffu);
+        const int sexp = min(268 - eb, 237);
+        const float rscale = __uint_as_float((unsigned)sexp << 23);
+        rsinv = __uint_as_float((unsigned)(254 - sexp) << 23);
+        if (q == 0) rowinv[row] = __uint_as_float((unsigned)(254 - sexp - 15) << 23);      // undoes the row scale and the 2^15 of Zn
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = v[ks][e] * rscale;
+                const _Float16 hi = (_Float16)xs;
+                ah[ks][e] = hi;
+                am[ks][e] = (_Float16)(xs - (float)hi);
             }
         }
         __syncthreads();
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = 32 * ks + 8 * q + e;
-                const float aik = (float)ah[ks][e] + (float)am[ks][e] + (float)al[ks][e];      // the split is exact
+                const float aik = ((float)ah[ks][e] + (float)am[ks][e]) * rsinv;                // the A the MFMAs see (22 bits)
                 if (row < N && k < N) tp = __builtin_fmaf(aik, wl[row * N + k], tp);
             }
         }
@@ -419,54 +444,42 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
         if (q == 0) tl[row] = tp;
         __syncthreads();
     }
-    // this lane's output rows i = 16 wave + 4 q + reg: rho_i, t_i stay in registers for the whole episode
-    float rho4[4], t4[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        rho4[reg] = rl[16 * wave + 4 * q + reg];
-        t4[reg] = tl[16 * wave + 4 * q + reg];
-    }
-    // rho_j of the staging task's rows
-    float rhoj[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) rhoj[rr] = rl[4 * jg + rr];
+    // this lane's output rows i = 16 wave + 4 q + reg: rho_i, t_i, the un-scaling of the row stay in registers for the whole episode
+    const f32x4 rho4 = *reinterpret_cast<const f32x4*>(&rl[16 * wave + 4 * q]);
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(&tl[16 * wave + 4 * q]);
+    const f32x4 un4 = *reinterpret_cast<const f32x4*>(&rowinv[16 * wave + 4 * q]);
+    const f32x4 rhoj = *reinterpret_cast<const f32x4*>(&rl[4 * jg]);      // rho_j of the staging task's rows
     __syncthreads();                                     // everyone is done with the staged E before the image is written
     if constexpr (KP > NP) {                             // columns j in [NP, KP) of the image are never staged: zero them once
         constexpr int PADV = (KP - NP) / 8;
-        for (int i = tid; i < 3 * BD * PADV; i += NTH) {
+        for (int i = tid; i < 2 * 2 * BD * PADV; i += NTH) {     // both buffers, both planes
             const int rowi = i / PADV, pc = i % PADV;
             *reinterpret_cast<float4*>(zt + (size_t)rowi * RS + NP + 8 * pc) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 
-    auto lstore = [&]() {                                // zn = (a x + s) rho_j, split, transposed 8-byte stores
+    auto lstore = [&](const int buf) {                   // zn = (a x + s) rho_j (|zn| <= 1), scaled 2-way f16 split, transposed 8-byte stores
         const float av[4] = {sa.x, sa.y, sa.z, sa.w}, sv[4] = {ss.x, ss.y, ss.z, ss.w};
         const float x[4][4] = {{rg[0].x, rg[1].x, rg[2].x, rg[3].x}, {rg[0].y, rg[1].y, rg[2].y, rg[3].y},
                                {rg[0].z, rg[1].z, rg[2].z, rg[3].z}, {rg[0].w, rg[1].w, rg[2].w, rg[3].w}};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            bf16x4 h, m, l;
+            float zn[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const float zn = __builtin_fmaf(av[t], x[t][rr], sv[t]) * rhoj[rr];
-                __bf16 hh, mm, ll;
-                split3s(zn, hh, mm, ll);
-                h[rr] = hh;
-                m[rr] = mm;
-                l[rr] = ll;
-            }
-            __bf16* dst = zt + (16 * t + d4) * RS + 4 * jg;
-            *reinterpret_cast<bf16x4*>(dst) = h;
-            *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
-            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+            for (int rr = 0; rr < 4; ++rr) zn[rr] = __builtin_fmaf(av[t], x[t][rr], sv[t]) * rhoj[rr];
+            f16x4 h, m;
+            split2h(make_float4(zn[0], zn[1], zn[2], zn[3]), DKT_F16_SCALE, h, m);
+            _Float16* dst = zt + buf * 2 * PLANE + (16 * t + d4) * RS + 4 * jg;
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + PLANE) = m;
         }
     };
 
     __syncthreads();                                     // pad columns zeroed
-    lstore();
+    lstore(0);
     __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
-        const int d0 = sl * BD;
+        const int d0 = sl * BD, buf = sl & 1;
         if (sl + 1 < nslab) gload(d0 + BD);
         // epilogue operands of this lane's 4 rows x 4 features (d = d0 + 4 r16 + t): issued early, consumed after the MFMAs
         const bool din = d0 + 4 * r16 < D;
@@ -485,21 +498,17 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const __bf16* base = zt + r16 * RS + 8 * q;
+        const _Float16* base = zt + buf * 2 * PLANE + r16 * RS + 8 * q;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const __bf16* p = base + 16 * t * RS + 32 * ks;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(p);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(p + PLANE);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(p + 2 * PLANE);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bm, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bm, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ks], bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[t], 0, 0, 0);
+                const _Float16* p = base + 16 * t * RS + 32 * ks;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(p);
+                const f16x8 bm = *reinterpret_cast<const f16x8*>(p + PLANE);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[t], 0, 0, 0);
             }
         }
         // dY (overwrites acc) and the normalised inputs xh (kept for the second half)
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float zn = __builtin_fmaf(eav[t], xv[t], esv[t]) * rho4[reg];
-                const float dy = rho4[reg] * __builtin_fmaf(-zn, t4[reg], acc[t][reg]);
+                const float dy = rho4[reg] * __builtin_fmaf(-zn, t4[reg], acc[t][reg] * un4[reg]);
                 acc[t][reg] = dy;
                 if constexpr (TRAIN_BN) {
                     xh[t][reg] = (xv[t] - emv[t]) * erv[t];
@@ -533,21 +542,21 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
             if (q == 0) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    cs[wave][4 * r16 + t][0] = c1[t];
-                    cs[wave][4 * r16 + t][1] = c2[t];
+                    cs[buf][wave][4 * r16 + t][0] = c1[t];
+                    cs[buf][wave][4 * r16 + t][1] = c2[t];
                 }
             }
         }
-        __syncthreads();                                 // image consumed; column partials of every wave published
-        if (sl + 1 < nslab) lstore();
+        if (sl + 1 < nslab) lstore(buf ^ 1);             // the other image buffer: last read before the previous barrier
+        __syncthreads();                                 // next image staged; column partials of every wave published
         float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (TRAIN_BN) {
 #pragma unroll
             for (int w = 0; w < NT; ++w) {               // fixed order over the waves: deterministic
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    m1[t] += cs[w][4 * r16 + t][0];
-                    m2[t] += cs[w][4 * r16 + t][1];
+                    m1[t] += cs[buf][w][4 * r16 + t][0];
+                    m2[t] += cs[buf][w][4 * r16 + t][1];
                 }
             }
             if (wave == 0 && q == 0 && din) {
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bn_bwd_ep_kernel(const float*
             }
             if (i < N && din) *reinterpret_cast<float4*>(dXb + (size_t)i * D + d0 + 4 * r16) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        __syncthreads();                                 // next image staged; cs free again
+        // no second barrier: cs[buf] and image[buf] are written again two slabs on, i.e. behind the next slab's barrier
     }
 }
 

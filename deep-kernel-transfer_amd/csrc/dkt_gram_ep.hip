@@ -134,7 +134,6 @@ __global__ __launch_bounds__(256) void gram_sym_ep_kernel(const float* __restric
 // F.normalize); an element beyond 1.999 overflows f16 and poisons the episode with inf / NaN (loud, not silent).
 // The MFMA flushes f16 subnormals: the low piece of an element below 2^-18 (and all of one below 2^-29) is dropped, an
 // absolute error of at most 2^-30 |b| per product -- far below the fp32 resolution of a cosine similarity.
-#define DKT_F16_SCALE 32768.f
 #define DKT_F16_UNSCALE (1.f / (32768.f * 32768.f))
 template <int NT, int NBUF, int PF, int BK = 32, int SPL = 3, int MINWG = ((NBUF == 1 && NT <= 7 && BK == 32) ? (PF == 1 ? 4 : 3) : 2), int POL = 0>
 __global__ __launch_bounds__(256, MINWG) void gram_sym_ep_split_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {

@@ -39,6 +39,9 @@ __device__ __forceinline__ void split3s(float x, __bf16& h, __bf16& m, __bf16& l
 // HALF the MFMAs, two thirds of the LDS traffic and 12 instead of 22 VALU instructions per float4 of the 3-way bf16 split.
 // The scale keeps m out of the f16 subnormal range (which the MFMA flushes) for every element that matters and is undone
 // exactly in the epilogue.
+#ifndef DKT_F16_SCALE
+#define DKT_F16_SCALE 32768.f          // 2^15: unit-norm operands use the f16 exponent range up to just below its maximum
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
