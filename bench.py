@@ -226,6 +226,61 @@ def _workload(cfg, b, dev, rank, unit_rows):
                       n_backbone=n_backbone, kernel="bncossim")
 
 
+def _aux_paths(dev, b=2048, steps=5):
+    """The two other entries into the same hot path, at the headline shape (cfg2: N = 105, D = 1600, C = 5), driver-timed next to it:
+    `from_trunk_features` = what DKT.train_loop runs for bncossim (bn_out in train mode + F.normalize folded into the Gram kernels:
+    dkt_gram_bn_train_f32 -> dkt_mll_f32 -> dkt_gram_bn_bwd_f32), `rbf_per_class_lengthscales` = the non-linear kernels (dkt_gram_f32 SQDIST ->
+    dkt_class_kernel_f32 -> dkt_mll_f32 with DKT_MLL_E_PER_CLASS -> dkt_class_kernel_bwd_f32 -> dkt_gram_bwd_f32)."""
+    from dkt_amd import ops
+    c, s, q, d = CONFIGS["cfg2"][:4]
+    n = c * (s + q)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    x = (torch.randn(b, n, d, generator=g, device=dev).abs() + 1.0).requires_grad_(True)        # ReLU-like trunk output, common offset
+    gamma = torch.ones(d, device=dev, requires_grad=True)
+    beta = torch.zeros(d, device=dev, requires_grad=True)
+    raw_s, mean = perturbed_hypers(c, 99, dev)
+    raw_s.requires_grad_(True)
+    mean.requires_grad_(True)
+    ls = torch.linspace(25.0, 40.0, c, device=dev).requires_grad_(True)                         # ~ the distance scale of these features
+    noise = torch.full((c,), 0.1, device=dev)
+    cls = torch.arange(c, device=dev).repeat_interleave(s + q)
+    y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
+    cw = torch.full((c,), -1.0 / (c * n), device=dev)
+    leaves = (x, gamma, beta, raw_s, mean, ls)
+
+    def trunk():
+        for t in leaves:
+            t.grad = None
+        outs = ops.episode_loss_bn(x, gamma, beta, y, torch.nn.functional.softplus(raw_s), mean, noise, cw)
+        outs[0].mean().backward()
+        return outs[3]
+
+    def rbf():
+        for t in leaves:
+            t.grad = None
+        outs = ops.episode_loss_class_kernel(x, y, torch.nn.functional.softplus(raw_s), mean, noise, cw, "rbf", ls)
+        outs[0].mean().backward()
+        return outs[3]
+
+    res = {}
+    for name, fn in (("from_trunk_features", trunk), ("rbf_per_class_lengthscales", rbf)):
+        for _ in range(2):
+            info = fn()
+        torch.cuda.synchronize()
+        ops.kernel_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            info = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
+        ops.kernel_timing(False)
+        res[name] = {"value": round(b / dt, 1), "unit": "episodes/s", "episodes_per_step": b, "ms_per_step": round(1e3 * dt, 4),
+                     "valid": bool(int(info.abs().max().item()) == 0 and x.grad is not None and bool(torch.isfinite(x.grad).all().item())),
+                     "kernels_ms": kt}
+    return res
+
+
 def _algorithmic(cfg, n, d, c, unit_rows):
     """Algorithmic bytes / flops per EPISODE, per ABI kernel of the step; `exec_f16`: the f16 MFMA flops the split Gram
     kernels actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split)."""
@@ -459,6 +514,8 @@ def run(args):
                            "kernels": ko, "roofline_by_kernel": ro}
         out["other_configs"] = others
         del m
+        torch.cuda.empty_cache()
+        out["other_paths_cfg2"] = _aux_paths(dev)
         torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_test_time and args.config != "cfg0":

@@ -1,0 +1,159 @@
+// dkt_classkernel.hip -- the per-class element-wise maps of the non-linear base kernels and their chain rule.
+//
+// Reference: every class model of the one-vs-rest list owns its base kernel (one ExactGPLayer per class, methods/DKT.py:63-66,
+// 352-365): RBFKernel / MaternKernel(nu = 2.5) with its own lengthscale, PolynomialKernel(power 1 / 2) with its own offset.  All C
+// kernels are functions of ONE contraction per episode -- the squared distances |z_i - z_j|^2 or the Gram z_i . z_j
+// (dkt_gram_f32) -- so the episode pays for one O(N^2 D) pass and
+//   dkt_class_kernel_f32      base[B, NN] -> E[B, C, NN] = f(base; param_c)                     (replaces C kernel evaluations)
+//   dkt_class_kernel_bwd_f32  W[B, C, N, N] = d obj / d E  ->  Wp[B, N, N] ready for dkt_gram_bwd_f32 (dZ = (Wp + Wp^T) Z)
+//                             and d obj / d param [B, C]                                       (replaces autograd through them)
+// run in front of / behind the ONE marginal-likelihood launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS).
+// Memory-bound element-wise work: coalesced dword accesses, base read once per element for all classes.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "dkt_common.h"
+#include "../../include/dkt_abi.h"
+
+namespace {
+
+// f and f' = d f / d t of the class map at t = the map's own argument:
+//   RBF       t = u = d2 / l^2            f = exp(-u / 2)                         f' = -f / 2
+//   MATERN25  t = u = d2 / l^2, r = sqrt(5 max(u, 1e-30))   f = (1 + r + r^2 / 3) exp(-r)      f' = -(5 / 6)(1 + r) exp(-r)
+//   POLY      t = g + offset              f = t^p (p = 1, 2)                      f' = p t^(p - 1)
+template <int KIND>
+__device__ __forceinline__ void class_map(const float t, const int power, float& f, float& df) {
+    if constexpr (KIND == DKT_CLASSMAP_RBF) {
+        f = expf(-0.5f * t);
+        df = -0.5f * f;
+    } else if constexpr (KIND == DKT_CLASSMAP_MATERN25) {
+        const float r = sqrtf(5.0f * fmaxf(t, 1e-30f));          // gpytorch clamps d2 >= 1e-30 before the sqrt
+        const float er = expf(-r);
+        f = (1.0f + r + r * r * (1.0f / 3.0f)) * er;
+        df = -(5.0f / 6.0f) * (1.0f + r) * er;
+    } else {
+        f = (power == 2) ? t * t : t;
+        df = (power == 2) ? 2.0f * t : 1.0f;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void class_kernel_fwd(const float* __restrict__ base, const float* __restrict__ param, int power,
+                                                        float* __restrict__ E, int C, int NN) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= NN) return;
+    const float v = base[(size_t)b * NN + k];
+    float* Eb = E + (size_t)b * C * NN + k;
+    for (int c = 0; c < C; ++c) {
+        const float p = param[c];
+        float t;
+        if constexpr (KIND == DKT_CLASSMAP_POLY) t = v + p;
+        else t = v / (p * p);
+        float f, df;
+        class_map<KIND>(t, power, f, df);
+        Eb[(size_t)c * NN] = f;
+    }
+}
+
+// One workgroup (8 waves) per episode; wave w owns the rows i = w, w + 8, ...; lanes stride over the columns.  Per element: base once, W of every
+// class once (coalesced per class).  The row sums of A (distance kinds) are wave reductions; the per-class parameter gradients are
+// accumulated per thread in LDS ([C][512], no conflicts: a thread owns its slot) and reduced in a fixed order at the end.
+constexpr int CKB_T = 512;
+
+template <int KIND>
+__global__ __launch_bounds__(CKB_T) void class_kernel_bwd(const float* __restrict__ W, const float* __restrict__ base,
+                                                        const float* __restrict__ param, int power, float* __restrict__ Wp,
+                                                        float* __restrict__ dparam, int C, int N) {
+    extern __shared__ float dyn[];                       // [C][CKB_T] parameter-gradient partials, then [C][8] wave sums
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t nn = (size_t)N * N;
+    const float* Wb = W + (size_t)b * C * nn;
+    const float* Bb = base + (size_t)b * nn;
+    float* Wpb = Wp + (size_t)b * nn;
+    for (int c = 0; c < C; ++c) dyn[c * CKB_T + tid] = 0.f;
+    for (int i = wave; i < N; i += CKB_T / 64) {
+        float rowsum = 0.f, adiag = 0.f;
+#pragma unroll 2
+        for (int j = lane; j < N; j += 64) {
+            const float v = Bb[(size_t)i * N + j];
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float p = param[c];
+                const float w = Wb[(size_t)c * nn + (size_t)i * N + j];
+                float f, df;
+                if constexpr (KIND == DKT_CLASSMAP_POLY) {
+                    class_map<KIND>(v + p, power, f, df);
+                    const float g = w * df;
+                    a += g;                                              // d obj / d g_ij
+                    dyn[c * CKB_T + tid] += g;                           // d obj / d offset_c
+                } else {
+                    const float il2 = 1.0f / (p * p);
+                    const float u = v * il2;
+                    class_map<KIND>(u, power, f, df);
+                    const float g = w * df;                              // d obj / d u_c,ij
+                    a = __builtin_fmaf(2.0f * g, il2, a);                // A = 2 d obj / d d2
+                    dyn[c * CKB_T + tid] += g * (-2.0f * u / p);           // d u / d l = -2 u / l
+                }
+            }
+            if constexpr (KIND == DKT_CLASSMAP_POLY) {
+                Wpb[(size_t)i * N + j] = a;
+            } else {
+                rowsum += a;
+                if (j == i) adiag = a;
+                else Wpb[(size_t)i * N + j] = -a;
+            }
+        }
+        if constexpr (KIND != DKT_CLASSMAP_POLY) {
+            rowsum = wave_allsum(rowsum);
+            adiag = wave_allsum(adiag);                                  // one lane held it
+            if (lane == 0) Wpb[(size_t)i * N + i] = rowsum - adiag;     // Wp = diag(A 1) - A
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        const float s = wave_allsum(dyn[c * CKB_T + tid]);
+        __syncthreads();                                                 // (every thread has read its slot of class c)
+        if (lane == 0) dyn[c * CKB_T + wave] = s;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const float* d = &dyn[tid * CKB_T];
+        dparam[(size_t)b * C + tid] = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    }
+}
+
+}  // namespace
+
+extern "C" int dkt_class_kernel_f32(const float* base, int kind, const float* param, int power, float* E, int B, int C, int NN,
+                                    void* stream) {
+    if (!base || !param || !E || B <= 0 || C <= 0 || NN <= 0) return DKT_ERR_BAD_ARG;
+    if (kind == DKT_CLASSMAP_POLY && power != 1 && power != 2) return DKT_ERR_BAD_ARG;
+    if (B > 65535) return DKT_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((NN + 255) / 256, B), block(256);
+    switch (kind) {
+        case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_RBF>, grid, block, 0, st, base, param, power, E, C, NN); break;
+        case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, base, param, power, E, C, NN); break;
+        case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_POLY>, grid, block, 0, st, base, param, power, E, C, NN); break;
+        default: return DKT_ERR_BAD_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int kind, const float* param, int power, float* Wp,
+                                        float* dparam, int B, int C, int N, void* stream) {
+    if (!W || !base || !param || !Wp || !dparam || B <= 0 || C <= 0 || N <= 0) return DKT_ERR_BAD_ARG;
+    if (kind == DKT_CLASSMAP_POLY && power != 1 && power != 2) return DKT_ERR_BAD_ARG;
+    if (C > 32) return DKT_ERR_TOO_LARGE;                                // 32 x 512 floats of LDS partials (64 KB)
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B), block(CKB_T);
+    const size_t lds = (size_t)C * CKB_T * sizeof(float);
+    switch (kind) {
+        case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd<DKT_CLASSMAP_RBF>, grid, block, lds, st, W, base, param, power, Wp, dparam, C, N); break;
+        case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd<DKT_CLASSMAP_MATERN25>, grid, block, lds, st, W, base, param, power, Wp, dparam, C, N); break;
+        case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd<DKT_CLASSMAP_POLY>, grid, block, lds, st, W, base, param, power, Wp, dparam, C, N); break;
+        default: return DKT_ERR_BAD_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}

@@ -79,6 +79,7 @@ struct BnTrainOut {                // train-mode statistics written by the STATS
     float *mean, *rstd, *a, *s, *var_unbiased;
     float eps;
     int has_gamma, has_beta;
+    const float* lengthscale;      // EPI > 0 (distance epilogues): [1]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -88,7 +89,11 @@ struct BnTrainOut {                // train-mode statistics written by the STATS
 // bn_stats_kernel) are reduced over the 32 threads that hold a feature (three lane exchanges + a 1-KB table in LDS that rides on
 // the slab loop's two existing barriers), folded into a = gamma rstd, s = beta - mean a, and applied to the same registers.
 // X is read ONCE; A / S are then gamma / beta [D].
-template <int NT, bool STATS>
+// EPI (round 3; dkt_gram_f32 kinds SQDIST / RBF at 32 < N <= 128): the same kernel as the episode-resident squared-distance build -- the
+// affine map is y = x - x_0 (row 0 of the episode: the shift GPyTorch's mean-centring provides, taken while the slice is staged), the
+// epilogue reads |y_i|^2 off the diagonal and emits d2_ij / l^2 = (|y_i|^2 + |y_j|^2 - 2 y_i . y_j) / l^2 (EPI = 1) or exp(-d2 / 2 l^2)
+// (EPI = 2), exact zero / unit diagonal, bitwise symmetric.  A / S are unused.
+template <int NT, bool STATS, int EPI = 0>
 __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_sym_ep_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                                               const float* __restrict__ S, long ab_bstride,
                                                                               float* __restrict__ E, float* __restrict__ rnorm,
@@ -134,6 +139,10 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
             if (bo.has_beta) bsc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, fo, k0 * 4, 0));
             x0 = bload4(xr, in ? 16 * c4 : OOB, k0 * 4); // row 0 of the thread's features: the shift of the sums
             kcur = k0;
+        } else if constexpr (EPI != 0) {
+            x0 = bload4(xr, in ? 16 * c4 : OOB, k0 * 4);
+            av = make_float4(1.f, 1.f, 1.f, 1.f);
+            sv = make_float4(-x0.x, -x0.y, -x0.z, -x0.w);
         } else {
             av = bload4(ar, in ? 16 * c4 : OOB, k0 * 4);
             sv = bload4(sr, in ? 16 * c4 : OOB, k0 * 4);
@@ -270,7 +279,8 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
         if ((r16 >> 2) == q) {
             const int rr = r16 & 3;
             const float v = rr == 0 ? t[0] : rr == 1 ? t[1] : rr == 2 ? t[2] : t[3];
-            rho[16 * row_blk + r16] = 1.0f / fmaxf(sqrtf(fmaxf(v, 0.f)), 1e-12f);    // F.normalize: x / max(||x||, 1e-12)
+            if constexpr (EPI != 0) rho[16 * row_blk + r16] = fmaxf(v, 0.f);          // |y_i|^2
+            else rho[16 * row_blk + r16] = 1.0f / fmaxf(sqrtf(fmaxf(v, 0.f)), 1e-12f);    // F.normalize: x / max(||x||, 1e-12)
         }
     };
     auto diag_of = [&](auto w) {
@@ -284,28 +294,39 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
     else if (wave == 2) diag_of(std::integral_constant<int, 2>{});
     else diag_of(std::integral_constant<int, 3>{});
     __syncthreads();
-    if (tid < N) rnorm[(size_t)b * N + tid] = rho[tid];
+    if constexpr (EPI == 0) {
+        if (tid < N) rnorm[(size_t)b * N + tid] = rho[tid];
+    }
+    float inv_l2 = 0.f;
+    if constexpr (EPI != 0) {
+        const float l = bo.lengthscale[0];
+        inv_l2 = 1.0f / (l * l);
+    }
+    auto emit = [&](f32x4& t, const int rowblk, const int tj) {     // tile (rowblk, tj) of G' -> the kernel's output values, in place
+        const float rj = rho[16 * tj + r16];
+        const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * rowblk + 4 * q]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if constexpr (EPI == 0) {
+                t[reg] *= ri[reg] * rj;
+            } else {
+                float d2 = fmaxf(ri[reg] + rj - 2.0f * t[reg], 0.f);
+                if (rowblk == tj && 4 * q + reg == r16) d2 = 0.f;
+                t[reg] = (EPI == 2) ? expf(-0.5f * d2 * inv_l2) : d2 * inv_l2;
+            }
+        }
+    };
     auto finish = [&](auto w) {
         constexpr int W = decltype(w)::value;
         constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
         if constexpr (RA >= 0) {
 #pragma unroll
-            for (int tj = 0; tj <= RA; ++tj) {
-                const float rj = rho[16 * tj + r16];
-                const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * RA + 4 * q]);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[tj][reg] *= ri[reg] * rj;
-            }
+            for (int tj = 0; tj <= RA; ++tj) emit(acc[tj], RA, tj);
             sym_store_row<RA>(acc, Eb, N, r16, q);
         }
         if constexpr (RB >= 0) {
 #pragma unroll
-            for (int tj = 0; tj <= RB; ++tj) {
-                const float rj = rho[16 * tj + r16];
-                const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * RB + 4 * q]);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[RA + 1 + tj][reg] *= ri[reg] * rj;
-            }
+            for (int tj = 0; tj <= RB; ++tj) emit(acc[RA + 1 + tj], RB, tj);
             sym_store_row<RB>(acc + RA + 1, Eb, N, r16, q);
         }
     };
@@ -592,7 +613,10 @@ void launch_gram_bn_bwd(const float* W, const float* E, const float* X, const fl
 template <int NT>
 void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
                     const BnTrainOut* bo) {
-    if (bo) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo);
+    if (bo && bo->lengthscale) {
+        if (bo->has_gamma) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 2>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);      // RBF
+        else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 1>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);                     // SQDIST
+    } else if (bo) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo);
     else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{});
 }
 
@@ -612,6 +636,20 @@ int gram_bn_dispatch(const float* X, const float* a, const float* s, long abs, f
 }
 
 }  // namespace
+
+// Episode-resident squared-distance / RBF build of dkt_gram_f32 (symmetric, 32 < N <= 128, D % 4 == 0, 16-byte aligned Z, a batch that
+// fills the GPU); returns false when it does not apply (the generic 64 x 64-tile kernel then runs).
+bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
+    static const int minb = [] { const char* v = getenv("DKT_GRAM_EP_MINB"); return v ? atoi(v) : 64; }();
+    static const bool on = [] { const char* v = getenv("DKT_GRAM_DIST_EP"); return !(v && v[0] == '0'); }();
+    if (!on || N <= 32 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || B < minb || !lengthscale) return false;
+    if (kind != DKT_KERNEL_RBF && kind != DKT_KERNEL_SQDIST) return false;
+    BnTrainOut bo{};
+    bo.lengthscale = lengthscale;
+    bo.has_gamma = (kind == DKT_KERNEL_RBF);             // (selects the epilogue, see launch_gram_bn)
+    gram_bn_dispatch(Z, Z, Z, 0, E, nullptr, B, N, D, st, &bo);
+    return true;
+}
 
 extern "C" int dkt_bn_stats_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
                                 float* a, float* s, float* var_unbiased, int B, int N, int D, void* stream) {
@@ -637,7 +675,7 @@ extern "C" int dkt_gram_bn_train_f32(const float* X, const float* gamma, const f
     if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return DKT_ERR_BAD_ARG;
     if (((uintptr_t)mean & 15) || ((uintptr_t)rstd & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || ((uintptr_t)var_unbiased & 15)) return DKT_ERR_BAD_ARG;
     if (N > 128) return DKT_ERR_TOO_LARGE;
-    BnTrainOut bo;
+    BnTrainOut bo{};
     bo.mean = mean; bo.rstd = rstd; bo.a = a; bo.s = s; bo.var_unbiased = var_unbiased;
     bo.eps = eps; bo.has_gamma = gamma != nullptr; bo.has_beta = beta != nullptr;
     // absent gamma / beta: any valid pointer keeps the descriptor legal, the values are ignored (has_* = 0)

@@ -21,6 +21,7 @@ bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, in
 bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 // wave-per-episode kernels for N <= 32 (dkt_gram_small.hip): every kind, symmetric; DKT_GRAM_SMALL=0 keeps the generic kernels
 bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st);
+bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st);      // dkt_frontend.hip
 bool dkt_gram_small_bwd_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st);
 bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st);
 
@@ -368,6 +369,8 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     const char* sm = getenv("DKT_GRAM_SMALL");
     const bool small_ok = !(sm && sm[0] == '0');
     if (sym && small_ok && dkt_gram_small_launch(A, E, B, N, D, kind, lengthscale, st))
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    if (sym && kind != DKT_KERNEL_LINEAR && dkt_gram_dist_ep_launch(A, E, B, N, D, kind, lengthscale, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, unit, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

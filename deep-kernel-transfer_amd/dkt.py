@@ -303,10 +303,10 @@ class DKT(MetaTemplate):
             # DKT.py:63-66), so the base matrix differs per class
             ls, off = self.model.lengthscale, self.model.offset
             if n + 1 <= 112:
-                # ONE contraction per episode (squared distances / Gram), the per-class map element-wise, ONE marginal-likelihood
-                # launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS)
-                e = ops.base_matrix_per_class(zb, self.kernel_type, ls, off)
-                obj, logp, alpha, info, jit = ops.mll_objective(e, y, sv, mean, noise, cw, self.jitter0, self.max_tries)
+                # ONE contraction per episode (squared distances / Gram), the C class maps in one launch, ONE marginal-likelihood
+                # launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS), the chain rule back in two launches
+                obj, logp, alpha, info, jit, e = ops.episode_loss_class_kernel(zb, y, sv, mean, noise, cw, self.kernel_type, ls, off,
+                                                                               self.jitter0, self.max_tries)
             else:
                 # larger episodes: one Gram + one single-model launch per class
                 objs, logps, alphas, infos, jits = [], [], [], [], []

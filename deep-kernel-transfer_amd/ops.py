@@ -426,6 +426,102 @@ def spectral_mixture_matrix(z: torch.Tensor, weights: torch.Tensor, means: torch
     return _SpectralMixtureFn.apply(z, weights, means, scales)
 
 
+CLASSMAP_RBF, CLASSMAP_MATERN25, CLASSMAP_POLY = 0, 1, 2
+
+
+def _classmap_of(kernel: str, lengthscale, offset):
+    """(map id, power, parameter [C], base-matrix kind) of a kernel whose class models own their base-kernel parameter."""
+    if kernel in POLY_KINDS:
+        return CLASSMAP_POLY, POLY_KINDS[kernel], offset, KERNEL_LINEAR
+    if kernel in MATERN_KINDS:
+        return CLASSMAP_MATERN25, 0, lengthscale, KERNEL_SQDIST
+    if kernel in RBF_KINDS:
+        return CLASSMAP_RBF, 0, lengthscale, KERNEL_SQDIST
+    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' has no per-class base-kernel parameter")
+
+
+def class_kernel(base: torch.Tensor, cmap: int, power: int, param: torch.Tensor) -> torch.Tensor:
+    """E[B,C,...] = f(base[B,...]; param[c]) -- the C class kernels of an episode from its ONE contraction (dkt_class_kernel_f32)."""
+    base = _req(base, "base")
+    param = _req(param.reshape(-1), "param", 1)
+    b_, c = base.shape[0], param.numel()
+    nn = base[0].numel()
+    e = torch.empty((b_, c) + tuple(base.shape[1:]), device=base.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_class_kernel_f32"):
+        st = lib.dkt_class_kernel_f32(_p(base), int(cmap), _p(param), int(power), _p(e), b_, c, nn, _stream())
+    _lib.check(st, "dkt_class_kernel_f32")
+    return e
+
+
+def class_kernel_bwd(w: torch.Tensor, base: torch.Tensor, cmap: int, power: int, param: torch.Tensor):
+    """Chain rule behind the per-class marginal-likelihood launch: w [B,C,N,N] = d obj / d E (symmetric per matrix) -> (Wp [B,N,N] for
+    gram_bwd, dparam [B,C])."""
+    w = _req(w, "w", 4)
+    base = _req(base, "base", 3)
+    param = _req(param.reshape(-1), "param", 1)
+    b_, c, n, _ = w.shape
+    if tuple(base.shape) != (b_, n, n) or param.numel() != c:
+        raise RuntimeError("class_kernel_bwd: base must be [B,N,N] and param [C]")
+    wp = torch.empty_like(base)
+    dparam = torch.empty((b_, c), device=w.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_class_kernel_bwd_f32"):
+        st = lib.dkt_class_kernel_bwd_f32(_p(w), _p(base), int(cmap), _p(param), int(power), _p(wp), _p(dparam), b_, c, n, _stream())
+    _lib.check(st, "dkt_class_kernel_bwd_f32")
+    return wp, dparam
+
+
+class _EpisodeLossClassKernelFn(torch.autograd.Function):
+    """Fused training episode for the kernels whose class models own a base-kernel parameter (rbf / matern: lengthscale [C]; poli1 / poli2:
+    offset [C]; reference DKT.py:63-66, 352-365):
+       forward : ONE contraction per episode (dkt_gram_f32: squared distances or Gram) -> the C class kernels (dkt_class_kernel_f32)
+                 -> logp, W[B,C,N,N], hyper grads in ONE launch (dkt_mll_f32, DKT_MLL_E_PER_CLASS)
+       backward: dkt_class_kernel_bwd_f32 (sum over the classes, parameter gradients) -> dkt_gram_bwd_f32 (upstream grad as ep_scale)."""
+
+    @staticmethod
+    def forward(ctx, z, y, sv, mean, noise, cls_weight, param, cmap, power, base_kind, jitter0, max_tries):
+        one = torch.ones(1, device=z.device, dtype=torch.float32)
+        base = gram(z, None, base_kind, one if base_kind == KERNEL_SQDIST else None)
+        e = class_kernel(base, cmap, power, param)
+        out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
+        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        ctx.save_for_backward(z, base, out["w"], param, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
+        ctx.maps = (int(cmap), int(power))
+        ctx.shapes = (sv.shape, mean.shape, noise.shape, param.shape)
+        ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e)
+        ctx.set_materialize_grads(False)
+        return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e
+
+    @staticmethod
+    def backward(ctx, gobj, *_unused):
+        if gobj is None:
+            return (None,) * 12
+        z, base, w, param, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        gobj = gobj.contiguous()
+        ng = ctx.needs_input_grad
+        dz = gparam = None
+        if ng[0] or ng[6]:
+            wp, dpar = class_kernel_bwd(w, base, ctx.maps[0], ctx.maps[1], param)
+            if ng[0]:
+                dz = gram_bwd(wp, z, gobj)
+            if ng[6]:
+                gparam = (gobj.reshape(-1, 1) * dpar).sum(0).reshape(ctx.shapes[3])
+        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[2] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[3] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[4] else None
+        return dz, None, gsv, gmean, gnoise, None, gparam, None, None, None, None, None
+
+
+def episode_loss_class_kernel(z, y, sv, mean, noise, cls_weight, kernel: str, lengthscale=None, offset=None,
+                              jitter0: float = 1e-6, max_tries: int = 3):
+    """Training episode(s) z:[B,N,D] for rbf / matern / poli1 / poli2 with per-class lengthscale / offset [C], N + 1 <= 112.
+    Returns (obj[B], logp[B,C], alpha[B,C,N], info[B,C], jitter[B,C], E[B,C,N,N])."""
+    cmap, power, param, base_kind = _classmap_of(kernel, lengthscale, offset)
+    return _EpisodeLossClassKernelFn.apply(_req(z, "z", 3), y, sv, mean, noise, cls_weight, param, cmap, power, base_kind, jitter0, max_tries)
+
+
 def base_matrix_per_class(z: torch.Tensor, kernel: str, lengthscale: Optional[torch.Tensor] = None,
                           offset: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Differentiable E[B,C,N,N] for the kernels whose class models own their base-kernel parameter (one ExactGPLayer per class,
@@ -445,16 +541,11 @@ def base_matrix_per_class(z: torch.Tensor, kernel: str, lengthscale: Optional[to
 
 def kernel_matrix_per_class(a: torch.Tensor, bm: Optional[torch.Tensor], kernel: str, lengthscale: Optional[torch.Tensor] = None,
                             offset: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """k_c(a, bm) for every class model, [B,C,M,N] (no autograd): one contraction, C element-wise maps."""
+    """k_c(a, bm) for every class model, [B,C,M,N] (no autograd): one contraction (dkt_gram_f32), the C class maps in one launch
+    (dkt_class_kernel_f32)."""
+    cmap, power, param, base_kind = _classmap_of(kernel, lengthscale, offset)
     one = torch.ones(1, device=a.device, dtype=torch.float32)
-    if kernel in POLY_KINDS:
-        return (gram(a, bm, KERNEL_LINEAR).unsqueeze(1) + offset.reshape(1, -1, 1, 1)) ** POLY_KINDS[kernel]
-    u = gram(a, bm, KERNEL_SQDIST, one).unsqueeze(1) / (lengthscale.reshape(1, -1, 1, 1) ** 2)
-    if kernel in MATERN_KINDS:
-        return _matern25(u)
-    if kernel in RBF_KINDS:
-        return torch.exp(-0.5 * u)
-    raise ValueError("[ERROR] the kernel '" + str(kernel) + "' has no per-class base-kernel parameter")
+    return class_kernel(gram(a, bm, base_kind, one if base_kind == KERNEL_SQDIST else None), cmap, power, param.detach())
 
 
 def base_matrix(z: torch.Tensor, kernel: str = "bncossim", lengthscale: Optional[torch.Tensor] = None,

@@ -206,6 +206,30 @@ int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const fl
                         float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream);
 
 /*
+ * ---- per-class element-wise maps of the non-linear base kernels ------------------------------
+ * Reference: one ExactGPLayer per class, each with its own RBFKernel / MaternKernel(nu = 2.5) lengthscale or PolynomialKernel offset
+ * (methods/DKT.py:63-66, 352-365).  All C kernels of an episode are functions of ONE contraction (dkt_gram_f32: DKT_KERNEL_SQDIST with
+ * lengthscale 1, or DKT_KERNEL_LINEAR):
+ *
+ * dkt_class_kernel_f32 -- E[b,c,k] = f(base[b,k]; param[c]), k < NN (NN = N*N, or M*N for a cross kernel):
+ *   DKT_CLASSMAP_RBF       u = base / l_c^2, f = exp(-u / 2)
+ *   DKT_CLASSMAP_MATERN25  u = base / l_c^2, r = sqrt(5 max(u, 1e-30)), f = (1 + r + r^2 / 3) exp(-r)
+ *   DKT_CLASSMAP_POLY      f = (base + offset_c)^power, power = 1 or 2
+ *
+ * dkt_class_kernel_bwd_f32 -- chain rule behind the marginal-likelihood launch with DKT_MLL_E_PER_CLASS: W[B,C,N,N] = d obj / d E (symmetric
+ *   per matrix: what dkt_mll_f32 writes) -> Wp[B,N,N] such that d obj / d Z = dkt_gram_bwd_f32(Wp, Z) = (Wp + Wp^T) Z
+ *   (distance kinds: Wp = diag(A 1) - A, A = 2 d obj / d d2; POLY: Wp = d obj / d (z_i . z_j)), and dparam[b,c] = d obj / d l_c (or offset_c)
+ *   of episode b (the caller sums over b).  C <= 32.
+ * Replaces autograd through the C kernel evaluations (loss.backward(), methods/DKT.py:163).
+ */
+#define DKT_CLASSMAP_RBF 0
+#define DKT_CLASSMAP_MATERN25 1
+#define DKT_CLASSMAP_POLY 2
+int dkt_class_kernel_f32(const float* base, int kind, const float* param, int power, float* E, int B, int C, int NN, void* stream);
+int dkt_class_kernel_bwd_f32(const float* W, const float* base, int kind, const float* param, int power, float* Wp, float* dparam,
+                             int B, int C, int N, void* stream);
+
+/*
  * dkt_smk_f32 -- spectral-mixture base kernel of the regression head
  *   (gpytorch.kernels.SpectralMixtureKernel(num_mixtures=4, ard_num_dims=2916), methods/DKT_regression.py:121-122):
  *   E[b,i,j] = sum_q weights[q] prod_d exp(-2 pi^2 (scales[q,d] tau_d)^2) cos(2 pi means[q,d] tau_d),

@@ -568,6 +568,81 @@ def test_mll_per_class_base_matrices_one_launch(cuda, c, per, d):
         ops.mll(big, torch.ones(2, 120, device=cuda), torch.ones(2, device=cuda), torch.zeros(2, device=cuda), torch.full((2,), 0.1, device=cuda), want_grad=True)
 
 
+def _class_kernel_ref(base, kernel, param):
+    """float64 torch restatement of the per-class maps (gpytorch RBFKernel / MaternKernel(nu=2.5) / PolynomialKernel, DKT.py:352-365)."""
+    p = param.reshape(1, -1, 1, 1)
+    if kernel in ("poli1", "poli2"):
+        return (base.unsqueeze(1) + p) ** (1 if kernel == "poli1" else 2)
+    u = base.unsqueeze(1) / p ** 2
+    if kernel == "rbf":
+        return torch.exp(-0.5 * u)
+    r = torch.sqrt(5.0 * u.clamp_min(1e-30))
+    return (1.0 + r + r * r / 3.0) * torch.exp(-r)
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2"])
+@pytest.mark.parametrize("b,c,n,d", [(3, 5, 25, 16), (2, 5, 105, 64), (2, 3, 64, 8), (1, 20, 33, 12)])
+def test_class_kernel_maps_and_chain_rule(cuda, kernel, b, c, n, d):
+    """dkt_class_kernel_f32 / dkt_class_kernel_bwd_f32: E[b,c] = f(base[b]; param_c) and, for a symmetric W[b,c] = d obj / d E[b,c], the matrix
+    Wp with d obj / d Z = (Wp + Wp^T) Z and d obj / d param -- against float64 autograd of obj = sum W . f(base(z); param)."""
+    rng = np.random.default_rng(n_hash(b, c, n, d) + len(kernel))
+    z = (0.4 * rng.standard_normal((b, n, d))).astype(np.float32)
+    param = np.linspace(0.7, 1.8, c).astype(np.float32)
+    w = rng.standard_normal((b, c, n, n)).astype(np.float32)
+    w = 0.5 * (w + w.transpose(0, 1, 3, 2))
+    cmap, power, _, base_kind = ops._classmap_of(kernel, torch.tensor(param), torch.tensor(param))
+    one = torch.ones(1, device=cuda)
+    zd = dev_t(z, cuda)
+    base = ops.gram(zd, None, base_kind, one if base_kind == ops.KERNEL_SQDIST else None)
+    e = ops.class_kernel(base, cmap, power, dev_t(param, cuda))
+    wp, dpar = ops.class_kernel_bwd(dev_t(w, cuda), base, cmap, power, dev_t(param, cuda))
+    dz = ops.gram_bwd(wp, zd)
+    # float64 autograd reference
+    z64 = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+    p64 = torch.tensor(param, dtype=torch.float64, requires_grad=True)
+    if base_kind == ops.KERNEL_SQDIST:
+        diff = z64.unsqueeze(2) - z64.unsqueeze(1)
+        base64 = (diff * diff).sum(-1)
+    else:
+        base64 = z64 @ z64.transpose(1, 2)
+    e64 = _class_kernel_ref(base64, kernel, p64)
+    obj = (torch.tensor(w, dtype=torch.float64) * e64).sum((1, 2, 3))          # per episode
+    assert rel_l2(e.cpu().numpy(), e64.detach().numpy()) < 2e-5
+    dpar_ref = np.stack([torch.autograd.grad(obj[i], p64, retain_graph=True)[0].numpy() for i in range(b)])
+    dz_ref = torch.autograd.grad(obj.sum(), z64)[0].numpy()
+    assert rel_l2(dz.cpu().numpy(), dz_ref) < 1e-4, rel_l2(dz.cpu().numpy(), dz_ref)
+    assert rel_l2(dpar.cpu().numpy(), dpar_ref) < 1e-4, rel_l2(dpar.cpu().numpy(), dpar_ref)
+    # cross matrices (test time): [B, M, N] bases go through the same map
+    ex = ops.kernel_matrix_per_class(zd[:, :7], zd, kernel, dev_t(param, cuda), dev_t(param, cuda))
+    assert ex.shape == (b, c, 7, n) and rel_l2(ex.cpu().numpy(), e64.detach().numpy()[:, :, :7]) < 2e-5
+
+
+@pytest.mark.parametrize("n,d", [(33, 64), (85, 512), (105, 1600), (128, 100), (64, 36)])
+def test_gram_distance_kinds_episode_resident(cuda, n, d):
+    """dkt_gram_f32 kinds SQDIST / RBF at 32 < N <= 128 and a batch that fills the GPU: the episode-resident kernel (features shifted by row 0 while
+    they are staged, split bf16 products, |y_i|^2 off the diagonal) against float64 and against the generic tile kernel (small batch)."""
+    b = 64
+    rng = np.random.default_rng(n * 13 + d)
+    z = (np.abs(rng.standard_normal((b, n, d))) * 0.3 + rng.uniform(0.0, 2.0, (1, 1, d))).astype(np.float32)     # ReLU-like, common offset
+    ls = dev_t(np.array([1.7 * np.sqrt(d) * 0.3]), cuda)
+    zd = dev_t(z, cuda)
+    z64 = z.astype(np.float64)
+    for kind in (ops.KERNEL_SQDIST, ops.KERNEL_RBF):
+        e = ops.gram(zd, None, kind, ls)
+        eg = ops.gram(zd[:4].contiguous(), None, kind, ls)                       # B < 64: generic kernel
+        assert torch.equal(e, e.transpose(1, 2))
+        l2 = float(ls.item()) ** 2
+        for i in (0, 1, b - 1):
+            diff = z64[i][:, None, :] - z64[i][None, :, :]
+            u = (diff * diff).sum(-1) / l2
+            ref = np.exp(-0.5 * u) if kind == ops.KERNEL_RBF else u
+            err = np.abs(e[i].cpu().numpy() - ref).max()
+            assert err < 2e-5 * max(1.0, ref.max()), (kind, err)
+        assert (e[:4] - eg).abs().max().item() < 2e-5 * max(1.0, float(eg.abs().max().item()))
+        dg = torch.diagonal(e, dim1=1, dim2=2)
+        assert torch.equal(dg, torch.ones_like(dg) if kind == ops.KERNEL_RBF else torch.zeros_like(dg))
+
+
 def n_hash(*a):
     return int(sum((i + 1) * v for i, v in enumerate(a)))
 

@@ -40,10 +40,16 @@ def timed(fn, it=10):
 for b in (1, 64, 1024):
     z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=dev), dim=2).requires_grad_(True)
 
-    def one_launch():
+    def one_launch_torch_maps():            # round 3 first version: the class maps and their chain rule as torch element-wise ops
         z.grad = None
         e = ops.base_matrix_per_class(z, "rbf", ls)
         obj, *_ = ops.mll_objective(e, y, sv, mean, noise, cw)
+        obj.mean().backward()
+
+    def one_launch():                       # the product path: dkt_gram_f32 (SQDIST) -> dkt_class_kernel_f32 -> dkt_mll_f32 -> dkt_class_kernel_bwd_f32 -> dkt_gram_bwd_f32
+        z.grad = None
+        ls.grad = None
+        obj, *_ = ops.episode_loss_class_kernel(z, y, sv, mean, noise, cw, "rbf", ls)
         obj.mean().backward()
 
     def per_class_loop():
@@ -60,6 +66,12 @@ for b in (1, 64, 1024):
         obj, *_ = ops.episode_loss_linear(z, y, sv, mean, noise, cw, unit_rows=True)
         obj.mean().backward()
 
-    a, bb, l = timed(one_launch), timed(per_class_loop), timed(linear)
-    print("B=%5d N=%d D=%d C=%d rbf, per-class lengthscales: one launch %.3f ms | per-class loop %.3f ms | linear episode %.3f ms | one-launch / linear %.2f" % (
-        b, n, d, c, a, bb, l, a / l), flush=True)
+    a, a0, bb, l = timed(one_launch), timed(one_launch_torch_maps), timed(per_class_loop), timed(linear)
+    ops.kernel_timing(True)
+    for _ in range(5):
+        one_launch()
+    torch.cuda.synchronize()
+    kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
+    ops.kernel_timing(False)
+    print("B=%5d N=%d D=%d C=%d rbf, per-class lengthscales: one launch %.3f ms (torch class maps: %.3f) | per-class loop %.3f ms | linear episode %.3f ms | one-launch / linear %.2f\n        kernels: %s" % (
+        b, n, d, c, a, a0, bb, l, a / l, kt), flush=True)
