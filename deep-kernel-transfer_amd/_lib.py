@@ -48,6 +48,7 @@ SIGNATURES = {
     "dkt_gram_bn_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                    _c_i, _c_i, _c_i, _c_p]),
     "dkt_class_kernel_f32": (_c_i, [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_class_kernel_bwd_nsplit": (_c_i, [_c_i, _c_i]),
     "dkt_class_kernel_bwd_f32": (_c_i, [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),

@@ -464,12 +464,13 @@ def class_kernel_bwd(w: torch.Tensor, base: torch.Tensor, cmap: int, power: int,
     if tuple(base.shape) != (b_, n, n) or param.numel() != c:
         raise RuntimeError("class_kernel_bwd: base must be [B,N,N] and param [C]")
     wp = torch.empty_like(base)
-    dparam = torch.empty((b_, c), device=w.device, dtype=torch.float32)
     lib = _lib.load()
+    nsplit = int(lib.dkt_class_kernel_bwd_nsplit(b_, n))
+    dparam = torch.empty((b_, nsplit, c), device=w.device, dtype=torch.float32)
     with _timed("dkt_class_kernel_bwd_f32"):
         st = lib.dkt_class_kernel_bwd_f32(_p(w), _p(base), int(cmap), _p(param), int(power), _p(wp), _p(dparam), b_, c, n, _stream())
     _lib.check(st, "dkt_class_kernel_bwd_f32")
-    return wp, dparam
+    return wp, (dparam[:, 0] if nsplit == 1 else dparam.sum(1))
 
 
 class _EpisodeLossClassKernelFn(torch.autograd.Function):

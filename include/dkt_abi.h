@@ -218,14 +218,16 @@ int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const fl
  *
  * dkt_class_kernel_bwd_f32 -- chain rule behind the marginal-likelihood launch with DKT_MLL_E_PER_CLASS: W[B,C,N,N] = d obj / d E (symmetric
  *   per matrix: what dkt_mll_f32 writes) -> Wp[B,N,N] such that d obj / d Z = dkt_gram_bwd_f32(Wp, Z) = (Wp + Wp^T) Z
- *   (distance kinds: Wp = diag(A 1) - A, A = 2 d obj / d d2; POLY: Wp = d obj / d (z_i . z_j)), and dparam[b,c] = d obj / d l_c (or offset_c)
- *   of episode b (the caller sums over b).  C <= 32.
+ *   (distance kinds: Wp = diag(A 1) - A, A = 2 d obj / d d2; POLY: Wp = d obj / d (z_i . z_j)), and dparam[b,s,c] = the part of d obj / d l_c (or
+ *   offset_c) of episode b that row split s contributes: dparam is [B, nsplit, C] with nsplit = dkt_class_kernel_bwd_nsplit(B, N) (1 for batches that
+ *   fill the GPU; small batches split the rows of an episode over several workgroups); the caller sums over s (and b).  C <= 32.
  * Replaces autograd through the C kernel evaluations (loss.backward(), methods/DKT.py:163).
  */
 #define DKT_CLASSMAP_RBF 0
 #define DKT_CLASSMAP_MATERN25 1
 #define DKT_CLASSMAP_POLY 2
 int dkt_class_kernel_f32(const float* base, int kind, const float* param, int power, float* E, int B, int C, int NN, void* stream);
+int dkt_class_kernel_bwd_nsplit(int B, int N);
 int dkt_class_kernel_bwd_f32(const float* W, const float* base, int kind, const float* param, int power, float* Wp, float* dparam,
                              int B, int C, int N, void* stream);
 
