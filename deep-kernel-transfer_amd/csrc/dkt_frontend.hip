@@ -79,7 +79,8 @@ struct BnTrainOut {                // train-mode statistics written by the STATS
     float *mean, *rstd, *a, *s, *var_unbiased;
     float eps;
     int has_gamma, has_beta;
-    const float* lengthscale;      // EPI > 0 (distance epilogues): [1]
+    const float* lengthscale;      // distance epilogues: [1]
+    int epi;                       // 0: cosine similarities (this front end); 1: d2 / l^2; 2: exp(-d2 / 2 l^2)  (dkt_gram_f32 kinds SQDIST / RBF)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -613,8 +614,8 @@ void launch_gram_bn_bwd(const float* W, const float* E, const float* X, const fl
 template <int NT>
 void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
                     const BnTrainOut* bo) {
-    if (bo && bo->lengthscale) {
-        if (bo->has_gamma) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 2>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);      // RBF
+    if (bo && bo->epi != 0) {
+        if (bo->epi == 2) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 2>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);       // RBF
         else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 1>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);                     // SQDIST
     } else if (bo) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo);
     else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{});
@@ -646,7 +647,7 @@ bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int 
     if (kind != DKT_KERNEL_RBF && kind != DKT_KERNEL_SQDIST) return false;
     BnTrainOut bo{};
     bo.lengthscale = lengthscale;
-    bo.has_gamma = (kind == DKT_KERNEL_RBF);             // (selects the epilogue, see launch_gram_bn)
+    bo.epi = (kind == DKT_KERNEL_RBF) ? 2 : 1;
     gram_bn_dispatch(Z, Z, Z, 0, E, nullptr, B, N, D, st, &bo);
     return true;
 }
