@@ -22,7 +22,7 @@
 //       over the classes IN REGISTERS and stored once (tile + mirror).
 // The pass runs without jitter (attempt 0 of psd_safe_cholesky); an episode with a failed matrix is redone -- jitter ladder and all --
 // by the generic kernel in a fix-up launch (dkt_mll.hip), exactly as the blocked path does.  No host read-back.
-#include "dkt_mfma_tiles.h"
+#include "dkt_h2_tiles.h"
 
 namespace {
 
@@ -509,45 +509,79 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #ifndef DKT_TILED_W_WGS
 #define DKT_TILED_W_WGS 2
 #endif
-template <int MC>
-__global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(TiledArgs t) {
+// F16 (round 3, default; DKT_MLL_TILED_F16=0 keeps the fp32 products): the products run as scaled 2-way f16 splits on v_mfma_f32_16x16x16_f16
+// (dkt_h2_tiles.h), 3 instructions of 16 cycles instead of 4 of 32 per tile product.  M_c = R_c^-T of the kappa-scaled matrix is bounded a
+// priori, |M_c| <= ||K'_c^-1||^(1/2) <= 2^msc_c / sqrt(noise_c); the class weight is folded into the split scales,
+//   A operand: sign(coef_c) g_c U M_ki,  B operand: g_c U M_kj,  g_c = sqrt |coef_c|,  U = 2^(15 - e), 2^e >= max_c g_c 2^msc_c / sqrt(noise_c)
+// (one unit per episode), so the accumulators hold U^2 sum_c coef_c M_c^T M_c over the whole (class, k) stream.  The augmented row of M (-alpha^T,
+// not covered by the bound) is zeroed in both operands; the rank-one terms -coef_c kappa_c alpha_c alpha_c^T are added on the VALU at the end from
+// the alpha the invert kernel wrote.
+template <int MC, bool F16, int WB>
+__global__ __launch_bounds__(64 * WB, WB == 4 ? DKT_TILED_W_WGS : 2) void tiled_w_kernel(TiledArgs t) {
+    __shared__ float qa_s[64], qb_s[64], ct_s[64];
     const MllArgs& a = t.a;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, NT = t.NT, C = a.C;
     // workgroup -> (episode, block column): the block columns of an episode read the same tile arrays class by class, so they are given
     // workgroup ids 8 apart (consecutive ids go to consecutive XCDs): one XCD, one L2
-    const int nblk = (NT + TB - 1) / TB;
+    const int nblk = (NT + WB - 1) / WB;
     const int bl = ((int)(blockIdx.x >> 3) / nblk) * 8 + (int)(blockIdx.x & 7);
     if (bl >= t.bcnt) return;
-    const int j0 = ((int)(blockIdx.x >> 3) % nblk) * TB, b = t.b0 + bl;
+    const int j0 = ((int)(blockIdx.x >> 3) % nblk) * WB, b = t.b0 + bl;
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 sgn;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sgn[q] = (g4 + q == pN) ? -1.0f : 1.0f;
-    f32x4 acc[MC][TB];
+    for (int q = 0; q < 4; ++q) sgn[q] = (g4 + q == pN) ? (F16 ? 0.0f : -1.0f) : 1.0f;
+    f32x4 acc[MC][WB];
 #pragma unroll
     for (int aa = 0; aa < MC; ++aa)
 #pragma unroll
-        for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = zero4;
-    const int jmax = min(j0 + TB, NT) - 1;                                  // last column of the block
+        for (int jj = 0; jj < WB; ++jj) acc[aa][jj] = zero4;
+    const int jmax = min(j0 + WB, NT) - 1;                                  // last column of the block
     // One descriptor over the C tile arrays of the episode; the (class, k) steps form ONE software-pipelined stream (the loads of
     // the next class's first step fly during the last step of the current one).
     const brsrc Tr = mk_rsrc(t.tiles + (size_t)bl * C * (ntt + 1) * 256, (unsigned)((size_t)C * (ntt + 1) * 1024));
     const TiledScal* sc = t.scal + (size_t)bl * C;
     const int nk = NT - j0, total = C * nk;
+    float unit_inv2 = 1.0f;
+    if constexpr (F16) {
+        // per-class split scales and the episode's unit (see above); a failed class has coef = NaN and poisons the episode's W as in the fp32 kernel
+        float bound = 0.f, coef = 0.f, g = 0.f;
+        int msc = 0;
+        if (tid < C) {
+            coef = sc[tid].coef;
+            msc = sc[tid].msc;
+            g = __builtin_sqrtf(fabsf(coef));
+            bound = g * ldexpf(1.0f, msc) / __builtin_sqrtf(a.noise[tid]);
+            qa_s[tid] = bound;
+        }
+        __syncthreads();
+        float mx = 1e-30f;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, qa_s[c]);               // (fmaxf drops the NaN of a failed class)
+        __syncthreads();
+        float inv;
+        const float unit = scale_for(mx, inv);
+        unit_inv2 = inv * inv;
+        if (tid < C) {
+            qa_s[tid] = (coef < 0.f ? -g : g) * unit + (coef - coef);      // (+ NaN for a failed class)
+            qb_s[tid] = g * unit;
+            ct_s[tid] = coef * ldexpf(1.0f, 2 * msc) * unit * unit;         // coefficient of alpha alpha^T in the accumulators' unit
+        }
+        __syncthreads();
+    }
     // rows of this wave: aa = 0 is its row of the diagonal block (i = j0 + w, only the columns j >= i), aa >= 1 the rows above it
-    // (i = j0 + w - 4 aa >= 0, all four columns)
-    auto row_of = [&](const int aa) { return j0 + w - TB * aa; };
+    // (i = j0 + w - WB aa >= 0, all WB columns)
+    auto row_of = [&](const int aa) { return j0 + w - WB * aa; };
     int lc = 0, lk = j0;                                                    // load cursor
-    auto loadk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB]) {
+    auto loadk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[WB]) {
         const int cbase = min(lc, C - 1) * (int)(ntt + 1), k = lk, zt = (int)ntt;
         const bool in = lc < C;
 #pragma unroll
-        for (int jj = 0; jj < TB; ++jj) {
+        for (int jj = 0; jj < WB; ++jj) {
             const int j = j0 + jj;
             Bt[jj] = bload4(Tr, lane16, (cbase + ((in && j <= k) ? tslot(NT, j, k) : zt)) * 1024);      // M_kj (the diagonal slot for k = j)
         }
@@ -559,27 +593,58 @@ __global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(Tiled
         if (++lk == NT) { lk = j0; ++lc; }
     };
     int mcl = 0, mk = j0;                                                   // multiply cursor
-    auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[TB]) {
-        const float coef = sc[min(mcl, C - 1)].coef;
+    auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[WB]) {
+        if constexpr (F16) {
+            const int cls = min(mcl, C - 1);
+            const float qa = qa_s[cls], qb = qb_s[cls];
+            const bool lastk = mk == NT - 1;
 #pragma unroll
-        for (int jj = 0; jj < TB; ++jj) Bt[jj] *= coef;
-        if (mk == NT - 1) {
+            for (int jj = 0; jj < WB; ++jj) Bt[jj] = split_h2(lastk ? Bt[jj] * sgn : Bt[jj], qb);
 #pragma unroll
-            for (int aa = 0; aa < MC; ++aa) A[aa] *= sgn;
-        }
-        if (j0 + w <= jmax) {                                               // the diagonal-block row: columns jj >= w
+            for (int aa = 0; aa < MC; ++aa) A[aa] = split_h2(lastk ? A[aa] * sgn : A[aa], qa);
+            if (j0 + w <= jmax) {
 #pragma unroll
-            for (int jj = 0; jj < TB; ++jj)
-                if (jj >= w) acc[0][jj] = xty(A[0], Bt[jj], acc[0][jj]);
-        }
+                for (int jj = 0; jj < WB; ++jj)
+                    if (jj >= w) acc[0][jj] = xtyh(A[0], Bt[jj], acc[0][jj]);
+            }
 #pragma unroll
-        for (int aa = 1; aa < MC; ++aa) {
-            if (row_of(aa) >= 0) xty4_y(A[aa], Bt, acc[aa]);
+            for (int aa = 1; aa < MC; ++aa) {
+                if (row_of(aa) >= 0) {
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) acc[aa][u] = xtyh1<0>(A[aa], Bt[u], acc[aa][u]);
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) acc[aa][u] = xtyh1<1>(A[aa], Bt[u], acc[aa][u]);
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) acc[aa][u] = xtyh1<2>(A[aa], Bt[u], acc[aa][u]);
+                }
+            }
+        } else {
+            const float coef = sc[min(mcl, C - 1)].coef;
+#pragma unroll
+            for (int jj = 0; jj < WB; ++jj) Bt[jj] *= coef;
+            if (mk == NT - 1) {
+#pragma unroll
+                for (int aa = 0; aa < MC; ++aa) A[aa] *= sgn;
+            }
+            if (j0 + w <= jmax) {                                           // the diagonal-block row: columns jj >= w
+#pragma unroll
+                for (int jj = 0; jj < WB; ++jj)
+                    if (jj >= w) acc[0][jj] = xty(A[0], Bt[jj], acc[0][jj]);
+            }
+#pragma unroll
+            for (int aa = 1; aa < MC; ++aa) {
+                if (row_of(aa) >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < WB; ++u) acc[aa][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[aa][q], Bt[u][q], acc[aa][u], 0, 0, 0);
+                }
+            }
         }
         if (++mk == NT) { mk = j0; ++mcl; }
     };
     {
-        f32x4 A0[MC], B0[TB], A1[MC], B1[TB];
+        f32x4 A0[MC], B0[WB], A1[MC], B1[WB];
         loadk(A0, B0);
         for (int it = 0; it < total; it += 2) {
             loadk(A1, B1);
@@ -588,13 +653,47 @@ __global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(Tiled
             if (it + 1 < total) mulk(A1, B1);
         }
     }
+    if constexpr (F16) {
+        // ---- the rank-one terms: acc(i, j) -= ct_c alpha_c[rows of i] alpha_c[columns of j]^T, class after class (alpha: NaN for a failed class) ----
+#pragma unroll 2
+        for (int c = 0; c < C; ++c) {
+            const brsrc alr = mk_rsrc(a.alpha + ((size_t)b * C + c) * N, (unsigned)(N * 4));
+            const float ct = ct_s[c];
+            float aj[WB];
+#pragma unroll
+            for (int jj = 0; jj < WB; ++jj) {
+                const int col = 16 * (j0 + jj) + c16;
+                aj[jj] = ct * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(alr, col < N ? col * 4 : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa) {
+                const int i = row_of(aa);
+                if (i >= 0 && i <= jmax) {                                  // uniform
+                    f32x4 ai;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 16 * i + g4 + q;
+                        ai[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(alr, row < N ? row * 4 : OOB, 0, 0));
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < WB; ++jj)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[aa][jj][q] = __builtin_fmaf(-ai[q], aj[jj], acc[aa][jj][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+            for (int jj = 0; jj < WB; ++jj) acc[aa][jj] *= unit_inv2;
+    }
     // ---- store: tile (i, j) and its mirror ----
     const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
 #pragma unroll
     for (int aa = 0; aa < MC; ++aa)
 #pragma unroll
-        for (int jj = 0; jj < TB; ++jj) {
-            const int i = j0 + w - TB * aa, j = j0 + jj;
+        for (int jj = 0; jj < WB; ++jj) {
+            const int i = j0 + w - WB * aa, j = j0 + jj;
             if (j < NT && i >= 0 && i <= j) {                               // uniform
                 const f32x4 v = acc[aa][jj];
                 const bool col_ok = 16 * j + c16 < N;
@@ -611,6 +710,14 @@ __global__ __launch_bounds__(64 * TB, DKT_TILED_W_WGS) void tiled_w_kernel(Tiled
         }
 }
 
+int g_tiled_f16 = -1;
+inline bool tiled_f16() {
+    if (g_tiled_f16 < 0) {
+        const char* v = getenv("DKT_MLL_TILED_F16");
+        g_tiled_f16 = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_tiled_f16 != 0;
+}
 inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
 inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
@@ -630,13 +737,21 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 #endif
     if (grad) {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, true>), dim3(nmat), dim3(64 * TB), 0, st, t);
-        hipLaunchKernelGGL((tiled_w_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB)), dim3(64 * TB), 0, st, t);
+        // W on the f16 pipe (DKT_MLL_TILED_F16=0: round 2's fp32 products).  Block columns of 8 tile columns with 8 waves (WB = 8: 880 instead of
+        // 1232 tile reads per class matrix at NT = 27) were measured and are NOT used: 25.8 vs 22.2 ms per 1024 cfg4 episodes for the whole
+        // marginal likelihood -- one 8-wave workgroup per CU at 246 VGPRs hides less load latency than two independent 4-wave ones; the
+        // kernel is latency-bound, not bandwidth-bound.
+        const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
+        if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, dim3(64 * TB), 0, st, t);
+        else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, dim3(64 * TB), 0, st, t);
     } else {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, false>), dim3(nmat), dim3(64 * TB), 0, st, t);
     }
 }
 
 }  // namespace
+
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
