@@ -787,6 +787,44 @@ def test_mll_tile_array_path_edges(cuda, n, c):
             assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
 
 
+@pytest.mark.parametrize("n,c", [(130, 4), (257, 6)])
+def test_mll_tile_array_w_kernel_class_weights_signs_and_hyper_ranges(cuda, n, c):
+    """The tile-array W kernel folds the class weight into the scales of its f16 splits and takes the bound of M = R^-T from noise and kappa:
+    class weights of both signs and of very different magnitude (one of them zero), noise from 0.05 to 0.5, outputscales from 0.3 to 5 (cond(K) up to
+    ~25 x the reference's) -- W and the log-likelihood against float64, and W against the fp32-product kernel (DKT_MLL_TILED_F16=0)."""
+    rng = np.random.default_rng(7 * n + c)
+    z = rng.standard_normal((2, n, 48))
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    e_np = np.einsum("bnd,bmd->bnm", z, z)
+    y = np.sign(rng.standard_normal((c, n)))
+    sv = np.geomspace(0.3, 5.0, c)
+    mean = 0.05 * rng.standard_normal(c)
+    noise = np.geomspace(0.05, 0.5, c)[::-1].copy()
+    cw = np.array([(-1.0) ** k * 10.0 ** (-k) for k in range(c)]) / n
+    cw[c // 2] = 0.0
+    args = [dev_t(x, cuda) for x in (e_np, y, sv, mean, noise)]
+    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    assert int(o["info"].abs().max().item()) == 0
+    assert torch.equal(o["w"], o["w"].transpose(1, 2))
+    w_ref = np.zeros((2, n, n))
+    for b in range(2):
+        for k in range(c):
+            kk = sv[k] * e_np[b] + noise[k] * np.eye(n)
+            r = y[k] - mean[k]
+            alpha = np.linalg.solve(kk, r)
+            w_ref[b] += cw[k] * sv[k] * 0.5 * (np.outer(alpha, alpha) - np.linalg.inv(kk))
+            logp = -0.5 * r @ alpha - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+            assert abs(o["logp"][b, k].item() - logp) < MLL_RTOL * abs(logp)
+    assert rel_l2(o["w"].cpu().numpy(), w_ref) < GRAD_RTOL, rel_l2(o["w"].cpu().numpy(), w_ref)
+    os.environ["DKT_MLL_TILED_F16"] = "0"                # (ops.mll tells the library when a switch changed inside the process)
+    try:
+        o32 = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    finally:
+        del os.environ["DKT_MLL_TILED_F16"]
+    assert rel_l2(o["w"].cpu().numpy(), o32["w"].cpu().numpy()) < 2e-5, rel_l2(o["w"].cpu().numpy(), o32["w"].cpu().numpy())
+    assert rel_l2(o32["w"].cpu().numpy(), w_ref) < GRAD_RTOL
+
+
 @pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (257, 100)])
 def test_gram_large_n_unit_rows_kernel(cuda, n, d):
     """Symmetric linear Gram at N > 128 with the unit-row promise: the 64 x 64-tile f16-split kernel (dkt_gram_big.hip) against float64
