@@ -67,7 +67,6 @@ __device__ __forceinline__ Geo make_geo(const int tid, const int N, const int NT
 struct FormRt {
     brsrc Et, yr;                 // the episode's E in tile layout (tiled_etile_kernel), this class' targets
     float nsv, dg, mc, rsc;
-    float pad = -1.0f;            // the padding diagonal (-1, or -2^30 where S is held at that scale)
 };
 
 // E[b] -> tile layout, once per episode (shared by its C class matrices): tile (i, j), i <= j, element [4g+q][c] = E[16i + 4g + q][16j + c]
@@ -120,7 +119,7 @@ __device__ __forceinline__ f32x4 form_from_e(const FormRt& f, const Geo& g, cons
             for (int q = 0; q < 4; ++q) {
                 float v = s[q];
                 v = (g4 + q == pN) ? ((c16 < pN) ? (f.mc - yc) * f.rsc : 0.f) : v;
-                v = (g4 + q > pN) ? ((g4 + q == c16) ? f.pad : 0.f) : v;
+                v = (g4 + q > pN) ? ((g4 + q == c16) ? -1.0f : 0.f) : v;
                 s[q] = v;
             }
         }
@@ -342,239 +341,6 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
         s.msc = msc;
         s.fail_at = fa;
         t.scal[m] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// CU-resident factorisation (round 3; DKT_MLL_TILED_CU=1): ONE workgroup of 8 waves keeps the whole upper tile triangle of a class matrix
-// on chip for the factorisation -- tile rows < 14 in registers, the rest in LDS -- and writes R (and the M_ii of the diagonal slots) to
-// the tile array exactly as tiled_factor_kernel does, so that tiled_invert_kernel / tiled_w_kernel run unchanged behind it.
-//   * ownership: wave (A, B) = (w & 1, w >> 1) owns the tiles (i, j) with i = A mod 2, j = B mod 4; its register tiles sit in a slot grid
-//     [column group jj = j / 4][row pair ii = i / 2] with 2, 4, 6, 7, 7, 7, 7 rows per column group (40 slots, the same code for every
-//     wave: which slots are valid -- i <= j < NT -- is a uniform run-time test); tile rows >= 14 are read-modified-written in LDS;
-//   * right-looking block steps with three barriers: the owner sweeps the diagonal tile (dkt_mfma_tiles.h) and publishes M_kk; the four
-//     waves that own row k turn it into the panel R_kj = (-V_kk)^T S_kj and publish it (split f16 planes, 2^15 R); every wave updates its
-//     own tiles S_ij += R_ki^T R_kj with v_mfma_f32_16x16x16_f16 (dkt_h2_tiles.h), S held at 2^30 in fp32;
-//   * scales as in dkt_mll_h2.hip: K / kappa bounds R by 1; the augmented column is scaled by rho = 2^-er so that it is too, undone when
-//     R / M / the quadratic form leave the chip.
-constexpr int CUF_RS = 14;                       // tile rows below this: registers
-constexpr int CUF_NTMAX = 28;
-__host__ __device__ constexpr int cuf_rows(int jj) { return jj == 0 ? 2 : (jj == 1 ? 4 : (jj == 2 ? 6 : 7)); }
-__host__ __device__ constexpr int cuf_base(int jj) { int b = 0; for (int u = 0; u < jj; ++u) b += cuf_rows(u); return b; }
-constexpr int CUF_NSLOT = cuf_base(7);           // 40
-constexpr int CUF_NLT = (CUF_NTMAX - CUF_RS) * (CUF_NTMAX - CUF_RS + 1) / 2;      // 105 LDS tiles
-__device__ __forceinline__ int cuf_lidx(const int i, const int j) {               // CUF_RS <= i <= j < CUF_NTMAX
-    const int li = i - CUF_RS;
-    return li * (CUF_NTMAX - CUF_RS) - (li * (li - 1)) / 2 + (j - i);
-}
-
-__global__ __launch_bounds__(512, 2) void tiled_cufactor_kernel(TiledArgs t) {
-    __shared__ f32x4 lt[CUF_NLT * 64];           // S tiles of the tile rows >= 14 (2^30 S, fp32)
-    __shared__ f32x4 panel[CUF_NTMAX * 64];      // the current panel row: 2^15 R_kj as split f16 planes
-    __shared__ f32x4 mkk[64];                    // M_kk of the current step (fp32)
-    __shared__ float red[8], red2[8];
-    __shared__ float lsum_w[8], quad_s;
-    __shared__ int fail_w[8];
-    const MllArgs& a = t.a;
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int A = w & 1, B = w >> 1;
-    const int N = a.N, NT = t.NT, C = a.C;
-    const int bl = ((int)(blockIdx.x >> 3) / C) * 8 + (int)(blockIdx.x & 7), c = (int)(blockIdx.x >> 3) % C;
-    if (bl >= t.bcnt) return;
-    const int m = bl * C + c, b = t.b0 + bl;
-    const Geo g = make_geo(tid, N, NT);
-    const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
-    const size_t ntt = (size_t)NT * (NT + 1) / 2;
-    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
-    const float* Eb = a.E + (size_t)b * N * N;
-    const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
-    // kappa = 4^msc >= max_i K_ii;  |y - m|^2 for the scale of the augmented column
-    float emax = 0.f, r2 = 0.f;
-    {
-        const float* yb = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
-        for (int i = tid; i < N; i += 512) {
-            emax = fmaxf(emax, Eb[(size_t)i * (N + 1)]);
-            const float d = yb[i] - mc;
-            r2 = __builtin_fmaf(d, d, r2);
-        }
-        emax = wave_reduce_dpp<true>(emax);
-        r2 = wave_reduce_dpp<false>(r2);
-        if (lane == 0) { red[w] = emax; red2[w] = r2; }
-        __syncthreads();
-        emax = 0.f; r2 = 0.f;
-        for (int u = 0; u < 8; ++u) { emax = fmaxf(emax, red[u]); r2 += red2[u]; }
-    }
-    int ex;
-    (void)frexpf(fmaf(svc, emax, nzc), &ex);
-    const int msc = max(0, (ex + 1) >> 1);
-    const float ikap = ldexpf(1.0f, -2 * msc);
-    const float lam = fmaxf(nzc * ikap, 9.094947017729282e-13f);                  // >= 2^-40
-    int exm;
-    (void)frexpf(1.0f / lam, &exm);
-    const int emu = (exm + 1) >> 1;
-    int exr;
-    (void)frexpf(r2 * ikap * ldexpf(1.0f, 2 * emu), &exr);
-    const int er = (r2 > 0.f) ? max(0, (exr + 1) >> 1) : 0;
-    const float aug_unscale = ldexpf(1.0f, er);                                     // 1 / rho
-    FormRt f;
-    f.Et = mk_rsrc(t.etiles + (size_t)bl * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
-    f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
-    f.nsv = -svc * ikap * TWO30; f.dg = -nzc * ikap * TWO30; f.mc = mc; f.rsc = ldexpf(TWO30, -msc - er); f.pad = -TWO30;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    h4 negIh;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) negIh[q] = (g4 + q == c16) ? (_Float16)-1.0f : (_Float16)0.0f;
-    if (w == 0) bstore4(Tr, zero4, lane16, (int)ntt * 1024);               // the matrix' zero tile (read by the later kernels)
-
-    // ---- form the owned tiles: S = -2^30 K' ----
-    f32x4 T[CUF_NSLOT];
-#pragma unroll
-    for (int jj = 0; jj < 7; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < cuf_rows(jj); ++ii) {
-            const int i = 2 * ii + A, j = 4 * jj + B;
-            const bool ok = i <= j && j < NT;                               // uniform
-            f32x4 v = zero4;
-            if (ok) v = form_from_e(f, g, i, j, bload4(f.Et, lane16, tslot(NT, i, j) * 1024));
-            T[cuf_base(jj) + ii] = v;
-        }
-    for (int i = CUF_RS + A; i < NT; i += 2)
-        for (int j = i + ((B - i) & 3); j < NT; j += 4)
-            lt[cuf_lidx(i, j) * 64 + lane] = form_from_e(f, g, i, j, bload4(f.Et, lane16, tslot(NT, i, j) * 1024));
-    __syncthreads();
-
-    int fail_at = 0;
-    float lsum = 0.f, quad = 0.f;
-    // store one finished panel tile: fp32 R_kj to the tile array (the augmented column un-scaled), its split to the panel buffer
-    auto emit_panel = [&](const f32x4 S, const f32x4 nV, const float sig_inv, const int k, const int j) {
-        const f32x4 R = split_h2(xtyh0(nV, split_h2(S, TWOM15)), sig_inv);       // 2^15 R_kj, split
-        panel[j * 64 + lane] = R;
-        f32x4 r = join_h2(R) * TWOM15;
-        if (j == NT - 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = (c16 == pN) ? r[q] * aug_unscale : r[q];
-        }
-        bstore4(Tr, r, toff(NT, k, j, lane), 0);
-    };
-    for (int k = 0; k < NT; ++k) {
-        const bool myrow = (k & 1) == A;
-        // ---- (a) the diagonal tile: sweep by its owner ----
-        if (myrow && (k & 3) == B) {
-            f32x4 S = zero4;
-            if (k < CUF_RS) {
-                switch (k >> 1) {
-#define CUF_DIAG(cc) case cc: S = T[cuf_base((cc) >> 1) + (cc)]; break;
-                    CUF_DIAG(0) CUF_DIAG(1) CUF_DIAG(2) CUF_DIAG(3) CUF_DIAG(4) CUF_DIAG(5) CUF_DIAG(6)
-#undef CUF_DIAG
-                }
-            } else {
-                S = lt[cuf_lidx(k, k) * 64 + lane];
-            }
-            float x[16], dv;
-            sweep_begin(S * TWOM30, x, dv);
-            const bool last = k == NT - 1;
-            if (last) sweep_plain<0, true>(x, dv, g.ln, pN);
-            else sweep_plain<0, false>(x, dv, g.ln, pN);
-            f32x4 M = sweep_end(x, g.ln);
-            const bool valid = !last || (c16 < pN);
-            const unsigned long long badm = __ballot(valid && !(dv > 0.f)) & 0xffffull;
-            const int first = (int)__builtin_ctzll(badm | 0x10000ull);
-            fail_at = (fail_at == 0 && badm != 0) ? 16 * k + first + 1 : fail_at;
-            lsum += (valid && g.ln.g0) ? __builtin_amdgcn_logf(dv) : 0.f;
-            if (last) {
-                quad = -__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), pN)) * aug_unscale * aug_unscale;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) M[q] = (g4 + q == pN && c16 < pN) ? M[q] * aug_unscale : M[q];       // row N of M: -rho alpha^T -> -alpha^T
-            }
-            mkk[lane] = M;
-            bstore4(Tr, M, toff(NT, k, k, lane), 0);                       // the diagonal slot keeps M_kk
-        }
-        __syncthreads();
-        // ---- (b) the panel row k: R_kj = (-V_kk)^T S_kj for the owned columns j > k ----
-        if (myrow && k + 1 < NT) {
-            const f32x4 M = mkk[lane];
-            float mx = fmaxf(fmaxf(fabsf(M[0]), fabsf(M[1])), fmaxf(fabsf(M[2]), fabsf(M[3])));
-            mx = wave_reduce_dpp<true>(mx);
-            mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));
-            float sig_inv;
-            const float sig = scale_for(mx, sig_inv);
-            const f32x4 nV = neg_transpose_h2(split_h2(M, sig), negIh);   // sig (-V_kk), split
-            if (k < CUF_RS) {
-                switch (k >> 1) {
-#define CUF_PANEL(cc)                                                                                                          \
-                    case cc:                                                                                                   \
-                        _Pragma("unroll") for (int jj = 0; jj < 7; ++jj) {                                                     \
-                            if (cc < cuf_rows(jj)) {                                                                           \
-                                const int j = 4 * jj + B;                                                                      \
-                                if (j > k && j < NT) emit_panel(T[cuf_base(jj) + (cc)], nV, sig_inv, k, j);                    \
-                            }                                                                                                  \
-                        }                                                                                                      \
-                        break;
-                    CUF_PANEL(0) CUF_PANEL(1) CUF_PANEL(2) CUF_PANEL(3) CUF_PANEL(4) CUF_PANEL(5) CUF_PANEL(6)
-#undef CUF_PANEL
-                }
-            } else {
-                for (int j = k + 1 + ((B - (k + 1)) & 3); j < NT; j += 4) emit_panel(lt[cuf_lidx(k, j) * 64 + lane], nV, sig_inv, k, j);
-            }
-        }
-        __syncthreads();
-        // ---- (c) trailing updates of the owned tiles: S_ij += R_ki^T R_kj, k < i <= j ----
-        if (k + 1 < NT) {
-            f32x4 Pj[7];
-#pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
-                const int j = 4 * jj + B;
-                Pj[jj] = (j > k && j < NT) ? panel[j * 64 + lane] : zero4;
-            }
-#pragma unroll
-            for (int ii = 0; ii < 7; ++ii) {
-                const int i = 2 * ii + A;
-                if (i > k && i < NT) {                                      // uniform
-                    const f32x4 Pi = panel[i * 64 + lane];
-#pragma unroll
-                    for (int which = 0; which < 3; ++which)
-#pragma unroll
-                        for (int jj = 0; jj < 7; ++jj) {
-                            if (ii < cuf_rows(jj)) {
-                                const int j = 4 * jj + B;
-                                if (i <= j && j < NT) {                     // uniform
-                                    f32x4& S = T[cuf_base(jj) + ii];
-                                    S = (which == 0) ? xtyh1<0>(Pi, Pj[jj], S) : (which == 1 ? xtyh1<1>(Pi, Pj[jj], S) : xtyh1<2>(Pi, Pj[jj], S));
-                                }
-                            }
-                        }
-                }
-            }
-            for (int i = max(CUF_RS, k + 1) + ((A - max(CUF_RS, k + 1)) & 1); i < NT; i += 2) {
-                const f32x4 Pi = panel[i * 64 + lane];
-                for (int j = i + ((B - i) & 3); j < NT; j += 4) {
-                    const int ix = cuf_lidx(i, j) * 64 + lane;
-                    lt[ix] = xtyh(Pi, panel[j * 64 + lane], lt[ix]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- per-matrix scalars ----
-    lsum = wave_allsum(lsum);
-    if (lane == 0) { lsum_w[w] = lsum; fail_w[w] = fail_at; }
-    if (w == (((NT - 1) & 1) + 2 * ((NT - 1) & 3)) && lane == 0) quad_s = quad;   // the owner of the last diagonal tile
-    __syncthreads();
-    if (tid == 0) {
-        int fa = 0;
-        float ls = 0.f;
-        for (int u = 0; u < 8; ++u) {
-            fa = (fail_w[u] != 0 && (fa == 0 || fail_w[u] < fa)) ? fail_w[u] : fa;
-            ls += lsum_w[u];
-        }
-        TiledScal sc;
-        sc.lsum2 = ls + (float)(2 * msc * N);
-        sc.quad = quad_s;
-        sc.coef = 0.f;
-        sc.msc = msc;
-        sc.fail_at = fa;
-        t.scal[m] = sc;
     }
 }
 
@@ -952,14 +718,6 @@ inline bool tiled_f16() {
     }
     return g_tiled_f16 != 0;
 }
-int g_tiled_cu = -1;
-inline bool tiled_cu() {
-    if (g_tiled_cu < 0) {
-        const char* v = getenv("DKT_MLL_TILED_CU");
-        g_tiled_cu = (v && v[0] == '1') ? 1 : 0;
-    }
-    return g_tiled_cu != 0;
-}
 inline int tiled_nt(int N) { return (N + 1 + 15) / 16; }
 inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
@@ -973,8 +731,7 @@ template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
     hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
-    if (tiled_cu()) hipLaunchKernelGGL(tiled_cufactor_kernel, dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(512), 0, st, t);
-    else hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(64 * TB), 0, st, t);
+    hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(64 * TB), 0, st, t);
 #ifdef DKT_TILED_CLOCKS
     return;
 #endif
@@ -994,7 +751,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 
 }  // namespace
 
-void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_cu = -1; }      // dkt_reload_env()
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
