@@ -474,8 +474,9 @@ def run(args):
         kernels, roofline_all = _kernel_report(args.config, m, UNIT_ROWS, traffic)
         dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
         roofline = roofline_all.get(dom)
-        mll_arith = ("the factorisations and the K^-1 products as scaled 2-way f16 splits too (v_mfma_f32_16x16x16_f16, fp32 accumulate), "
-                     "the triangular inverse on v_mfma_f32_16x16x4_f32" if n + 1 <= 128 else "the factorisations / inverses on v_mfma_f32_16x16x4_f32")
+        mll_arith = ("the factorisations, the triangular inverses and the K^-1 products as scaled 2-way f16 splits too (v_mfma_f32_16x16x16_f16, "
+                     "fp32 accumulate; diagonal-tile sweeps in fp32 on the VALU)" if n + 1 <= 128 else
+                     "the factorisations / inverses on v_mfma_f32_16x16x4_f32, the K^-1 products as scaled 2-way f16 splits")
         arith = ("f32 (results fp32-faithful; the two Gram contractions run as a scaled 2-way f16 split of every fp32 operand -- "
                  "22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16 products, fp32 accumulate; " + mll_arith + ")" if UNIT_ROWS else
                  "f32 (the two Gram contractions as an exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate; " + mll_arith + ")")
