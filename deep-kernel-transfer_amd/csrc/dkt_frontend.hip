@@ -373,10 +373,10 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
     constexpr int RS = 8 * SU;
     constexpr int PLANE = BD * RS;
     constexpr int IMG = 2 * PLANE * 2;                   // bytes of the [d][j] image (two f16 planes)
-    constexpr int STG = (2 * IMG > NP * NP * 4) ? 2 * IMG : NP * NP * 4;     // two image buffers; the region also stages W, then E (N x N fp32)
+    constexpr int STG = (2 * IMG > 2 * NP * NP * 4) ? 2 * IMG : 2 * NP * NP * 4;     // two image buffers; the region also stages W AND E (N x N fp32 each) together
     __shared__ __attribute__((aligned(16))) unsigned char smem[STG];
     __shared__ __attribute__((aligned(16))) float rl[NP], tl[NP], rowinv[NP];
-    __shared__ __attribute__((aligned(16))) float cs[2][NT][BD][2];          // double-buffered like the image: ONE barrier per slab
+    __shared__ __attribute__((aligned(16))) float cs[2][NT][16][8];          // per wave and lane column: the c1 / c2 sums of its 4 features; double-buffered like the image: ONE barrier per slab
     _Float16* zt = reinterpret_cast<_Float16*>(smem);
     float* wl = reinterpret_cast<float*>(smem);
 
@@ -414,8 +414,16 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
     const int row = wave * 16 + r16;
     float rsinv;                                         // 1 / (row scale of A)
     {
+        // W and E are staged TOGETHER (one global round trip and two barriers less than one after the other: with one workgroup per CU nothing
+        // else covers the prologue, which the phase clocks put at a quarter of an episode)
         const float* Wb = W + (size_t)b * nn;
-        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        const float* Eb = Eg + (size_t)b * nn;
+        float* el = wl + NP * NP;
+        for (int i = tid; i < nn; i += NTH) {
+            wl[i] = Wb[i];
+            el[i] = Eb[i];
+        }
+        if (tid < NP) rl[tid] = (tid < N) ? rnorm[(size_t)b * N + tid] : 0.f;      // padded rows: rho = 0 -> dY = 0
         __syncthreads();
         float v[KS][8];
         float rmax = 0.f;
@@ -446,11 +454,6 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
                 am[ks][e] = (_Float16)(xs - (float)hi);
             }
         }
-        __syncthreads();
-        const float* Eb = Eg + (size_t)b * nn;
-        for (int i = tid; i < nn; i += NTH) wl[i] = Eb[i];
-        if (tid < NP) rl[tid] = (tid < N) ? rnorm[(size_t)b * N + tid] : 0.f;      // padded rows: rho = 0 -> dY = 0
-        __syncthreads();
         float tp = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
             for (int e = 0; e < 8; ++e) {
                 const int k = 32 * ks + 8 * q + e;
                 const float aik = ((float)ah[ks][e] + (float)am[ks][e]) * rsinv;                // the A the MFMAs see (22 bits)
-                if (row < N && k < N) tp = __builtin_fmaf(aik, wl[row * N + k], tp);
+                if (row < N && k < N) tp = __builtin_fmaf(aik, el[row * N + k], tp);
             }
         }
         tp += __shfl_xor(tp, 16, DKT_WAVE);
@@ -467,9 +470,15 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
         __syncthreads();
     }
     // this lane's output rows i = 16 wave + 4 q + reg: rho_i, t_i, the un-scaling of the row stay in registers for the whole episode
-    const f32x4 rho4 = *reinterpret_cast<const f32x4*>(&rl[16 * wave + 4 * q]);
-    const f32x4 t4 = *reinterpret_cast<const f32x4*>(&tl[16 * wave + 4 * q]);
-    const f32x4 un4 = *reinterpret_cast<const f32x4*>(&rowinv[16 * wave + 4 * q]);
+    // dY_i = rho_i (dZn_i - zn_i t_i) with dZn = un_i acc and zn = rho_i y:  dY = (rho un) acc - (rho^2 t) y -- two constants per row
+    f32x4 ru4, r2t4;
+    {
+        const f32x4 rho4 = *reinterpret_cast<const f32x4*>(&rl[16 * wave + 4 * q]);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&tl[16 * wave + 4 * q]);
+        const f32x4 un4 = *reinterpret_cast<const f32x4*>(&rowinv[16 * wave + 4 * q]);
+        ru4 = rho4 * un4;
+        r2t4 = rho4 * rho4 * t4;
+    }
     const f32x4 rhoj = *reinterpret_cast<const f32x4*>(&rl[4 * jg]);      // rho_j of the staging task's rows
     __syncthreads();                                     // everyone is done with the staged E before the image is written
     if constexpr (KP > NP) {                             // columns j in [NP, KP) of the image are never staged: zero them once
@@ -497,9 +506,16 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
         }
     };
 
+#ifdef DKT_FE_CLOCKS      // measurement build (tools/fe_bwd_clocks.py): shader clocks per phase of wave 0, summed over the slabs -> dgamma_part[b, 0..7]
+    unsigned long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_amdgcn_s_memtime();
+#define FCLK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long c1 = __builtin_amdgcn_s_memtime(); ck[i] += c1 - c0; c0 = c1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FCLK(i) do { } while (0)
+#endif
     __syncthreads();                                     // pad columns zeroed
     lstore(0);
     __syncthreads();
+    FCLK(0);                                             // prologue (W, E staging, A fragments, first image)
     for (int sl = 0; sl < nslab; ++sl) {
         const int d0 = sl * BD, buf = sl & 1;
         if (sl + 1 < nslab) gload(d0 + BD);
@@ -533,74 +549,103 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[t], 0, 0, 0);
             }
         }
-        // dY (overwrites acc) and the normalised inputs xh (kept for the second half)
-        const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, esv[4] = {es.x, es.y, es.z, es.w};
-        const float emv[4] = {em.x, em.y, em.z, em.w}, erv[4] = {er.x, er.y, er.z, er.w};
-        float xh[4][4];                                  // [t][reg]
-        float c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+        FCLK(1);                                         // loads issued + MFMA loop (LDS fragment reads)
+#ifdef DKT_FE_CLOCKS
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00 | 0xc000);      // vmcnt(0) expcnt(7) lgkmcnt... : the epilogue operands (and the prefetch) have arrived
+        FCLK(2);
+#endif
+        // dY and the normalised inputs xh in packed fp32 (pairs of adjacent features: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 halve the
+        // VALU instructions of what the phase clocks show to be the heaviest part of a slab)
+        const f32x2 a2[2] = {{ea.x, ea.y}, {ea.z, ea.w}}, s2[2] = {{es.x, es.y}, {es.z, es.w}};
+        const f32x2 er2[2] = {{er.x, er.y}, {er.z, er.w}};
+        const f32x2 emer2[2] = {{-em.x * er.x, -em.y * er.y}, {-em.z * er.z, -em.w * er.w}};       // xh = x rstd - mean rstd
+        f32x2 dy2[4][2], xh2[4][2];                     // [reg][feature pair]
+        f32x2 c1p[2] = {{0.f, 0.f}, {0.f, 0.f}}, c2p[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float xv[4] = {xe[reg].x, xe[reg].y, xe[reg].z, xe[reg].w};
+            const f32x2 x2[2] = {{xe[reg].x, xe[reg].y}, {xe[reg].z, xe[reg].w}};
+            const f32x2 ru = {ru4[reg], ru4[reg]}, r2t = {r2t4[reg], r2t4[reg]};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float zn = __builtin_fmaf(eav[t], xv[t], esv[t]) * rho4[reg];
-                const float dy = rho4[reg] * __builtin_fmaf(-zn, t4[reg], acc[t][reg] * un4[reg]);
-                acc[t][reg] = dy;
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const f32x2 y = a2[p2] * x2[p2] + s2[p2];
+                const f32x2 ac = {acc[2 * p2][reg], acc[2 * p2 + 1][reg]};
+                const f32x2 dy = ac * ru - r2t * y;
+                dy2[reg][p2] = dy;
                 if constexpr (TRAIN_BN) {
-                    xh[t][reg] = (xv[t] - emv[t]) * erv[t];
-                    c1[t] += dy;
-                    c2[t] = __builtin_fmaf(dy, xh[t][reg], c2[t]);
+                    const f32x2 xh = x2[p2] * er2[p2] + emer2[p2];
+                    xh2[reg][p2] = xh;
+                    c1p[p2] += dy;
+                    c2p[p2] += dy * xh;
                 }
             }
         }
         if constexpr (TRAIN_BN) {
+            // over the 4 row groups q of the wave: reduce-scatter with v_permlane32_swap / v_permlane16_swap on PAIRS of values (one swap + one add
+            // halves the live values); row group q ends up with the sums number {0, 2, 1, 3}[q] (of c1) and 4 + that (of c2) of its column r16
+            const float v[8] = {c1p[0].x, c1p[0].y, c1p[1].x, c1p[1].y, c2p[0].x, c2p[0].y, c2p[1].x, c2p[1].y};
+            float u[4], w2[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {                // over the 4 row groups q of the wave
-                c1[t] += __shfl_xor(c1[t], 16, DKT_WAVE);
-                c1[t] += __shfl_xor(c1[t], 32, DKT_WAVE);
-                c2[t] += __shfl_xor(c2[t], 16, DKT_WAVE);
-                c2[t] += __shfl_xor(c2[t], 32, DKT_WAVE);
+            for (int h = 0; h < 4; ++h) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * h]), __float_as_uint(v[2 * h + 1]), false, false);
+                u[h] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             }
-            if (q == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    cs[buf][wave][4 * r16 + t][0] = c1[t];
-                    cs[buf][wave][4 * r16 + t][1] = c2[t];
-                }
+            for (int h = 0; h < 2; ++h) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * h]), __float_as_uint(u[2 * h + 1]), false, false);
+                w2[h] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             }
+            const int idx = ((q & 1) << 1) | (q >> 1);
+            float* dst = &cs[buf][wave][r16][0];
+            dst[idx] = w2[0];
+            dst[4 + idx] = w2[1];
         }
+        FCLK(3);                                         // first half of the epilogue
         if (sl + 1 < nslab) lstore(buf ^ 1);             // the other image buffer: last read before the previous barrier
+        FCLK(4);                                         // split + LDS stores of the next image
         __syncthreads();                                 // next image staged; column partials of every wave published
-        float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+        FCLK(5);                                         // barrier wait
+        f32x2 m1p[2] = {{0.f, 0.f}, {0.f, 0.f}}, m2p[2] = {{0.f, 0.f}, {0.f, 0.f}};
         if constexpr (TRAIN_BN) {
 #pragma unroll
             for (int w = 0; w < NT; ++w) {               // fixed order over the waves: deterministic
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    m1[t] += cs[buf][w][4 * r16 + t][0];
-                    m2[t] += cs[buf][w][4 * r16 + t][1];
-                }
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(&cs[buf][w][r16][0]);
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(&cs[buf][w][r16][4]);
+                m1p[0] += (f32x2){p1[0], p1[1]}; m1p[1] += (f32x2){p1[2], p1[3]};
+                m2p[0] += (f32x2){p2[0], p2[1]}; m2p[1] += (f32x2){p2[2], p2[3]};
             }
             if (wave == 0 && q == 0 && din) {
                 const size_t o = (size_t)b * D + d0 + 4 * r16;
-                *reinterpret_cast<float4*>(dbeta_part + o) = make_float4(m1[0], m1[1], m1[2], m1[3]);
-                *reinterpret_cast<float4*>(dgamma_part + o) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+                *reinterpret_cast<float4*>(dbeta_part + o) = make_float4(m1p[0].x, m1p[0].y, m1p[1].x, m1p[1].y);
+                *reinterpret_cast<float4*>(dgamma_part + o) = make_float4(m2p[0].x, m2p[0].y, m2p[1].x, m2p[1].y);
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                m1p[p2] *= inv_n;
+                m2p[p2] *= inv_n;
             }
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int i = 16 * wave + 4 * q + reg;
-            float o[4];
+            f32x2 o2[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float v = acc[t][reg];
-                if constexpr (TRAIN_BN) v = v - m1[t] * inv_n - xh[t][reg] * (m2[t] * inv_n);
-                o[t] = eav[t] * v;
+            for (int p2 = 0; p2 < 2; ++p2) {
+                f32x2 vv = dy2[reg][p2];
+                if constexpr (TRAIN_BN) vv = vv - m1p[p2] - xh2[reg][p2] * m2p[p2];
+                o2[p2] = a2[p2] * vv;
             }
-            if (i < N && din) *reinterpret_cast<float4*>(dXb + (size_t)i * D + d0 + 4 * r16) = make_float4(o[0], o[1], o[2], o[3]);
+            if (i < N && din) *reinterpret_cast<float4*>(dXb + (size_t)i * D + d0 + 4 * r16) = make_float4(o2[0].x, o2[0].y, o2[1].x, o2[1].y);
         }
+        FCLK(6);                                         // second half of the epilogue + dX stores
         // no second barrier: cs[buf] and image[buf] are written again two slabs on, i.e. behind the next slab's barrier
     }
+#ifdef DKT_FE_CLOCKS
+    if (tid == 0 && dgamma_part) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dgamma_part[(size_t)b * D + i] = (float)ck[i];
+    }
+#endif
+#undef FCLK
 }
 
 template <int NT>
