@@ -175,16 +175,6 @@ def _compile_link(sources, target, replace=None, verbose=False) -> str:
             usage.update(json.load(fh))
     with open(os.path.join(OBJ_DIR, os.path.basename(target) + ".resource_usage.json"), "w") as fh:
         json.dump(usage, fh, indent=1, sort_keys=True)
-    if os.path.abspath(target) == os.path.abspath(LIB_PATH) and not os.environ.get("DKT_EXTRA_HIPCC_FLAGS"):
-        # the shipped build's register / spill / LDS figures, in a TRACKED file (profiles/resource_usage.json): what the evidence cites is
-        # what was built
-        try:
-            prof = os.path.join(_ROOT, "profiles")
-            os.makedirs(prof, exist_ok=True)
-            with open(os.path.join(prof, "resource_usage.json"), "w") as fh:
-                json.dump(usage, fh, indent=1, sort_keys=True)
-        except OSError:
-            pass
     bad = check_resources(usage)
     if bad:
         raise RuntimeError("register spills beyond the budget (deep-kernel-transfer_amd/_lib.py SPILL_BUDGET):\n" +
@@ -220,6 +210,13 @@ def build_diag(verbose: bool = False) -> str:
     return _compile_link(DIAG_SOURCES, DIAG_LIB_PATH, None, verbose)
 
 
+def abi_version_of_header() -> int:
+    """DKT_ABI_VERSION as include/dkt_abi.h declares it."""
+    import re
+    with open(os.path.join(INCLUDE, "dkt_abi.h")) as fh:
+        return int(re.search(r"#define\s+DKT_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+
+
 def load() -> ctypes.CDLL:
     """dlopen the HIP library and bind every declared symbol; raises (never falls back) on failure."""
     global _lib
@@ -239,6 +236,11 @@ def load() -> ctypes.CDLL:
                 raise RuntimeError("libdkt_hip.so lacks symbol %s declared in include/dkt_abi.h" % name) from e
             fn.restype = res
             fn.argtypes = args
+        want = abi_version_of_header()
+        got = int(lib.dkt_abi_version())
+        if got != want:
+            raise RuntimeError("%s implements DKT_ABI_VERSION %d, include/dkt_abi.h declares %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+                               % (path, got, want))
         _lib = lib
         return lib
 

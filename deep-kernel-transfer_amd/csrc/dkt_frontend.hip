@@ -685,9 +685,13 @@ int gram_bn_dispatch(const float* X, const float* a, const float* s, long abs, f
 
 // Episode-resident squared-distance / RBF build of dkt_gram_f32 (symmetric, 32 < N <= 128, D % 4 == 0, 16-byte aligned Z, a batch that
 // fills the GPU); returns false when it does not apply (the generic 64 x 64-tile kernel then runs).
+static int g_dist_ep_minb = -1, g_dist_ep_on = -1;           // DKT_GRAM_EP_MINB / DKT_GRAM_DIST_EP, read at the first call and at dkt_reload_env()
+void dkt_frontend_reload_env() { g_dist_ep_minb = -1; g_dist_ep_on = -1; }
 bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
-    static const int minb = [] { const char* v = getenv("DKT_GRAM_EP_MINB"); return v ? atoi(v) : 64; }();
-    static const bool on = [] { const char* v = getenv("DKT_GRAM_DIST_EP"); return !(v && v[0] == '0'); }();
+    if (g_dist_ep_minb < 0) { const char* v = getenv("DKT_GRAM_EP_MINB"); g_dist_ep_minb = v ? atoi(v) : 64; }
+    if (g_dist_ep_on < 0) { const char* v = getenv("DKT_GRAM_DIST_EP"); g_dist_ep_on = (v && v[0] == '0') ? 0 : 1; }
+    const int minb = g_dist_ep_minb;
+    const bool on = g_dist_ep_on != 0;
     if (!on || N <= 32 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || B < minb || !lengthscale) return false;
     if (kind != DKT_KERNEL_RBF && kind != DKT_KERNEL_SQDIST) return false;
     BnTrainOut bo{};

@@ -202,6 +202,9 @@ void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipS
     hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(count), dim3(256), mll_vec_floats(a.N) * sizeof(float), st, a);
 }
 
+static int g_mll_env_read = 0, g_p2_guard = 1, g_force_f32mfma = 0;
+void dkt_mll_reload_env() { g_mll_env_read = 0; }         // dkt_reload_env()
+
 extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
     if (B <= 0 || N <= 0 || C <= 0) return 0;
     if (N + 1 <= 128) return 0;                              // register-resident kernel
@@ -227,9 +230,17 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.dmean = dmean; a.dnoise = dnoise; a.jitter_used = jitter_used; a.info = info;
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
-    {
+    if (g_mll_env_read == 0) {
         const char* pg = getenv("DKT_MLL_P2_GUARD");      // validation aid: a negative guard forces the grow-on-demand path of dkt_mll_h2.hip
-        a.p2_guard = pg ? atoi(pg) : 1;
+        g_p2_guard = pg ? atoi(pg) : 1;
+        const char* fm = getenv("DKT_MLL_F32MFMA");       // process-wide DKT_MLL_FORCE_F32MFMA: exact-fp32 tile products for every N <= 127 call
+        g_force_f32mfma = (fm && fm[0] == '1') ? 1 : 0;
+        g_mll_env_read = 1;
+    }
+    a.p2_guard = g_p2_guard;
+    if (g_force_f32mfma && !(flags & (DKT_MLL_E_PER_CLASS | DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED))) {
+        flags |= DKT_MLL_FORCE_F32MFMA;
+        a.flags = flags;
     }
     hipStream_t st = (hipStream_t)stream;
     if (flags & DKT_MLL_E_PER_CLASS) {

@@ -130,6 +130,10 @@ __device__ __forceinline__ f32x4 form_from_e(const FormRt& f, const Geo& g, cons
 // c[u] += x[u]^T y (u = 0..3) resp. c[u] += x^T y[u]: four independent accumulator chains advanced together, so that no MFMA waits
 // for the one issued just before it.
 __device__ __forceinline__ void xty4_x(const f32x4 (&x)[TB], const f32x4 y, f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+#ifdef DKT_TILED_NOMATH      // traffic-only measurement build (tools/tiled_traffic_ceiling.sh): the same tile stream, the products replaced by one add
+    c0 += x[0] + y; c1 += x[1] + y; c2 += x[2] + y; c3 += x[3] + y;
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[0][q], y[q], c0, 0, 0, 0);
@@ -409,10 +413,15 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #pragma unroll
             for (int aa = 0; aa < MC; ++aa) {
                 if (w + TB * aa <= k) {
+#ifdef DKT_TILED_NOMATH
+#pragma unroll
+                    for (int jj = 0; jj < TB; ++jj) acc[aa][jj] += X[jj] + Y[aa];
+#else
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[jj][q], Y[aa][q], acc[aa][jj], 0, 0, 0);
+#endif
                 }
             }
         };
@@ -594,6 +603,14 @@ __global__ __launch_bounds__(64 * WB, WB == 4 ? DKT_TILED_W_WGS : 2) void tiled_
     };
     int mcl = 0, mk = j0;                                                   // multiply cursor
     auto mulk = [&](f32x4 (&A)[MC], f32x4 (&Bt)[WB]) {
+#ifdef DKT_TILED_NOMATH
+#pragma unroll
+        for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+            for (int u = 0; u < WB; ++u) acc[aa][u] += A[aa] + Bt[u];
+        if (++mk == NT) { mk = j0; ++mcl; }
+        return;
+#endif
         if constexpr (F16) {
             const int cls = min(mcl, C - 1);
             const float qa = qa_s[cls], qb = qb_s[cls];
@@ -710,6 +727,253 @@ __global__ __launch_bounds__(64 * WB, WB == 4 ? DKT_TILED_W_WGS : 2) void tiled_
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// W with RESIDENT accumulators (round 4; default for C <= 64, DKT_MLL_TILED_WRES=0 restores the block-column kernel above).
+// W[b] = sum_c coef_c M_c^T M_c - (rank-one terms) is a SYRK over the "strips" of M: strip k of class c = the tiles M_k0 .. M_kk (slots (i, k),
+// i <= k), and W_ij += strip_k[i]^T strip_k[j] for every i <= j <= k.  The block-column kernel re-reads every strip once per block column of
+// W (1229 tile reads per class matrix at NT = 27 for 378 distinct tiles; its traffic-only build, DKT_TILED_NOMATH, takes 4.75 of its 6.05 ms:
+// profiles/r04/v0_tiled_traffic_ceiling.txt).  Here a workgroup of 4 waves keeps a COLUMN RANGE [c0, c1) of W -- up to 4 MAXT accumulator tiles,
+// i.e. a whole third of W at NT = 27 -- in registers for the whole (class, k) stream, so a strip is read once per range that needs it
+// (k >= c0, tiles i < c1: 668 tile reads per class matrix for the three ranges [0,15) [15,22) [22,27)), split ONCE while it is staged
+// (fp32 tile -> registers -> scaled 2-way f16 split with the class weight folded in -> LDS), and every product takes both operands from
+// that LDS image: D += A^T B = 3 x v_mfma_f32_16x16x16_f16 on two ds_read_b128.  The strips are double-buffered in LDS (2 x NT KB), the
+// global loads of step s + 2 fly while step s is multiplied; one barrier per step.
+// Wave w of a range owns its tiles t = w, w + 4, ... in column-major order (t -> (i, j): column j holds the tiles i = 0 .. j): the tile
+// coordinates are wave-uniform scalars advanced on the SALU, the accumulator index is static.
+// Scales as in the block-column kernel (|M_c| <= 2^msc_c / sqrt(noise_c); U = one power-of-two unit per episode), but both operands now
+// come from ONE image scaled by g_c U, g_c = sqrt|coef_c|, so the sign of coef_c cannot ride in an operand: the accumulators hold
+// sigma U^2 sum_c coef_c M_c^T M_c and are negated when a class changes sigma (class weights of one sign: never).
+struct WRanges { int ng; int c0[6]; };           // column ranges [c0[g], c0[g + 1]) of W, g < ng
+
+template <int MAXT>
+__global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges rg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wres_smem[];
+    const MllArgs& a = t.a;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, NT = t.NT, C = a.C;
+    const int ng = rg.ng;
+    // workgroup -> (episode, range): the ranges of an episode read the same strips, so they get workgroup ids 8 apart (one XCD, one L2)
+    const int bl = ((int)(blockIdx.x >> 3) / ng) * 8 + (int)(blockIdx.x & 7);
+    if (bl >= t.bcnt) return;
+    const int gi = (int)(blockIdx.x >> 3) % ng, b = t.b0 + bl;
+    const int c0 = rg.c0[gi], c1 = rg.c0[gi + 1];
+    const Geo g = make_geo(tid, N, NT);
+    const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2;
+    // LDS: [2][NT + 1] split tiles of 1 KB (tile NT of each buffer: all zero) | q[C] | sg[C] | ct[C]
+    f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
+    float* q_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * (NT + 1) * 1024);
+    float* sg_s = q_s + 64;
+    float* ct_s = sg_s + 64;
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)bl * C * (ntt + 1) * 256, (unsigned)((size_t)C * (ntt + 1) * 1024));
+    const TiledScal* sc = t.scal + (size_t)bl * C;
+    float unit_inv2;
+    {
+        float bound = 0.f, coef = 0.f, gc = 0.f;
+        int msc = 0;
+        if (tid < C) {
+            coef = sc[tid].coef;
+            msc = sc[tid].msc;
+            gc = __builtin_sqrtf(fabsf(coef));
+            bound = gc * ldexpf(1.0f, msc) / __builtin_sqrtf(a.noise[tid]);
+            q_s[tid] = bound;
+        }
+        __syncthreads();
+        float mx = 1e-30f;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, q_s[c]);                // (fmaxf drops the NaN of a failed class)
+        __syncthreads();
+        float inv;
+        const float unit = scale_for(mx, inv);
+        unit_inv2 = inv * inv;
+        if (tid < C) {
+            q_s[tid] = gc * unit + (coef - coef);                           // (+ NaN for a failed class: poisons the episode's W)
+            sg_s[tid] = coef < 0.f ? -1.0f : (coef > 0.f ? 1.0f : 0.0f);
+            ct_s[tid] = coef * ldexpf(1.0f, 2 * msc) * unit * unit;         // coefficient of alpha alpha^T in the accumulators' unit
+        }
+        __syncthreads();
+    }
+    // this wave's tiles: t = w + 4u in column-major order over the columns [c0, c1)
+    auto advance = [](int& i, int& j, const int n) {
+        i += n;
+        while (i > j) { i -= j + 1; ++j; }
+    };
+    int ti0 = 0, tj0 = c0;
+    advance(ti0, tj0, w);
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 keep;                                                             // rows of the last tile row that are real rows of M (the augmented row
+#pragma unroll                                                              // -alpha^T and the identity padding below it are zeroed: the rank-one terms
+    for (int q = 0; q < 4; ++q) keep[q] = (g4 + q < pN) ? 1.0f : 0.0f;      // are added at the end, the padding only reaches padded entries of W)
+    constexpr int NST = 7;                                                  // staged tiles per wave and step (NT <= 28)
+    const int nk = NT - c0, total = C * nk;
+    int lc = 0, lk = c0;                                                    // load cursor (class, strip)
+    auto load_step = [&](f32x4 (&S)[NST]) {
+        const int cbase = min(lc, C - 1) * (int)(ntt + 1), k = lk;
+        const bool in = lc < C;
+        const int lim = min(k + 1, c1);
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int i = w + 4 * x;
+            S[x] = bload4(Tr, (in && i < lim) ? lane16 : OOB, (cbase + ((i < lim) ? tslot(NT, i, k) : 0)) * 1024);
+        }
+        if (++lk == NT) { lk = c0; ++lc; }
+    };
+    int wc = 0, wk = c0;                                                    // split / LDS-write cursor
+    auto write_step = [&](const f32x4 (&S)[NST], const int bufi) {
+        const float q = q_s[min(wc, C - 1)];
+        const bool lastk = wk == NT - 1;
+        const int lim = min(wk + 1, c1);
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int i = w + 4 * x;
+            if (i < lim) sbuf[(bufi * (NT + 1) + i) * 64 + lane] = split_h2(lastk ? S[x] * keep : S[x], q);
+        }
+        if (++wk == NT) { wk = c0; ++wc; }
+    };
+    float cursign = 0.0f;
+    int mc_ = 0, mk = c0;                                                   // multiply cursor
+    auto mul_step = [&](const int bufi) {
+        const int k = mk;
+        if (k == c0) {                                                      // a new class: its sign against the accumulators'
+            const float sgc = sg_s[min(mc_, C - 1)];
+            if (sgc != 0.0f && sgc != cursign) {
+                if (cursign != 0.0f) {
+#pragma unroll
+                    for (int u = 0; u < MAXT; ++u) acc[u] = -acc[u];
+                }
+                cursign = sgc;
+            }
+        }
+        const f32x4* sb = sbuf + bufi * (NT + 1) * 64 + lane;
+        int ii = ti0, jj = tj0;
+        asm volatile("" : "+s"(ii), "+s"(jj));                              // (opaque: otherwise the 2 MAXT tile coordinates are hoisted out of the step loop -- and spilled)
+        // a tile (i, j) takes part in step k when j <= k; the wave's tiles are column-major, so the participants are a prefix of its list, and the
+        // tiles past the end of its list have j >= c1: one test, j <= min(k, c1 - 1).  Four tiles per block (four independent accumulator chains,
+        // eight ds_read_b128 in flight); a block's tiles beyond the prefix read the buffer's all-zero tile.
+        const int kk = min(k, c1 - 1), zt = NT;
+#pragma unroll
+        for (int u = 0; u < MAXT; u += 4) {
+            int ti[4], tj[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                ti[x] = ii; tj[x] = jj;
+                advance(ii, jj, 4);
+            }
+            if (tj[0] <= kk) {
+                f32x4 A[4], Bt[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const bool ok = tj[x] <= kk;
+                    A[x] = sb[(ok ? ti[x] : zt) * 64];
+                    Bt[x] = sb[(ok ? tj[x] : zt) * 64];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<0>(A[x], Bt[x], acc[u + x]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<1>(A[x], Bt[x], acc[u + x]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<2>(A[x], Bt[x], acc[u + x]);
+            }
+        }
+        if (++mk == NT) { mk = c0; ++mc_; }
+    };
+    {
+        // one staging array: the loads of step s + 2 are issued right after step s + 1 went to LDS and fly during the barrier and step s + 1's products
+        f32x4 S[NST];
+        if (w < 2) sbuf[(w * (NT + 1) + NT) * 64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_step(S);
+        write_step(S, 0);
+        load_step(S);
+        __syncthreads();
+        for (int s = 0; s < total; ++s) {
+            mul_step(s & 1);                                                // step s
+            write_step(S, (s + 1) & 1);                                     // step s + 1 (that buffer was read last in step s - 1, a barrier ago)
+            load_step(S);                                                   // step s + 2
+            __syncthreads();
+        }
+    }
+    // ---- the rank-one terms: acc(i, j) -= sigma ct_c alpha_c[rows of i] alpha_c[columns of j]^T (alpha: NaN for a failed class), the alphas of
+    //      a group of classes staged in the strip buffers ----
+    {
+        const int npad = 16 * NT;
+        float* al_s = reinterpret_cast<float*>(wres_smem);
+        const int cgrp = max(1, min(C, (2 * (NT + 1) * 1024) / (npad * 4)));
+        const float sgn_acc = (cursign == 0.0f) ? 1.0f : cursign;
+        for (int cb = 0; cb < C; cb += cgrp) {
+            const int cn = min(cgrp, C - cb);
+            __syncthreads();
+            for (int idx = tid; idx < cn * npad; idx += 256) {
+                const int c = idx / npad, r = idx - c * npad;
+                al_s[idx] = (r < N) ? a.alpha[((size_t)b * C + cb + c) * N + r] : 0.f;
+            }
+            __syncthreads();
+            int i0 = ti0, j0 = tj0;
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                if (j0 < c1) {
+                    for (int c = 0; c < cn; ++c) {
+                        const float aj = sgn_acc * ct_s[cb + c] * al_s[c * npad + 16 * j0 + c16];
+                        const f32x4 ai = *reinterpret_cast<const f32x4*>(al_s + c * npad + 16 * i0 + g4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[u][q] = __builtin_fmaf(-ai[q], aj, acc[u][q]);
+                    }
+                }
+                advance(i0, j0, 4);
+            }
+        }
+        const float fin = sgn_acc * unit_inv2;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) acc[u] *= fin;
+    }
+    // ---- store: tile (i, j) and its mirror (as the block-column kernel: a diagonal tile from its upper half only -> bitwise symmetric) ----
+    const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
+    {
+        int i = ti0, j = tj0;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            if (j < c1) {
+                const f32x4 v = acc[u];
+                const bool col_ok = 16 * j + c16 < N;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool row_ok = 16 * i + g4 + q < N && (i < j || g4 + q <= c16);
+                    bstore1(Wr, v[q], (row_ok && col_ok) ? ((16 * i + g4 + q) * N + 16 * j + c16) * 4 : OOB, 0);
+                    if (i == j) bstore1(Wr, v[q], (row_ok && col_ok && g4 + q < c16) ? ((16 * j + c16) * N + 16 * i + g4 + q) * 4 : OOB, 0);
+                }
+                if (i < j) bstore4(Wr, v, col_ok ? ((16 * j + c16) * N + 16 * i + g4) * 4 : OOB, 0);   // i < j <= NT - 1: 16 i + g4 + 3 < N
+            }
+            advance(i, j, 4);
+        }
+    }
+}
+constexpr int WRES_MAXT = 36;                    // accumulator tiles per wave: 144 VGPRs of the 256 a wave has at 2 workgroups per CU
+
+// column ranges of W with at most 4 MAXT tiles each (greedy from the left: NT = 27 -> [0,15) [15,22) [22,27), NT = 21 -> [0,16) [16,21))
+inline WRanges wres_ranges(const int NT) {
+    WRanges r;
+    r.ng = 0;
+    r.c0[0] = 0;
+    int cnt = 0;
+    for (int j = 0; j < NT; ++j) {
+        if (cnt + j + 1 > 4 * WRES_MAXT) { r.c0[++r.ng] = j; cnt = 0; }
+        cnt += j + 1;
+    }
+    r.c0[++r.ng] = NT;
+    return r;
+}
+
+int g_tiled_wres = -1;
+inline bool tiled_wres() {
+    if (g_tiled_wres < 0) {
+        const char* v = getenv("DKT_MLL_TILED_WRES");
+        g_tiled_wres = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_tiled_wres != 0;
+}
+
 int g_tiled_f16 = -1;
 inline bool tiled_f16() {
     if (g_tiled_f16 < 0) {
@@ -725,7 +989,16 @@ inline size_t tiled_ws_floats(int Bc, int C, int N) {
     const size_t gen = dkt_mll_generic_global_floats(Bc, N);               // the fix-up pass works in the same region
     return fl > gen ? fl : gen;
 }
-constexpr int TILED_CHUNK = 1024;          // episodes per pass over the workspace (N = 420, C = 20: 7.7 GB of tiles)
+constexpr int TILED_CHUNK_MAX = 1024;      // episodes per pass over the workspace (N = 420, C = 20: 7.7 GB of tiles): the workspace is sized for it
+int g_tiled_chunk = -1;
+inline int tiled_chunk_episodes() {        // DKT_MLL_TILED_CHUNK (measurement aid: <= 1024; a chunk whose tile arrays fit the 256-MB memory-side cache)
+    if (g_tiled_chunk < 0) {
+        const char* v = getenv("DKT_MLL_TILED_CHUNK");
+        const int c = v ? atoi(v) : TILED_CHUNK_MAX;
+        g_tiled_chunk = (c >= 1 && c <= TILED_CHUNK_MAX) ? c : TILED_CHUNK_MAX;
+    }
+    return g_tiled_chunk;
+}
 
 template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
@@ -742,7 +1015,16 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         // marginal likelihood -- one 8-wave workgroup per CU at 246 VGPRs hides less load latency than two independent 4-wave ones; the
         // kernel is latency-bound, not bandwidth-bound.
         const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
-        if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, dim3(64 * TB), 0, st, t);
+        if (tiled_f16() && tiled_wres() && t.a.C <= 64) {
+            const WRanges rg = wres_ranges(t.NT);
+            const size_t lds = (size_t)2 * (t.NT + 1) * 1024 + 3 * 64 * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 29 * 1024 + 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXT>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        } else if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, dim3(64 * TB), 0, st, t);
         else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, dim3(64 * TB), 0, st, t);
     } else {
         hipLaunchKernelGGL((tiled_invert_kernel<MC, false>), dim3(nmat), dim3(64 * TB), 0, st, t);
@@ -751,14 +1033,14 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 
 }  // namespace
 
-void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; }      // dkt_reload_env()
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
 }
 
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N) {
-    const int bc = B < TILED_CHUNK ? B : TILED_CHUNK;
+    const int bc = B < TILED_CHUNK_MAX ? B : TILED_CHUNK_MAX;
     return tiled_ws_floats(bc, C, N) * sizeof(float);
 }
 
@@ -767,7 +1049,7 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
     const int N = a.N, C = a.C;
     if (!workspace || ws_bytes < dkt_mll_tiled_workspace_bytes(a.B, C, N)) return DKT_ERR_WORKSPACE;
     const int NT = tiled_nt(N);
-    const int Bc = a.B < TILED_CHUNK ? a.B : TILED_CHUNK;
+    const int Bc = a.B < tiled_chunk_episodes() ? a.B : tiled_chunk_episodes();
     const size_t ntt = (size_t)NT * (NT + 1) / 2, nmat_max = (size_t)Bc * C;
     TiledArgs t;
     t.a = a;
@@ -791,7 +1073,7 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
         }
         // fix-up: episodes with a failed matrix are redone by the generic kernel with the jitter ladder (its global working
         // matrices reuse the tile region, which is dead by now)
-#ifndef DKT_TILED_CLOCKS
+#if !defined(DKT_TILED_CLOCKS) && !defined(DKT_TILED_NOMATH)
         MllArgs f = a;
         f.only_failed = a.info;
         dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);

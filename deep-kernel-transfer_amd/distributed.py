@@ -107,11 +107,14 @@ class GradBucket:
         if self._flat is not None:
             self._flat.zero_()
 
-    def allreduce_mean(self, flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    def allreduce_mean(self, flag: Optional[torch.Tensor] = None, force: bool = False) -> Optional[torch.Tensor]:
         """Average the gradients over the ranks.  `flag` (a 0-dim / 1-element tensor, e.g. max |info| of the step) rides in the
         same collective and comes back SUMMED over the ranks, so that every rank learns about a failure on any rank in the
-        same step (and raises together instead of leaving the others blocked in the next collective)."""
-        if not is_distributed() or not self.params:
+        same step (and raises together instead of leaving the others blocked in the next collective).
+        `force`: issue the collective even in a process group of ONE rank (bench.py's RCCL self-test on a 1-GPU box: the same
+        code path, launch and view aliasing as a multi-rank step; at world 1 it is otherwise skipped)."""
+        forced = force and dist.is_available() and dist.is_initialized()
+        if not (is_distributed() or forced) or not self.params:
             return flag
         flat = self._buffer()
         flat[self.numel] = flag.reshape(-1)[0].to(torch.float32) if flag is not None else 0.0

@@ -412,6 +412,26 @@ class DKT(MetaTemplate):
         loss, aux = self._episode_loss(z_train, y_targets)
         return loss, aux, z_train, False
 
+    def _bucket(self):
+        """The flat gradient bucket of the multi-rank step (None outside torch.distributed).  Every fp32 parameter's `.grad` is a VIEW of
+        it (`attach`), so the backward writes the bucket directly and the all-reduce needs no pack / unpack copies -- provided the
+        training loop clears the gradients with `zero_()` / `set_to_none=False` and masks in place, which `train_loop` does."""
+        if not distributed.is_distributed():
+            return None
+        if self._grad_bucket is None:
+            self._grad_bucket = distributed.GradBucket(self.parameters())
+        self._grad_bucket.attach()           # (re-attaches a gradient somebody replaced; a no-op when the views are in place)
+        return self._grad_bucket
+
+    def _zero_grads(self, optimizer):
+        """Start of a step: outside torch.distributed the reference's `optimizer.zero_grad()`; with ranks ONE fill of the flat bucket the
+        gradients are views of (set_to_none would drop the views and turn the all-reduce back into pack -> reduce -> scatter)."""
+        bucket = self._bucket()
+        if bucket is None:
+            optimizer.zero_grad()
+        else:
+            bucket.zero_()
+
     def _sync_grads(self, flag=None):
         """One all-reduce of the flat gradient bucket; `flag` (max |info| of this rank's step) is summed over the ranks in the
         same collective.  Returns the (global) flag."""
@@ -475,7 +495,7 @@ class DKT(MetaTemplate):
                 loss, aux, z_train, fused = graphed.run(x_all)
                 self._bad_steps = graphed.bad
             else:
-                optimizer.zero_grad()
+                self._zero_grads(optimizer)
                 loss, aux, z_train, fused = self._train_forward(x_all, y_targets, nb, n_ep, need_eval)
                 loss.backward()
                 # failure flag of the step (not positive definite after every jitter retry), kept on the device, summed over the
@@ -486,13 +506,15 @@ class DKT(MetaTemplate):
                 if fused_adam:
                     optimizer.found_inf = (bad != 0).to(torch.float32).reshape(())    # no NaN ever reaches the weights or Adam's moments
                 else:
-                    # the default (foreach) implementation has no device-side skip: zero the poisoned gradients instead -- the step then
-                    # only decays Adam's moments, no NaN reaches the weights -- (one [1]-sized mask multiply per tensor, no host sync)
-                    keep = (bad == 0).to(torch.float32)
+                    # the default (foreach) implementation has no device-side skip: the poisoned gradients are zeroed IN PLACE (the views
+                    # into the gradient bucket survive; no allocation, no host sync), so no NaN reaches the weights or the moments.  This
+                    # is NOT a skipped step: Adam still advances its step count, decays its moments and moves the weights by the existing
+                    # momentum -- only the fused path (found_inf) leaves the optimizer state untouched.
+                    failed = (bad != 0).reshape(())
                     for group in optimizer.param_groups:
                         for p_ in group['params']:
                             if p_.grad is not None:
-                                p_.grad = torch.where(keep.bool(), p_.grad, torch.zeros_like(p_.grad))
+                                p_.grad.masked_fill_(failed, 0.0)
                 optimizer.step()
             x_all = x_all[:n_ep]                          # the in-loop evaluation looks at the step's first episode
 

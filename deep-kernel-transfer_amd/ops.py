@@ -107,7 +107,8 @@ class _timed:
 # raw (non-differentiable) entry points
 # ------------------------------------------------------------------------------------------------
 _ENV_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_EP_MINB", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR",
-                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_F16")
+                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_F16",
+                 "DKT_GRAM_DIST_EP", "DKT_MLL_F32MFMA", "DKT_MLL_P2_GUARD", "DKT_MLL_TILED_CHUNK")
 _env_seen = None
 
 

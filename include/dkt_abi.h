@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DKT_ABI_VERSION 1
+#define DKT_ABI_VERSION 2 /* 2 (round 3-4): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA */
 
 /* status codes */
 #define DKT_OK 0
@@ -104,6 +104,12 @@ size_t dkt_mll_workspace_bytes(int B, int C, int N);
  *        lengthscale / offset: one ExactGPLayer per class, methods/DKT.py:63-66, 352-365):  K_c = sv[c] * E[b,c] + noise[c] * I with
  *        E:[B,C,N,N], and W:[B,C,N,N] holds W[b,c] = cls_weight[c] * sv[c] * M_c = d obj_b / d E[b,c] per class.  One launch for all
  *        classes; N <= 111, without DKT_MLL_WANT_CHOL / DKT_MLL_FORCE_* (DKT_ERR_TOO_LARGE / DKT_ERR_BAD_ARG otherwise).
+ * Range contract of the default kernels for N <= 127 (scaled 2-way f16 splits on the f16 matrix pipe, 22 significand bits, fp32
+ *   accumulate): every K_c = sv[c] E + noise[c] I must satisfy |K_ij| <= max_i K_ii, which every positive semi-definite E (any Gram /
+ *   RBF / Matern / polynomial base matrix) does.  An E that violates it (not PSD, or user-supplied with off-diagonals beyond the
+ *   diagonal) can overflow the f16 planes: the matrix then reports info != 0 / NaN outputs -- loud, never a silently wrong value.
+ *   DKT_MLL_FORCE_F32MFMA (per call) or the environment variable DKT_MLL_F32MFMA=1 (process-wide, read at the first call and at
+ *   dkt_reload_env()) selects the exact-fp32 twin, which has no such contract.
  * Replaces: `loss = -self.mll(output, self.model.train_targets)` and its autograd backward
  *   (methods/DKT.py:161-163, 252-254; methods/DKT_regression.py:53-56): GPyTorch
  *   GaussianLikelihood.marginal + MultivariateNormal.log_prob + psd_safe_cholesky +

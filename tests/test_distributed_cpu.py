@@ -65,6 +65,40 @@ def _worker(rank, world, port, q):
             p_.grad = torch.full_like(p_, float(rank))
         flag = bucket.allreduce_mean(torch.tensor(3.0 if rank == 1 else 0.0))
         assert float(flag) == 3.0 and all(torch.allclose(p_.grad, torch.full_like(p_, (world - 1) / 2.0)) for p_ in bucket.params)
+        # the training loop's own step protocol (DKT._zero_grads / _sync_grads, dkt.py): gradients stay VIEWS of the flat bucket over
+        # the steps -- cleared by one fill, written by backward, reduced in place, masked in place -- so no step packs by copy
+        from dkt_amd.dkt import DKT
+
+        class Host(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.lin = torch.nn.Linear(6, 4)
+                self.raw = torch.nn.Parameter(torch.zeros(3))
+                self._grad_bucket = None
+            _bucket, _zero_grads, _sync_grads = DKT._bucket, DKT._zero_grads, DKT._sync_grads
+        torch.manual_seed(1)
+        host = Host()
+        opt = torch.optim.Adam(host.parameters(), lr=1e-2)
+        for step in range(3):
+            host._zero_grads(opt)
+            xb = torch.tensor(np.random.default_rng(10 * step + rank).standard_normal((5, 6)), dtype=torch.float32)
+            loss = (host.lin(xb) ** 2).mean() + (host.raw ** 2).sum() * (1.0 + rank)
+            loss.backward()
+            mine_w = host.lin.weight.grad.clone()
+            bad = host._sync_grads(torch.tensor(0.0))
+            assert float(bad) == 0.0
+            bkt = host._grad_bucket
+            assert bkt.copies_last == 0, (step, bkt.copies_last)
+            flat = bkt._flat
+            for p_ in bkt.params:
+                assert flat.data_ptr() <= p_.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+            # the reduced gradient is the mean over the ranks of what each rank's backward wrote
+            both_w = [torch.zeros_like(mine_w) for _ in range(world)]
+            dist.all_gather(both_w, mine_w)
+            assert torch.allclose(host.lin.weight.grad, sum(both_w) / world, atol=1e-6)
+            for p_ in host.parameters():
+                p_.grad.masked_fill_(torch.tensor(False), 0.0)          # the non-fused failure mask of train_loop: in place
+            opt.step()
         # BatchNorm running estimates averaged over the ranks before a checkpoint is written
         bn = torch.nn.BatchNorm1d(4)
         bn.running_mean.fill_(float(rank))

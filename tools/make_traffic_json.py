@@ -1,4 +1,4 @@
-"""Condense the per-config rocprofv3 summaries of tools/prof_all.sh (profiles/r03/<config>_summary.txt) into
+"""Condense the per-config rocprofv3 summaries of tools/prof_all.sh (profiles/r0N/<config>_summary.txt) into
 profiles/pmc_traffic.json: HBM-side bytes per launch of every ABI function of the step, per BASELINE config, which bench.py reports
 as `roofline.traffic`.
 
@@ -8,61 +8,102 @@ kernels: the result equals the algorithmic Z bytes to 0.02 %); WRITE_SIZE is use
 bytes).  An ABI function that launches several kernels per call (the tile-array marginal likelihood: etile + factor + invert + w +
 the fix-up launch) is the sum over its kernels, per call.
 
-usage: python tools/make_traffic_json.py profiles/r03 [profiles/pmc_traffic.json]"""
+Device kernel -> ABI function is an EXPLICIT table (KERNEL_TABLE): a kernel of this library that the table does not know and that moved
+more than 1 MB per dispatch aborts the run (round 3 matched by substrings and silently summed cfg0's `gram_small_bwd_kernel` into
+dkt_gram_f32).  Kernels of other libraries (torch element-wise glue) are ignored.
+
+usage: python tools/make_traffic_json.py profiles/r04 [profiles/pmc_traffic.json]"""
 import glob
 import json
 import os
 import re
 import sys
 
-src_dir = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03"
+src_dir = sys.argv[1] if len(sys.argv) > 1 else "profiles/r04"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
+
+# device kernel (name without namespace / template arguments / signature) -> ABI function of include/dkt_abi.h that launches it
+KERNEL_TABLE = {
+    # dkt_gram_f32
+    "gram_sym_ep_split_kernel": "dkt_gram_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_sym_tiles_split_kernel": "dkt_gram_f32",
+    "gram_sym_big_ep_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
+    # dkt_gram_bwd_f32
+    "gram_bwd_ep_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
+    "gram_bwd_rows_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_big_ep_kernel": "dkt_gram_bwd_f32", "gram_small_bwd_kernel": "dkt_gram_bwd_f32",
+    "gram_bwd_kernel": "dkt_gram_bwd_f32", "gram_bn_bwd_ep_kernel": "dkt_gram_bwd_f32",
+    # dkt_mll_f32
+    "mll_h2e_kernel": "dkt_mll_f32", "mll_h2_kernel": "dkt_mll_f32", "mll_mfma_kernel": "dkt_mll_f32", "mll_generic_kernel": "dkt_mll_f32",
+    "tiled_etile_kernel": "dkt_mll_f32", "tiled_factor_kernel": "dkt_mll_f32", "tiled_invert_kernel": "dkt_mll_f32", "tiled_w_kernel": "dkt_mll_f32",
+    "tiled_wres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
+    "big_trmv_kernel": "dkt_mll_f32", "big_finish_kernel": "dkt_mll_f32",
+    # the element-wise chain rules
+    "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",
+    "class_kernel_fwd": "dkt_class_kernel_f32", "class_kernel_bwd": "dkt_class_kernel_bwd_f32",
+    "predict_kernel": "dkt_predict_f32", "predict_var_kernel": "dkt_predict_var_f32",
+}
+OURS = re.compile(r"gram|mll_|tiled_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats")
+
+
+def short_name(kernel: str) -> str:
+    """`void (anonymous namespace)::gram_small_kernel<1, 2>(float const*, ...)` -> `gram_small_kernel<1, 2>`"""
+    k = kernel.strip()
+    if k.startswith("void "):
+        k = k[5:]
+    k = k.replace("(anonymous namespace)::", "")
+    depth, end = 0, len(k)
+    for idx, ch in enumerate(k):                       # cut the signature: the first '(' outside the template argument list
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = idx
+            break
+    return k[:end].strip()
 
 
 def abi_of(kernel: str):
-    k = kernel
-    if "rbf_bwd" in k:
-        return "dkt_rbf_bwd_f32"
-    if "sqdist_bwd" in k:
-        return "dkt_sqdist_bwd_f32"
-    if "gram_bwd" in k or "gram_bn_bwd" in k:
-        return "dkt_gram_bwd_f32"
-    if "gram_" in k:
-        return "dkt_gram_f32"
-    if any(t in k for t in ("mll_", "tiled_", "big_", "bgemm", "chol_inv")):
-        return "dkt_mll_f32"
-    return None
+    return KERNEL_TABLE.get(short_name(kernel).split("<")[0])
 
 
-res = {"unit": "bytes per launch (ABI call)", "correction": "FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read under-count, 16-byte-per-lane loads) + WRITE_SIZE KB x 1024",
-       "configs": {}}
-for path in sorted(glob.glob(os.path.join(src_dir, "*_summary.txt"))):
-    cfg = os.path.basename(path)[:-len("_summary.txt")]
-    episodes = None
-    per_kernel = {}                                    # kernel -> {counter: (dispatches, mean)}
-    for line in open(path):
-        if line.startswith("{") and "episodes_per_step_per_gpu" in line:
-            episodes = json.loads(line)["config"]["episodes_per_step_per_gpu"]
-        m = re.match(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches\s+(\d+)\s+mean\s+([0-9.e+-]+)", line)
-        if m:
-            per_kernel.setdefault(m.group(1).strip(), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
-    if episodes is None or not per_kernel:
-        continue
-    fn = {}
-    for kname, ctr in per_kernel.items():
-        f = abi_of(kname)
-        if f is None:
+def main():
+    res = {"unit": "bytes per launch (ABI call)",
+           "correction": "FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read under-count, 16-byte-per-lane loads) + WRITE_SIZE KB x 1024", "configs": {}}
+    for path in sorted(glob.glob(os.path.join(src_dir, "*_summary.txt"))):
+        cfg = os.path.basename(path)[:-len("_summary.txt")]
+        episodes = None
+        per_kernel = {}                                    # kernel -> {counter: (dispatches, mean)}
+        for line in open(path):
+            if line.startswith("{") and "episodes_per_step_per_gpu" in line:
+                episodes = json.loads(line)["config"]["episodes_per_step_per_gpu"]
+            m = re.match(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches\s+(\d+)\s+mean\s+([0-9.e+-]+)", line)
+            if m:
+                per_kernel.setdefault(m.group(1).strip(), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
+        if episodes is None or not per_kernel:
             continue
-        d = fn.setdefault(f, {"kernels": {}, "calls": None})
-        disp = max(v[0] for v in ctr.values())
-        d["kernels"][kname] = {"dispatches": disp, "fetch_kb_mean": ctr.get("FETCH_SIZE", (0, 0.0))[1], "write_kb_mean": ctr.get("WRITE_SIZE", (0, 0.0))[1]}
-    kernels = {}
-    for f, d in fn.items():
-        calls = min(k["dispatches"] for k in d["kernels"].values())
-        fetch = sum(k["fetch_kb_mean"] * k["dispatches"] for k in d["kernels"].values()) / calls * 1024.0 * 2.0
-        write = sum(k["write_kb_mean"] * k["dispatches"] for k in d["kernels"].values()) / calls * 1024.0
-        kernels[f] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "calls_in_profile": calls,
-                      "device_kernels": sorted(k.split("(")[0][:70] for k in d["kernels"])}
-    res["configs"][cfg] = {"episodes_per_launch": episodes, "source": path, "kernels": kernels}
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({c: {k: round(v["hbm_bytes"] / 1e9, 3) for k, v in d["kernels"].items()} for c, d in res["configs"].items()}, indent=1))
+        fn = {}
+        for kname, ctr in per_kernel.items():
+            f = abi_of(kname)
+            kb = sum(v[1] for v in ctr.values())
+            if f is None:
+                if OURS.search(kname) and kb > 1024.0:
+                    raise SystemExit("make_traffic_json: %s: kernel `%s` (%.1f MB per dispatch) is not in KERNEL_TABLE" % (path, short_name(kname), kb / 1024.0))
+                continue
+            d = fn.setdefault(f, {"kernels": {}})
+            disp = max(v[0] for v in ctr.values())
+            d["kernels"][short_name(kname)] = {"dispatches": disp, "fetch_kb_mean": ctr.get("FETCH_SIZE", (0, 0.0))[1], "write_kb_mean": ctr.get("WRITE_SIZE", (0, 0.0))[1]}
+        kernels = {}
+        for f, d in fn.items():
+            calls = min(k["dispatches"] for k in d["kernels"].values())      # ABI calls in the profile (every kernel of the function runs once per call and chunk)
+            fetch = sum(k["fetch_kb_mean"] * k["dispatches"] for k in d["kernels"].values()) / calls * 1024.0 * 2.0
+            write = sum(k["write_kb_mean"] * k["dispatches"] for k in d["kernels"].values()) / calls * 1024.0
+            kernels[f] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "calls_in_profile": calls,
+                          "device_kernels": {n_: {"dispatches": k["dispatches"], "fetch_bytes": k["fetch_kb_mean"] * 2048.0, "write_bytes": k["write_kb_mean"] * 1024.0}
+                                             for n_, k in sorted(d["kernels"].items())}}
+        res["configs"][cfg] = {"episodes_per_launch": episodes, "source": path, "kernels": kernels}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({c: {k: round(v["hbm_bytes"] / 1e9, 3) for k, v in d["kernels"].items()} for c, d in res["configs"].items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
