@@ -90,7 +90,7 @@ def _cpu_worker(job):
     """One host process = one core: single-threaded torch, B = 1 sequential training episodes (the way the reference runs them) of the
     same synthetic workload, counted inside wall-clock windows that every worker shares (so the sum over the workers is a rate all
     cores sustained AT THE SAME TIME)."""
-    wid, n, d, n_way, raw_s, mean, t_open, windows, window_s = job
+    wid, n, d, n_way, raw_s, mean, t_open_v, ready_q, windows, window_s = job
     import torch as _t
     _t.set_num_threads(1)
     from oracle import dkt_oracle_torch as T
@@ -102,10 +102,16 @@ def _cpu_worker(job):
     def episode(i):
         zi = z[i % z.shape[0]].clone().requires_grad_(True)
         T.cpu_baseline_train_episode(zi, n_way, raw_s.clone().requires_grad_(True), mean.clone().requires_grad_(True))
-    i = 0
-    while time.time() < t_open:                  # warm-up until the first window opens
+    for i in range(3):
+        episode(i)
+    ready_q.put(wid)                             # imported, warmed up: the parent opens the windows once every worker said so
+    i = 3
+    while t_open_v.value == 0.0 or time.time() < t_open_v.value:      # keep running (warm) until the first window opens
         episode(i)
         i += 1
+        if t_open_v.value < 0.0:
+            return []
+    t_open = t_open_v.value
     counts = []
     for wdw in range(windows):
         t_end = t_open + (wdw + 1) * window_s
@@ -159,15 +165,27 @@ def cpu_baseline(z_cpu, n_way, raw_s, mean, warm=20, timed=200, repeats=5, windo
             import multiprocessing as mp
             ctx = mp.get_context("spawn")
             n, d = int(z_cpu.shape[1]), int(z_cpu.shape[2])
-            t_open = time.time() + 15.0                      # every worker has imported torch and warmed up by then
-            jobs = [(w, n, d, n_way, raw_s.tolist(), mean.tolist(), t_open, windows, window_s) for w in range(phys)]
-            q = ctx.Queue()
+            t_open_v = ctx.Value("d", 0.0)
+            q, ready_q = ctx.Queue(), ctx.Queue()
+            jobs = [(w, n, d, n_way, raw_s.tolist(), mean.tolist(), t_open_v, ready_q, windows, window_s) for w in range(phys)]
             procs = [ctx.Process(target=_cpu_worker_entry, args=(j, q), daemon=True) for j in jobs]
             for pr in procs:
                 pr.start()
-            deadline = t_open + windows * window_s + 30.0
             counts = []
             try:
+                t_lim = time.time() + 90.0                   # every worker imports torch first: the windows open when ALL of them are warm
+                nready = 0
+                while nready < phys and time.time() < t_lim:
+                    try:
+                        ready_q.get(timeout=1.0)
+                        nready += 1
+                    except Exception:  # noqa: BLE001 -- queue.Empty
+                        pass
+                if nready < phys:
+                    t_open_v.value = -1.0
+                    raise RuntimeError("only %d of %d baseline processes came up within 90 s" % (nready, phys))
+                t_open_v.value = time.time() + 1.0
+                deadline = t_open_v.value + windows * window_s + 30.0
                 while len(counts) < phys:
                     counts.append(q.get(timeout=max(1.0, deadline - time.time())))
             finally:                                         # (never a hang: whatever has not answered by the deadline is killed)
@@ -256,9 +274,10 @@ def _workload(cfg, b, dev, rank, unit_rows):
         # QMUL regression head (DKT_regression.py:45-64): one GP per task on Conv3 features [19, 2916], RBF kernel, learned noise;
         # features ~ ReLU-like non-negative activations, targets = head-pose angles scaled to [-1, 1] per task ([B, 1, N])
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        z = (torch.randn(b, n, d, generator=g, device=dev).abs() * 0.3).contiguous().requires_grad_(True)
+        z = (torch.randn(b, n, d, generator=g, device=dev).abs() * 0.35).contiguous().requires_grad_(True)
         y = (torch.rand(b, 1, n, generator=g, device=dev) * 2.0 - 1.0).contiguous()
-        raw_ls = torch.tensor([2.5], device=dev, requires_grad=True)           # lengthscale = softplus(raw) ~ 2.58
+        raw_ls = torch.tensor([11.0], device=dev, requires_grad=True)          # lengthscale = softplus(raw) ~ 11: off-diagonal kernel values ~ 0.3 at this
+                                                                               # feature scale (round 3 ran 2.58: E = I to 6e-7, a degenerate task)
         raw_nz = torch.tensor([0.0], device=dev, requires_grad=True)           # GaussianLikelihood default: noise = softplus(0) + 1e-4
         cw = torch.full((1,), -1.0 / n, device=dev)
         params = [raw_s, mean, raw_ls, raw_nz]

@@ -733,20 +733,22 @@ __global__ __launch_bounds__(64 * WB, WB == 4 ? DKT_TILED_W_WGS : 2) void tiled_
 // W[b] = sum_c coef_c M_c^T M_c - (rank-one terms) is a SYRK over the "strips" of M: strip k of class c = the tiles M_k0 .. M_kk (slots (i, k),
 // i <= k), and W_ij += strip_k[i]^T strip_k[j] for every i <= j <= k.  The block-column kernel re-reads every strip once per block column of
 // W (1229 tile reads per class matrix at NT = 27 for 378 distinct tiles; its traffic-only build, DKT_TILED_NOMATH, takes 4.75 of its 6.05 ms:
-// profiles/r04/v0_tiled_traffic_ceiling.txt).  Here a workgroup of 4 waves keeps a COLUMN RANGE [c0, c1) of W -- up to 4 MAXT accumulator tiles,
-// i.e. a whole third of W at NT = 27 -- in registers for the whole (class, k) stream, so a strip is read once per range that needs it
-// (k >= c0, tiles i < c1: 668 tile reads per class matrix for the three ranges [0,15) [15,22) [22,27)), split ONCE while it is staged
-// (fp32 tile -> registers -> scaled 2-way f16 split with the class weight folded in -> LDS), and every product takes both operands from
-// that LDS image: D += A^T B = 3 x v_mfma_f32_16x16x16_f16 on two ds_read_b128.  The strips are double-buffered in LDS (2 x NT KB), the
-// global loads of step s + 2 fly while step s is multiplied; one barrier per step.
-// Wave w of a range owns its tiles t = w, w + 4, ... in column-major order (t -> (i, j): column j holds the tiles i = 0 .. j): the tile
-// coordinates are wave-uniform scalars advanced on the SALU, the accumulator index is static.
+// profiles/r04/v0_tiled_traffic_ceiling.txt).  Here a workgroup of 4 waves keeps a COLUMN RANGE [c0, c1) of W -- a third of W at NT = 27 --
+// in registers for the whole (class, k) stream, so a strip is read once per range that needs it (k >= c0, tiles i < c1: 664 tile reads per
+// class matrix for the three ranges [0,16) [16,22) [22,27)), split ONCE while it is staged (fp32 tile -> registers -> scaled 2-way f16 split
+// with the class weight folded in -> LDS), and every product takes both operands from that LDS image.
+// Register blocking (v3; the first two versions loaded both operands per product: 14 scalar / vector / LDS instructions per MFMA, the matrix pipe
+// 23 % busy, profiles/r04/v1_wres_pmc.txt): a wave owns CHUNKS of 4 tile rows x 2 tile columns, so a chunk's 8 products = 24 MFMAs take 6
+// ds_read_b128 (two addresses + immediate offsets) and ~12 scalar instructions.  A chunk that straddles the diagonal also computes its tiles
+// below the diagonal (never stored); their operands may lie beyond the strip (stale LDS): garbage stays in those accumulators.
+// The strips are double-buffered in LDS, the global loads of step s + 2 fly while step s is multiplied; one barrier per step, and a step stages
+// a GROUP of consecutive strips that fills a buffer (short strips share a step).
 // Scales as in the block-column kernel (|M_c| <= 2^msc_c / sqrt(noise_c); U = one power-of-two unit per episode), but both operands now
 // come from ONE image scaled by g_c U, g_c = sqrt|coef_c|, so the sign of coef_c cannot ride in an operand: the accumulators hold
 // sigma U^2 sum_c coef_c M_c^T M_c and are negated when a class changes sigma (class weights of one sign: never).
-struct WRanges { int ng; int c0[6]; };           // column ranges [c0[g], c0[g + 1]) of W, g < ng
+struct WRanges { int ng; int c0[10]; };          // column ranges [c0[g], c0[g + 1]) of W, g < ng
 
-template <int MAXT>
+template <int MAXC>
 __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges rg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wres_smem[];
     const MllArgs& a = t.a;
@@ -762,9 +764,10 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
-    // LDS: [2][NT + 1] split tiles of 1 KB (tile NT of each buffer: all zero) | q[C] | sg[C] | ct[C]
+    // LDS: [2][32] split tiles of 1 KB (28 slots for a step's group of strips + 4 that a diagonal chunk may read past it) | q[C] | sg[C] | ct[C]
+    constexpr int NST = 7, GT = 4 * NST, BUFT = GT + 4;                     // staged tiles per wave and step; tile slots per group; per buffer
     f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
-    float* q_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * (NT + 1) * 1024);
+    float* q_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * BUFT * 1024);
     float* sg_s = q_s + 64;
     float* ct_s = sg_s + 64;
     const brsrc Tr = mk_rsrc(t.tiles + (size_t)bl * C * (ntt + 1) * 256, (unsigned)((size_t)C * (ntt + 1) * 1024));
@@ -794,113 +797,189 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         }
         __syncthreads();
     }
-    // this wave's tiles: t = w + 4u in column-major order over the columns [c0, c1)
-    auto advance = [](int& i, int& j, const int n) {
-        i += n;
-        while (i > j) { i -= j + 1; ++j; }
-    };
-    int ti0 = 0, tj0 = c0;
-    advance(ti0, tj0, w);
-    f32x4 acc[MAXT];
+    // this wave's chunks: the chunks of the range in column-pair-major order -- pair (j0, j0 + 1), j0 = c0, c0 + 2, ..., rows i0 = 0, 4, ... <= j0 + 1 --
+    // dealt round-robin to the 4 waves; chunk u of the wave = chunk number w + 4 u.  Packed i0 | j0 << 8 in SGPRs for the whole kernel; a slot past
+    // the end of the list gets j0 = 255 (it never takes part).
+    int tc[MAXC];
+    {
+        int i0 = 0, j0 = c0;
+        auto step1 = [&]() {                                                // next chunk in the enumeration
+            i0 += 4;
+            if (i0 > j0 + 1) { i0 = 0; j0 += 2; }
+        };
+        for (int x = 0; x < w; ++x) step1();
 #pragma unroll
-    for (int u = 0; u < MAXT; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < MAXC; ++u) {
+            tc[u] = (j0 < c1) ? (i0 | (j0 << 8)) : (255 << 8);
+            step1(); step1(); step1(); step1();
+        }
+    }
+    f32x4 acc[MAXC][8];                                                     // [chunk][4 rows x 2 columns: index 2 x + y]
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[u][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 keep;                                                             // rows of the last tile row that are real rows of M (the augmented row
 #pragma unroll                                                              // -alpha^T and the identity padding below it are zeroed: the rank-one terms
     for (int q = 0; q < 4; ++q) keep[q] = (g4 + q < pN) ? 1.0f : 0.0f;      // are added at the end, the padding only reaches padded entries of W)
-    constexpr int NST = 7;                                                  // staged tiles per wave and step (NT <= 28)
-    const int nk = NT - c0, total = C * nk;
-    int lc = 0, lk = c0;                                                    // load cursor (class, strip)
-    auto load_step = [&](f32x4 (&S)[NST]) {
-        const int cbase = min(lc, C - 1) * (int)(ntt + 1), k = lk;
-        const bool in = lc < C;
-        const int lim = min(k + 1, c1);
-#pragma unroll
-        for (int x = 0; x < NST; ++x) {
-            const int i = w + 4 * x;
-            S[x] = bload4(Tr, (in && i < lim) ? lane16 : OOB, (cbase + ((i < lim) ? tslot(NT, i, k) : 0)) * 1024);
-        }
-        if (++lk == NT) { lk = c0; ++lc; }
+    // A STEP stages a GROUP of consecutive strips [ka, kb) of one class -- as many as fit the GT tile slots of an LDS buffer (short strips
+    // share a step), so that every step has enough products to cover the flight time of the next group's loads and there are fewer barriers.
+    auto lim = [&](const int k) { return min(k + 1, c1); };                 // tiles of strip k this range needs
+    auto group_end = [&](const int ka) {
+        int cnt = 0, kb = ka;
+        while (kb < NT && cnt + lim(kb) <= GT) { cnt += lim(kb); ++kb; }
+        return kb;
     };
-    int wc = 0, wk = c0;                                                    // split / LDS-write cursor
-    auto write_step = [&](const f32x4 (&S)[NST], const int bufi) {
-        const float q = q_s[min(wc, C - 1)];
-        const bool lastk = wk == NT - 1;
-        const int lim = min(wk + 1, c1);
+    int steps_per_class = 0;
+    for (int ka = c0; ka < NT; ka = group_end(ka)) ++steps_per_class;
+    const int total = C * steps_per_class;
+    // The groups repeat class after class, so everything a step needs to know about its group is tabulated ONCE, in the lanes of a few VGPRs
+    // (lane L = group L of a class; one v_readlane per use): gtab = ka | kb << 8, and per staged tile x of this wave (tile w + 4 x of the group)
+    // stab[x] = tile slot of (strip k, tile i) in the matrix' tile array | last strip << 12 | valid << 13.  (The first versions walked the
+    // strips with scalar loops in every step: 45 % of the kernel, profiles/r04/v2_wres_phase_clocks.log.)
+    struct Grp { int c, gi; };
+    int gtab, stab[NST];
+    {
+        int ka = c0, kb = group_end(c0);
+        for (int tstep = 0; tstep < lane && tstep < steps_per_class; ++tstep) { ka = kb; kb = ka < NT ? group_end(ka) : ka; }
+        const bool gvalid = lane < steps_per_class;
+        gtab = ka | (kb << 8);
 #pragma unroll
         for (int x = 0; x < NST; ++x) {
-            const int i = w + 4 * x;
-            if (i < lim) sbuf[(bufi * (NT + 1) + i) * 64 + lane] = split_h2(lastk ? S[x] * keep : S[x], q);
+            int k = ka, i = w + 4 * x;
+            while (k < kb && i >= lim(k)) { i -= lim(k); ++k; }
+            const bool ok = gvalid && k < kb;
+            stab[x] = ok ? (tslot(NT, i, k) | ((k == NT - 1) ? 0x1000 : 0) | 0x2000) : 0;
         }
-        if (++wk == NT) { wk = c0; ++wc; }
+    }
+    auto next_group = [&](const Grp gcur) {
+        Grp n;
+        n.c = gcur.c; n.gi = gcur.gi + 1;
+        if (n.gi >= steps_per_class) { n.gi = 0; ++n.c; }
+        return n;
+    };
+    auto load_step = [&](f32x4 (&S)[NST], const Grp gr) {
+        const int cbase = min(gr.c, C - 1) * (int)(ntt + 1);
+        const bool in = gr.c < C;
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
+            S[x] = bload4(Tr, (in && (e & 0x2000)) ? lane16 : OOB, (cbase + (e & 0xfff)) * 1024);
+        }
+    };
+    auto write_step = [&](const f32x4 (&S)[NST], const Grp gr, const int bufi) {
+        const float q = q_s[min(gr.c, C - 1)];
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
+            if (e & 0x2000) {
+                f32x4 v = S[x];
+                if (e & 0x1000) v *= keep;
+                sbuf[(bufi * BUFT + w + 4 * x) * 64 + lane] = split_h2(v, q);
+            }
+        }
     };
     float cursign = 0.0f;
-    int mc_ = 0, mk = c0;                                                   // multiply cursor
-    auto mul_step = [&](const int bufi) {
-        const int k = mk;
-        if (k == c0) {                                                      // a new class: its sign against the accumulators'
-            const float sgc = sg_s[min(mc_, C - 1)];
+    auto mul_step = [&](const Grp gr, const int bufi) {
+        const int gk = __builtin_amdgcn_readlane(gtab, gr.gi), gka = gk & 255, gkb = gk >> 8;
+        if (gr.gi == 0) {                                                   // a new class: its sign against the accumulators'
+            const float sgc = sg_s[min(gr.c, C - 1)];
             if (sgc != 0.0f && sgc != cursign) {
                 if (cursign != 0.0f) {
 #pragma unroll
-                    for (int u = 0; u < MAXT; ++u) acc[u] = -acc[u];
+                    for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[u][e] = -acc[u][e];
                 }
                 cursign = sgc;
             }
         }
-        const f32x4* sb = sbuf + bufi * (NT + 1) * 64 + lane;
-        int ii = ti0, jj = tj0;
-        asm volatile("" : "+s"(ii), "+s"(jj));                              // (opaque: otherwise the 2 MAXT tile coordinates are hoisted out of the step loop -- and spilled)
-        // a tile (i, j) takes part in step k when j <= k; the wave's tiles are column-major, so the participants are a prefix of its list, and the
-        // tiles past the end of its list have j >= c1: one test, j <= min(k, c1 - 1).  Four tiles per block (four independent accumulator chains,
-        // eight ds_read_b128 in flight); a block's tiles beyond the prefix read the buffer's all-zero tile.
-        const int kk = min(k, c1 - 1), zt = NT;
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(sbuf) + bufi * BUFT * 1024 + lane16;
+        int sbase = 0;
+        for (int k = gka; k < gkb; ++k) {
+            // column j takes part in strip k when j <= k; the chunks are column-pair-major, so the participants are a prefix of the wave's list
+            const int kk = min(k, c1 - 1);
 #pragma unroll
-        for (int u = 0; u < MAXT; u += 4) {
-            int ti[4], tj[4];
+            for (int u = 0; u < MAXC; ++u) {
+                int p = tc[u];
+                asm volatile("" : "+s"(p));                                 // (opaque: keeps the unpacked coordinates from being hoisted out of the loops -- and spilled)
+                const int j0 = p >> 8;
+                if (j0 <= kk) {
+                    const unsigned char* pa = sb + (sbase + (p & 255)) * 1024;
+                    const unsigned char* pb = sb + (sbase + j0) * 1024;
+                    f32x4 A[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                ti[x] = ii; tj[x] = jj;
-                advance(ii, jj, 4);
-            }
-            if (tj[0] <= kk) {
-                f32x4 A[4], Bt[4];
+                    for (int x = 0; x < 4; ++x) A[x] = *reinterpret_cast<const f32x4*>(pa + x * 1024);
+                    const f32x4 B0 = *reinterpret_cast<const f32x4*>(pb);
+                    if (j0 + 1 <= kk) {
+                        const f32x4 B1 = *reinterpret_cast<const f32x4*>(pb + 1024);
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const bool ok = tj[x] <= kk;
-                    A[x] = sb[(ok ? ti[x] : zt) * 64];
-                    Bt[x] = sb[(ok ? tj[x] : zt) * 64];
+                        for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<0>(A[x], B0, acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<0>(A[x], B1, acc[u][2 * x + 1]); }
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<1>(A[x], B0, acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<1>(A[x], B1, acc[u][2 * x + 1]); }
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<2>(A[x], B0, acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<2>(A[x], B1, acc[u][2 * x + 1]); }
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<0>(A[x], B0, acc[u][2 * x]);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<1>(A[x], B0, acc[u][2 * x]);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<2>(A[x], B0, acc[u][2 * x]);
+                    }
                 }
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<0>(A[x], Bt[x], acc[u + x]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<1>(A[x], Bt[x], acc[u + x]);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (u + x < MAXT) acc[u + x] = xtyh1<2>(A[x], Bt[x], acc[u + x]);
             }
+            sbase += lim(k);
         }
-        if (++mk == NT) { mk = c0; ++mc_; }
     };
     {
         // one staging array: the loads of step s + 2 are issued right after step s + 1 went to LDS and fly during the barrier and step s + 1's products
         f32x4 S[NST];
-        if (w < 2) sbuf[(w * (NT + 1) + NT) * 64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        load_step(S);
-        write_step(S, 0);
-        load_step(S);
+        Grp gA{0, 0};                                                       // the group being multiplied
+        Grp gB = next_group(gA), gC = next_group(gB);                       // ... being split into LDS, ... being loaded
+        load_step(S, gA);
+        write_step(S, gA, 0);
+        load_step(S, gB);
         __syncthreads();
+#ifdef DKT_WRES_CLOCKS      // measurement build (tools/wres_phase_clocks.py): shader clocks of this wave per phase, summed over the steps
+        unsigned long long ck[5] = {0, 0, 0, 0, 0}, tk0 = __builtin_amdgcn_s_memtime();
+#define WCLK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); ck[i] += tk1 - tk0; tk0 = tk1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WCLK(i) do { } while (0)
+#endif
         for (int s = 0; s < total; ++s) {
-            mul_step(s & 1);                                                // step s
-            write_step(S, (s + 1) & 1);                                     // step s + 1 (that buffer was read last in step s - 1, a barrier ago)
-            load_step(S);                                                   // step s + 2
+            mul_step(gA, s & 1);                                            // step s
+#ifdef DKT_WRES_CLOCKS
+            __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): the step's LDS reads are back (its MFMAs may still run)
+#endif
+            WCLK(0);
+#ifdef DKT_WRES_CLOCKS
+            __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);                    // vmcnt(0): how long the staged loads still needed
+#endif
+            WCLK(1);
+            write_step(S, gB, (s + 1) & 1);                                 // step s + 1 (that buffer was read last in step s - 1, a barrier ago)
+            WCLK(2);
+            load_step(S, gC);                                               // step s + 2
+            gA = gB; gB = gC; gC = next_group(gC);
+            WCLK(3);
             __syncthreads();
+            WCLK(4);
         }
+#ifdef DKT_WRES_CLOCKS
+        if (lane == 0 && w == 0 && a.dnoise) {                              // wave 0 of range gi -> slot (b, gi) of the per-class outputs
+            const size_t o = (size_t)b * C + gi;
+            a.logp[o] = (float)ck[0]; a.dsv[o] = (float)ck[1]; a.dmean[o] = (float)ck[2]; a.dnoise[o] = (float)ck[3]; a.jitter_used[o] = (float)ck[4];
+        }
+#endif
     }
+    // a tile of a chunk is real when it lies on or above the diagonal, inside the range
+    auto real_tile = [&](const int i, const int j) { return i <= j && j < c1; };
     // ---- the rank-one terms: acc(i, j) -= sigma ct_c alpha_c[rows of i] alpha_c[columns of j]^T (alpha: NaN for a failed class), the alphas of
     //      a group of classes staged in the strip buffers ----
     {
         const int npad = 16 * NT;
         float* al_s = reinterpret_cast<float*>(wres_smem);
-        const int cgrp = max(1, min(C, (2 * (NT + 1) * 1024) / (npad * 4)));
+        const int cgrp = max(1, min(C, (2 * BUFT * 1024) / (npad * 4)));
         const float sgn_acc = (cursign == 0.0f) ? 1.0f : cursign;
         for (int cb = 0; cb < C; cb += cgrp) {
             const int cn = min(cgrp, C - cb);
@@ -910,56 +989,72 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
                 al_s[idx] = (r < N) ? a.alpha[((size_t)b * C + cb + c) * N + r] : 0.f;
             }
             __syncthreads();
-            int i0 = ti0, j0 = tj0;
 #pragma unroll
-            for (int u = 0; u < MAXT; ++u) {
+            for (int u = 0; u < MAXC; ++u) {
+                const int i0 = tc[u] & 255, j0 = tc[u] >> 8;
                 if (j0 < c1) {
                     for (int c = 0; c < cn; ++c) {
-                        const float aj = sgn_acc * ct_s[cb + c] * al_s[c * npad + 16 * j0 + c16];
-                        const f32x4 ai = *reinterpret_cast<const f32x4*>(al_s + c * npad + 16 * i0 + g4);
+                        const float sct = sgn_acc * ct_s[cb + c];
+                        float aj[2];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[u][q] = __builtin_fmaf(-ai[q], aj, acc[u][q]);
+                        for (int y = 0; y < 2; ++y) aj[y] = (j0 + y < NT) ? sct * al_s[c * npad + 16 * (j0 + y) + c16] : 0.f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            if (i0 + x < NT) {
+                                const f32x4 ai = *reinterpret_cast<const f32x4*>(al_s + c * npad + 16 * (i0 + x) + g4);
+#pragma unroll
+                                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) acc[u][2 * x + y][q] = __builtin_fmaf(-ai[q], aj[y], acc[u][2 * x + y][q]);
+                            }
+                        }
                     }
                 }
-                advance(i0, j0, 4);
             }
         }
         const float fin = sgn_acc * unit_inv2;
 #pragma unroll
-        for (int u = 0; u < MAXT; ++u) acc[u] *= fin;
+        for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[u][e] *= fin;
     }
     // ---- store: tile (i, j) and its mirror (as the block-column kernel: a diagonal tile from its upper half only -> bitwise symmetric) ----
     const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
-    {
-        int i = ti0, j = tj0;
 #pragma unroll
-        for (int u = 0; u < MAXT; ++u) {
-            if (j < c1) {
-                const f32x4 v = acc[u];
-                const bool col_ok = 16 * j + c16 < N;
+    for (int u = 0; u < MAXC; ++u) {
+        const int i0 = tc[u] & 255, j0 = tc[u] >> 8;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool row_ok = 16 * i + g4 + q < N && (i < j || g4 + q <= c16);
-                    bstore1(Wr, v[q], (row_ok && col_ok) ? ((16 * i + g4 + q) * N + 16 * j + c16) * 4 : OOB, 0);
-                    if (i == j) bstore1(Wr, v[q], (row_ok && col_ok && g4 + q < c16) ? ((16 * j + c16) * N + 16 * i + g4 + q) * 4 : OOB, 0);
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int i = i0 + x, j = j0 + y;
+                if (real_tile(i, j)) {                                      // uniform
+                    const f32x4 v = acc[u][2 * x + y];
+                    const bool col_ok = 16 * j + c16 < N;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool row_ok = 16 * i + g4 + q < N && (i < j || g4 + q <= c16);
+                        bstore1(Wr, v[q], (row_ok && col_ok) ? ((16 * i + g4 + q) * N + 16 * j + c16) * 4 : OOB, 0);
+                        if (i == j) bstore1(Wr, v[q], (row_ok && col_ok && g4 + q < c16) ? ((16 * j + c16) * N + 16 * i + g4 + q) * 4 : OOB, 0);
+                    }
+                    if (i < j) bstore4(Wr, v, col_ok ? ((16 * j + c16) * N + 16 * i + g4) * 4 : OOB, 0);   // i < j <= NT - 1: 16 i + g4 + 3 < N
                 }
-                if (i < j) bstore4(Wr, v, col_ok ? ((16 * j + c16) * N + 16 * i + g4) * 4 : OOB, 0);   // i < j <= NT - 1: 16 i + g4 + 3 < N
             }
-            advance(i, j, 4);
-        }
     }
 }
-constexpr int WRES_MAXT = 36;                    // accumulator tiles per wave: 144 VGPRs of the 256 a wave has at 2 workgroups per CU
+constexpr int WRES_MAXC = 5;                     // chunks (of 8 accumulator tiles) per wave: 160 VGPRs of the 256 a wave has at 2 workgroups per CU
 
-// column ranges of W with at most 4 MAXT tiles each (greedy from the left: NT = 27 -> [0,15) [15,22) [22,27), NT = 21 -> [0,16) [16,21))
+// column ranges of W with at most 4 MAXC chunks each, cut at even distances from the start of a range (a chunk is a PAIR of columns):
+// NT = 27 -> [0,16) [16,22) [22,27); NT = 21 -> [0,16) [16,21)
 inline WRanges wres_ranges(const int NT) {
     WRanges r;
     r.ng = 0;
     r.c0[0] = 0;
     int cnt = 0;
-    for (int j = 0; j < NT; ++j) {
-        if (cnt + j + 1 > 4 * WRES_MAXT) { r.c0[++r.ng] = j; cnt = 0; }
-        cnt += j + 1;
+    for (int j0 = 0; j0 < NT; j0 += 2) {                                    // j0 - c0 is even: the pairs restart with every range
+        const int ch = (j0 + 1) / 4 + 1;                                    // chunks of the pair (j0, j0 + 1): rows i0 = 0, 4, ... <= j0 + 1
+        if (cnt + ch > 4 * WRES_MAXC) { r.c0[++r.ng] = j0; cnt = 0; }
+        cnt += ch;
     }
     r.c0[++r.ng] = NT;
     return r;
@@ -1017,13 +1112,13 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
         if (tiled_f16() && tiled_wres() && t.a.C <= 64) {
             const WRanges rg = wres_ranges(t.NT);
-            const size_t lds = (size_t)2 * (t.NT + 1) * 1024 + 3 * 64 * sizeof(float);
+            const size_t lds = (size_t)2 * 32 * 1024 + 3 * 64 * sizeof(float);
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 29 * 1024 + 1024);
+                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
                 attr_set = true;
             }
-            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXT>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         } else if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, dim3(64 * TB), 0, st, t);
         else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, dim3(64 * TB), 0, st, t);
     } else {

@@ -1118,11 +1118,11 @@ def test_bench_batch_cfg0_regression_head_vs_oracle(cuda):
     bench.py makes (ops.base_matrix -> ops.mll_objective), against O.regression_episode on sampled tasks; bitwise determinism."""
     b, n, d = 1024, 19, 2916
     g = torch.Generator(device="cpu").manual_seed(99)
-    z = (torch.randn(b, n, d, generator=g).abs() * 0.3).to(cuda).requires_grad_(True)
+    z = (torch.randn(b, n, d, generator=g).abs() * 0.35).to(cuda).requires_grad_(True)      # the fixture's feature scale (make_golden.cfg0_features)
     yb = (torch.rand(b, 1, n, generator=g) * 2.0 - 1.0).to(cuda)
     sv = torch.tensor([0.8], device=cuda, requires_grad=True)
     mean = torch.tensor([0.05], device=cuda, requires_grad=True)
-    ls = torch.tensor([2.58], device=cuda, requires_grad=True)
+    ls = torch.tensor([11.0], device=cuda, requires_grad=True)                               # off-diagonal kernel values ~ 0.3 at this feature scale
     nz = torch.tensor([0.6932], device=cuda, requires_grad=True)
     cw = torch.full((1,), -1.0 / n, device=cuda)
 
@@ -1138,7 +1138,7 @@ def test_bench_batch_cfg0_regression_head_vs_oracle(cuda):
     ls.grad = None
     obj2, logp2, _ = run(z2)
     assert torch.equal(logp, logp2) and torch.equal(z.grad, z2.grad)
-    hyp = O.GPHypers(np.array([0.8]), np.array([0.05]), np.array([0.6932]), lengthscale=2.58)
+    hyp = O.GPHypers(np.array([0.8]), np.array([0.05]), np.array([0.6932]), lengthscale=11.0)
     for i in (0, 511, 1023):
         ref = O.regression_episode(z[i].detach().cpu().numpy().astype(np.float64), yb[i, 0].cpu().numpy().astype(np.float64), hyp, "rbf")
         assert abs((logp[i, 0].item() - ref["logp"][0]) / ref["logp"][0]) < MLL_RTOL
