@@ -33,6 +33,8 @@ constexpr int TB = 4;                         // tile rows / columns per block =
 struct TiledScal {                            // per matrix, factor -> invert -> w
     float lsum2, quad, coef;
     int msc, fail_at;
+    float usc;                                // F16 pipeline: the power-of-two scale of the matrix' M = R^-T tiles in their f16-split storage (2^15 / bound)
+    int erho;                                 // F16 pipeline: the augmented column (and row N of M, -alpha^T) carries an extra factor 2^-erho
 };
 
 struct TiledArgs {
@@ -150,6 +152,20 @@ __device__ __forceinline__ void xty4_y(const f32x4 x, const f32x4 (&y)[TB], f32x
     }
 }
 
+// the same on f16-split tiles (dkt_h2_tiles.h): 3 plane products per tile product, the four chains advanced together
+__device__ __forceinline__ void xtyh4_x(const f32x4 (&x)[TB], const f32x4 y, f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+    c0 = xtyh1<0>(x[0], y, c0); c1 = xtyh1<0>(x[1], y, c1); c2 = xtyh1<0>(x[2], y, c2); c3 = xtyh1<0>(x[3], y, c3);
+    c0 = xtyh1<1>(x[0], y, c0); c1 = xtyh1<1>(x[1], y, c1); c2 = xtyh1<1>(x[2], y, c2); c3 = xtyh1<1>(x[3], y, c3);
+    c0 = xtyh1<2>(x[0], y, c0); c1 = xtyh1<2>(x[1], y, c1); c2 = xtyh1<2>(x[2], y, c2); c3 = xtyh1<2>(x[3], y, c3);
+}
+
+// F16 pipeline (round 4; default with gradients, C <= 64): the tile arrays hold f16-SPLIT tiles (h, m planes of dkt_h2_tiles.h in the 16 bytes
+// of a lane), so that every left-looking K loop multiplies them as they arrive -- 3 v_mfma_f32_16x16x16_f16 of 16 cycles per tile product instead
+// of 4 v_mfma_f32_16x16x4_f32 of 32, no split arithmetic in the loops.  Scales: R tiles x 2^15 (|R_ij| <= 1 after the kappa scaling; the augmented
+// column w = R^-T r is brought under the same bound by an extra factor 2^-erho on r, 2^erho >= sqrt(N / noise) max |r|, undone where the quadratic
+// form, alpha and the trace leave the kernels); M tiles x usc = 2^15 / bound, bound = 2^msc / sqrt(noise) >= ||R^-T|| (a power of two per matrix:
+// exact, invertible; the class weight is NOT folded in -- a class of weight zero still needs its M for alpha).  The last diagonal tile (it contains the
+// unbounded row -alpha^T) stays fp32 until the invert kernel has read alpha off it.
 __device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
     f32x4 n;
 #pragma unroll
@@ -159,7 +175,7 @@ __device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Factorisation.  Wave w owns the tile columns j = i0 + w + 4 bb of block row I.
-template <int MC>
+template <int MC, bool F16>
 __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     __shared__ f32x4 mbuf[64];
     __shared__ f32x4 xbuf[TB][64];
@@ -193,10 +209,30 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
     (void)frexpf(fmaf(svc, emax, nzc), &ex);
     const int msc = max(0, (ex + 1) >> 1);
     const float ikap = ldexpf(1.0f, -2 * msc);
+    int erho = 0;
+    float usc = 1.0f;
+    if constexpr (F16) {
+        // bound of the augmented column: |w|^2 = r^T K^-1 r <= N max|r|^2 / noise  ->  2^erho >= sqrt(N / noise) max|r|
+        const float* yb = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
+        float rmax = 0.f;
+        for (int i = tid; i < N; i += 64 * TB) rmax = fmaxf(rmax, fabsf(yb[i] - mc));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o, DKT_WAVE));
+        __syncthreads();
+        if (lane == 0) red[w] = rmax;
+        __syncthreads();
+        rmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float nzp = nzc > 0.f ? nzc : 1e-6f;            // (a matrix with non-positive noise fails or not on its own; the bound only has to be finite)
+        int ew;
+        (void)frexpf(__builtin_sqrtf((float)N / nzp) * rmax, &ew);
+        erho = min(max(ew, 0), 60);
+        float uinv_unused;
+        usc = scale_for(ldexpf(1.0f, msc) / __builtin_sqrtf(nzp), uinv_unused);
+    }
     FormRt f;
     f.Et = mk_rsrc(t.etiles + (size_t)bl * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
     f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
-    f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc);
+    f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc - erho);
     const f32x4 negI = neg_identity(g);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -235,7 +271,10 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
         auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC]) {
 #pragma unroll
             for (int bb = 0; bb < MC; ++bb) {
-                if (i0 + w + TB * bb < NT) xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
+                if (i0 + w + TB * bb < NT) {
+                    if constexpr (F16) xtyh4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
+                    else xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
+                }
             }
         };
         {
@@ -245,6 +284,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                 for (int bb = 0; bb < MC; ++bb) {
                     const int i = i0 + r, j = i0 + w + TB * bb;
                     acc[r][bb] = (i < NT && j < NT && j >= i) ? form_from_e(f, g, i, j, Y[bb]) : zero4;
+                    if constexpr (F16) acc[r][bb] *= TWO30;                 // the K loop below accumulates (2^15 R)^T (2^15 R)
                 }
             };
             loade(Y0, 0);
@@ -263,6 +303,12 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
                 loadk(X0, Y0, kt + 2);
                 mulk(X1, Y1);
             }
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int r = 0; r < TB; ++r)
+#pragma unroll
+                for (int bb = 0; bb < MC; ++bb) acc[r][bb] *= TWOM30;
         }
         TCLK(1);
         // ---- the block's tile rows ----
@@ -318,7 +364,13 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
 #pragma unroll
             for (int bb = 0; bb < MC; ++bb) {
                 const int i = i0 + r, j = i0 + w + TB * bb;
-                bstore4(Tr, acc[r][bb], (i < NT && j < NT && j >= i) ? toff(NT, i, j, lane) : OOB, 0);
+                f32x4 v = acc[r][bb];
+                if constexpr (F16) {
+                    // R tiles split at 2^15, the diagonal slot's M_ii at usc -- except the last diagonal tile (row -alpha^T is unbounded): fp32
+                    if (j > i) v = split_h2(v, 32768.0f);
+                    else if (i != NT - 1) v = split_h2(v, usc);
+                }
+                bstore4(Tr, v, (i < NT && j < NT && j >= i) ? toff(NT, i, j, lane) : OOB, 0);
             }
         __syncthreads();                                                    // visible to every wave's loads of the next block row
     }
@@ -340,17 +392,19 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
         for (int k = 0; k < TB; ++k) fa = (fail_w[k] != 0 && (fa == 0 || fail_w[k] < fa)) ? fail_w[k] : fa;
         TiledScal s;
         s.lsum2 = lsum_w[0] + lsum_w[1] + lsum_w[2] + lsum_w[3] + (float)(2 * msc * N);
-        s.quad = red[0];
+        s.quad = red[0] * ldexpf(1.0f, 2 * erho);
         s.coef = 0.f;
         s.msc = msc;
         s.fail_at = fa;
+        s.usc = usc;
+        s.erho = erho;
         t.scal[m] = s;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // M = R^-T in place.  Wave w owns the tile rows i = w + 4 aa of block column J.
-template <int MC, bool GRAD>
+template <int MC, bool GRAD, bool F16>
 __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
     __shared__ float tr_w[TB], as_w[TB];
     __shared__ f32x4 dblk[10][64];               // the diagonal block of the current block column: R_kj (k < j, slot j (j-1) / 2 + k), M_jj (6 + j)
@@ -366,7 +420,12 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
     const size_t bc = (size_t)b * C + c;
     const brsrc ar = mk_rsrc(a.alpha + bc * N, (unsigned)(N * 4));
     const TiledScal sc = t.scal[m];
-    const float rsc = ldexpf(1.0f, -sc.msc);
+    const float rsc = ldexpf(1.0f, -sc.msc + (F16 ? sc.erho : 0));         // row N of M is -alpha^T 2^msc (2^-erho): undone here
+    const float arow2 = F16 ? -ldexpf(1.0f, 2 * sc.erho) : -1.0f;          // weight of that row's squares in the trace
+    const float usc = F16 ? sc.usc : 1.0f, uinv = 1.0f / usc;              // (a power of two)
+    f32x4 keepv;                                                            // real rows of a tile of tile row NT - 1 (W must not see -alpha^T / the padding)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keepv[q] = (g.g4 + q < g.pN) ? 1.0f : 0.0f;
     const float qnan = __int_as_float(0x7fc00000);
     const bool failed = sc.fail_at != 0;
     const f32x4 negI = neg_identity(g);
@@ -381,7 +440,7 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = 16 * j + g4 + q;
-            const float s = (row == N) ? -1.0f : 1.0f;
+            const float s = (row == N) ? arow2 : 1.0f;
             trpp += col_ok ? s * v[q] * v[q] : 0.f;
         }
     };
@@ -417,10 +476,14 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #pragma unroll
                     for (int jj = 0; jj < TB; ++jj) acc[aa][jj] += X[jj] + Y[aa];
 #else
+                    if constexpr (F16) {
+                        xtyh4_x(X, Y[aa], acc[aa][0], acc[aa][1], acc[aa][2], acc[aa][3]);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[jj][q], Y[aa][q], acc[aa][jj], 0, 0, 0);
+                            for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[jj][q], Y[aa][q], acc[aa][jj], 0, 0, 0);
+                    }
 #endif
                 }
             }
@@ -438,14 +501,30 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
             f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
             loadk(X0, Y0, 0);
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (w + TB * u < 10) dblk[w + TB * u][lane] = dl[u];
+            for (int u = 0; u < 3; ++u) {
+                const int tt = w + TB * u;
+                if (tt < 10) {
+                    f32x4 v = dl[u];
+                    if constexpr (F16) {                                    // back to fp32 for the block's own columns: R tiles / 2^15, M_jj / usc (the last one is fp32)
+                        if (tt < 6) v = join_h2(v) * TWOM15;
+                        else if (j0 + (tt - 6) != NT - 1) v = join_h2(v) * uinv;
+                    }
+                    dblk[tt][lane] = v;
+                }
+            }
             for (int k = 0; k < j0; k += 2) {
                 loadk(X1, Y1, k + 1);
                 mulk(X0, Y0, k);
                 loadk(X0, Y0, k + 2);
                 mulk(X1, Y1, k + 1);
             }
+        }
+        if constexpr (F16) {
+            const float un = TWOM15 * uinv;                                 // the K loop accumulated (2^15 R)^T (usc M)
+#pragma unroll
+            for (int aa = 0; aa < MC; ++aa)
+#pragma unroll
+                for (int jj = 0; jj < TB; ++jj) acc[aa][jj] *= un;
         }
         __syncthreads();
         // ---- the block's columns, one after the other ----
@@ -477,7 +556,10 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
                 }
                 if (w == jj) {                                              // the diagonal tile of column j: trace / alpha once
                     if constexpr (GRAD) trace_tile(Mjj, j, j);
-                    if (j == NT - 1) alpha_tile(Mjj, j);
+                    if (j == NT - 1) {
+                        alpha_tile(Mjj, j);
+                        if constexpr (F16) bstore4(Tr, split_h2(Mjj * keepv, usc), toff(NT, j, j, lane), 0);      // the last diagonal slot, now in W's format
+                    }
                 }
             }
         }
@@ -487,7 +569,9 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
 #pragma unroll
             for (int jj = 0; jj < TB; ++jj) {
                 const int i = w + TB * aa, j = j0 + jj;
-                bstore4(Tr, acc[aa][jj], (j < NT && i < j) ? toff(NT, i, j, lane) : OOB, 0);
+                f32x4 v = acc[aa][jj];
+                if constexpr (F16) v = split_h2((j == NT - 1) ? v * keepv : v, usc);
+                bstore4(Tr, v, (j < NT && i < j) ? toff(NT, i, j, lane) : OOB, 0);
             }
         __syncthreads();
     }
@@ -764,39 +848,23 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
-    // LDS: [2][32] split tiles of 1 KB (28 slots for a step's group of strips + 4 that a diagonal chunk may read past it) | q[C] | sg[C] | ct[C]
+    // LDS: [2][32] split tiles of 1 KB (28 slots for a step's group of strips + 4 that a diagonal chunk may read past it) | kap[C] | cr[C]
     constexpr int NST = 7, GT = 4 * NST, BUFT = GT + 4;                     // staged tiles per wave and step; tile slots per group; per buffer
     f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
-    float* q_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * BUFT * 1024);
-    float* sg_s = q_s + 64;
-    float* ct_s = sg_s + 64;
+    float* kap_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * BUFT * 1024);
+    float* cr_s = kap_s + 64;
     const brsrc Tr = mk_rsrc(t.tiles + (size_t)bl * C * (ntt + 1) * 256, (unsigned)((size_t)C * (ntt + 1) * 1024));
     const TiledScal* sc = t.scal + (size_t)bl * C;
-    float unit_inv2;
-    {
-        float bound = 0.f, coef = 0.f, gc = 0.f;
-        int msc = 0;
-        if (tid < C) {
-            coef = sc[tid].coef;
-            msc = sc[tid].msc;
-            gc = __builtin_sqrtf(fabsf(coef));
-            bound = gc * ldexpf(1.0f, msc) / __builtin_sqrtf(a.noise[tid]);
-            q_s[tid] = bound;
-        }
-        __syncthreads();
-        float mx = 1e-30f;
-        for (int c = 0; c < C; ++c) mx = fmaxf(mx, q_s[c]);                // (fmaxf drops the NaN of a failed class)
-        __syncthreads();
-        float inv;
-        const float unit = scale_for(mx, inv);
-        unit_inv2 = inv * inv;
-        if (tid < C) {
-            q_s[tid] = gc * unit + (coef - coef);                           // (+ NaN for a failed class: poisons the episode's W)
-            sg_s[tid] = coef < 0.f ? -1.0f : (coef > 0.f ? 1.0f : 0.0f);
-            ct_s[tid] = coef * ldexpf(1.0f, 2 * msc) * unit * unit;         // coefficient of alpha alpha^T in the accumulators' unit
-        }
-        __syncthreads();
+    // The invert kernel left M_c in f16-split tiles scaled by usc_c (a power of two; the real rows only: the row -alpha^T and the padding are
+    // zero), so a staged tile goes to LDS as it is and a product is (usc M)^T (usc M).  The class weight enters at the ACCUMULATORS: they hold
+    // (sum_{c' <= c} kap_c' X_c') / kap_c with X_c = usc_c^2 M_c^T M_c and kap_c = coef_c / usc_c^2, rescaled by kap_c / kap_{c+1} when the class
+    // changes (one multiply per accumulator register and class; a class of weight zero is skipped; a failed class has coef = NaN and poisons W).
+    if (tid < C) {
+        const float coef = sc[tid].coef, us = sc[tid].usc;
+        kap_s[tid] = coef / (us * us);
+        cr_s[tid] = coef * ldexpf(1.0f, 2 * sc[tid].msc);                   // coefficient of alpha alpha^T (alpha is unscaled)
     }
+    __syncthreads();
     // this wave's chunks: the chunks of the range in column-pair-major order -- pair (j0, j0 + 1), j0 = c0, c0 + 2, ..., rows i0 = 0, 4, ... <= j0 + 1 --
     // dealt round-robin to the 4 waves; chunk u of the wave = chunk number w + 4 u.  Packed i0 | j0 << 8 in SGPRs for the whole kernel; a slot past
     // the end of the list gets j0 = 255 (it never takes part).
@@ -819,9 +887,6 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     for (int u = 0; u < MAXC; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[u][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 keep;                                                             // rows of the last tile row that are real rows of M (the augmented row
-#pragma unroll                                                              // -alpha^T and the identity padding below it are zeroed: the rank-one terms
-    for (int q = 0; q < 4; ++q) keep[q] = (g4 + q < pN) ? 1.0f : 0.0f;      // are added at the end, the padding only reaches padded entries of W)
     // A STEP stages a GROUP of consecutive strips [ka, kb) of one class -- as many as fit the GT tile slots of an LDS buffer (short strips
     // share a step), so that every step has enough products to cover the flight time of the next group's loads and there are fewer barriers.
     auto lim = [&](const int k) { return min(k + 1, c1); };                 // tiles of strip k this range needs
@@ -868,32 +933,31 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         }
     };
     auto write_step = [&](const f32x4 (&S)[NST], const Grp gr, const int bufi) {
-        const float q = q_s[min(gr.c, C - 1)];
 #pragma unroll
         for (int x = 0; x < NST; ++x) {
             const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
-            if (e & 0x2000) {
-                f32x4 v = S[x];
-                if (e & 0x1000) v *= keep;
-                sbuf[(bufi * BUFT + w + 4 * x) * 64 + lane] = split_h2(v, q);
-            }
+            if (e & 0x2000) sbuf[(bufi * BUFT + w + 4 * x) * 64 + lane] = S[x];
         }
     };
-    float cursign = 0.0f;
+    float curkap = 0.0f;                                                    // the accumulators' unit (0: nothing accumulated yet)
+    bool skip = false;
     auto mul_step = [&](const Grp gr, const int bufi) {
         const int gk = __builtin_amdgcn_readlane(gtab, gr.gi), gka = gk & 255, gkb = gk >> 8;
-        if (gr.gi == 0) {                                                   // a new class: its sign against the accumulators'
-            const float sgc = sg_s[min(gr.c, C - 1)];
-            if (sgc != 0.0f && sgc != cursign) {
-                if (cursign != 0.0f) {
+        if (gr.gi == 0) {                                                   // a new class: bring the accumulators to its unit
+            const float kc = kap_s[min(gr.c, C - 1)];
+            skip = kc == 0.0f;
+            if (!skip) {
+                if (curkap != 0.0f) {
+                    const float ratio = curkap / kc;
 #pragma unroll
                     for (int u = 0; u < MAXC; ++u)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[u][e] = -acc[u][e];
+                        for (int e = 0; e < 8; ++e) acc[u][e] *= ratio;
                 }
-                cursign = sgc;
+                curkap = kc;
             }
         }
+        if (skip) return;
         const unsigned char* sb = reinterpret_cast<const unsigned char*>(sbuf) + bufi * BUFT * 1024 + lane16;
         int sbase = 0;
         for (int k = gka; k < gkb; ++k) {
@@ -974,13 +1038,16 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     }
     // a tile of a chunk is real when it lies on or above the diagonal, inside the range
     auto real_tile = [&](const int i, const int j) { return i <= j && j < c1; };
-    // ---- the rank-one terms: acc(i, j) -= sigma ct_c alpha_c[rows of i] alpha_c[columns of j]^T (alpha: NaN for a failed class), the alphas of
+    // ---- the rank-one terms: acc(i, j) -= coef_c kappa_c alpha_c[rows of i] alpha_c[columns of j]^T (alpha: NaN for a failed class), the alphas of
     //      a group of classes staged in the strip buffers ----
     {
         const int npad = 16 * NT;
         float* al_s = reinterpret_cast<float*>(wres_smem);
         const int cgrp = max(1, min(C, (2 * BUFT * 1024) / (npad * 4)));
-        const float sgn_acc = (cursign == 0.0f) ? 1.0f : cursign;
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[u][e] *= curkap;                // -> sum_c coef_c M_c^T M_c (0 when every class weight is zero)
         for (int cb = 0; cb < C; cb += cgrp) {
             const int cn = min(cgrp, C - cb);
             __syncthreads();
@@ -994,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
                 const int i0 = tc[u] & 255, j0 = tc[u] >> 8;
                 if (j0 < c1) {
                     for (int c = 0; c < cn; ++c) {
-                        const float sct = sgn_acc * ct_s[cb + c];
+                        const float sct = cr_s[cb + c];
                         float aj[2];
 #pragma unroll
                         for (int y = 0; y < 2; ++y) aj[y] = (j0 + y < NT) ? sct * al_s[c * npad + 16 * (j0 + y) + c16] : 0.f;
@@ -1012,11 +1079,6 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
                 }
             }
         }
-        const float fin = sgn_acc * unit_inv2;
-#pragma unroll
-        for (int u = 0; u < MAXC; ++u)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[u][e] *= fin;
     }
     // ---- store: tile (i, j) and its mirror (as the block-column kernel: a diagonal tile from its upper half only -> bitwise symmetric) ----
     const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
@@ -1098,32 +1160,44 @@ inline int tiled_chunk_episodes() {        // DKT_MLL_TILED_CHUNK (measurement a
 template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
+    const dim3 fgrid(8 * ((bcnt + 7) / 8) * t.a.C), blk(64 * TB);
     hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
-    hipLaunchKernelGGL((tiled_factor_kernel<MC>), dim3(8 * ((bcnt + 7) / 8) * t.a.C), dim3(64 * TB), 0, st, t);
+#if defined(DKT_TILED_CLOCKS) || defined(DKT_TILED_NOMATH)
+    constexpr bool SPLIT_OK = false;                                        // the measurement builds instrument the fp32 kernels
+#else
+    constexpr bool SPLIT_OK = true;
+#endif
+    // F16 pipeline (default for a call with gradients and C <= 64): f16-split tile arrays end to end -- factor and invert K loops on the f16 pipe,
+    // W with resident accumulators.  DKT_MLL_TILED_WRES=0 -> round 3's kernels (fp32 factor / invert, block-column W on f16 products of fp32
+    // tiles); DKT_MLL_TILED_F16=0 -> round 2's all-fp32 kernels.  A forward-only call (no W) runs the fp32 factor / invert.
+    const bool msplit = SPLIT_OK && grad && tiled_f16() && tiled_wres() && t.a.C <= 64;
+    if (msplit) hipLaunchKernelGGL((tiled_factor_kernel<MC, true>), fgrid, blk, 0, st, t);
+    else hipLaunchKernelGGL((tiled_factor_kernel<MC, false>), fgrid, blk, 0, st, t);
 #ifdef DKT_TILED_CLOCKS
     return;
 #endif
-    if (grad) {
-        hipLaunchKernelGGL((tiled_invert_kernel<MC, true>), dim3(nmat), dim3(64 * TB), 0, st, t);
-        // W on the f16 pipe (DKT_MLL_TILED_F16=0: round 2's fp32 products).  Block columns of 8 tile columns with 8 waves (WB = 8: 880 instead of
-        // 1232 tile reads per class matrix at NT = 27) were measured and are NOT used: 25.8 vs 22.2 ms per 1024 cfg4 episodes for the whole
-        // marginal likelihood -- one 8-wave workgroup per CU at 246 VGPRs hides less load latency than two independent 4-wave ones; the
-        // kernel is latency-bound, not bandwidth-bound.
-        const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
-        if (tiled_f16() && tiled_wres() && t.a.C <= 64) {
-            const WRanges rg = wres_ranges(t.NT);
-            const size_t lds = (size_t)2 * 32 * 1024 + 3 * 64 * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
-        } else if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, dim3(64 * TB), 0, st, t);
-        else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, dim3(64 * TB), 0, st, t);
-    } else {
-        hipLaunchKernelGGL((tiled_invert_kernel<MC, false>), dim3(nmat), dim3(64 * TB), 0, st, t);
+    if (!grad) {
+        hipLaunchKernelGGL((tiled_invert_kernel<MC, false, false>), dim3(nmat), blk, 0, st, t);
+        return;
     }
+    if (msplit) {
+        hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
+        const WRanges rg = wres_ranges(t.NT);
+        const size_t lds = (size_t)2 * 32 * 1024 + 2 * 64 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        return;
+    }
+    hipLaunchKernelGGL((tiled_invert_kernel<MC, true, false>), dim3(nmat), blk, 0, st, t);
+    // Block-column W (rounds 2-3).  Block columns of 8 tile columns with 8 waves (WB = 8: 880 instead of 1232 tile reads per class matrix at
+    // NT = 27) were measured in round 3 and are NOT used: 25.8 vs 22.2 ms per 1024 cfg4 episodes for the whole marginal likelihood.
+    const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
+    if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, blk, 0, st, t);
+    else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, blk, 0, st, t);
 }
 
 }  // namespace
