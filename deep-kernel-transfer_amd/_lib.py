@@ -86,6 +86,9 @@ SPILL_BUDGET = {
     # (112 < N <= 128, 36 accumulator tiles) do
     r"gram_sym_ep_split_kernelILi7ELi1E": 70,
     r"gram_sym_ep_split_kernelILi8E": 140,
+    # tile-array factorisation at 3 workgroups per CU (168 VGPRs): ~28 values parked in scratch around the diagonal-tile sweep, none in the K loop
+    r"tiled_factor_kernelILi\dELb1ELi3E": 40,
+    r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 16,
 }
 
 

@@ -18,11 +18,18 @@
 #include "../../include/dkt_abi.h"
 
 bool dkt_gram_split_enabled();           // dkt_gram_ep.hip: DKT_GRAM_SPLIT
+#define DKT_F16_UNSCALE_BIG (1.f / (32768.f * 32768.f))
 
 namespace {
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+// NW = 4: round 2's kernel (64 output rows per workgroup, one LDS image, two barriers per slab, 2 workgroups per CU).
+// NW = 8 (round 4, default; DKT_GRAM_BWD_ROWS8=0 restores NW = 4): 128 output rows per workgroup -- the slab is split / transposed / staged 4 instead
+// of 7 times per N = 420 episode (the NW = 4 kernel issues 4.8 VALU instructions per MFMA, the matrix pipe 22 % busy, and half of its LDS cycles are bank
+// conflicts of the transposing stores: profiles/r04/v0_gram_big_pmc.txt) --, two LDS images (one barrier per slab), and the features of a slab permuted over
+// the image rows so that the 8-byte transposing stores of a wave fall into distinct banks (image row = 16 (t & 1) + d4 + 8 (t >> 1) for feature 4 d4 + t:
+// the 8 rows a 16-lane store group touches are CONSECUTIVE, 40 banks apart mod 64, instead of every second row, 16 banks apart).
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
                                                                     float* __restrict__ dZ, int B, int N, int D,
                                                                     const float* __restrict__ ep_scale, int nrb) {
     constexpr int KP = 32 * KS;
@@ -30,17 +37,19 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
     constexpr int SU = (KP / 8) + ((KP / 8) % 4 == 2 ? 0 : (6 - (KP / 8) % 4) % 4);
     constexpr int RS = 8 * SU;                           // f16 per LDS row (one feature, all rows j), 16-byte units == 2 mod 4
     constexpr int PLANE = BD * RS;
-    constexpr int NPASS = (KP + 127) / 128;              // staging passes of 128 rows
+    constexpr int RPP = 32 * NW;                         // rows staged per pass (128 / 256)
+    constexpr int NPASS = (KP + RPP - 1) / RPP;
+    constexpr int NBUF = NW == 4 ? 1 : 2;
     static_assert(SU % 4 == 2 && RS >= KP, "LDS row stride");
-    __shared__ __attribute__((aligned(16))) _Float16 zt[2 * PLANE];
-    __shared__ float rowinv[64];
+    __shared__ __attribute__((aligned(16))) _Float16 zt[NBUF][2 * PLANE];
+    __shared__ float rowinv[16 * NW];
 
     // workgroup -> (episode, row block): consecutive workgroup ids go to consecutive XCDs, so the row blocks of one episode are
     // given ids that are 8 apart
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int b = (slot / nrb) * 8 + xcd, rb = slot % nrb;
     if (b >= B) return;
-    const int r0 = 64 * rb;
+    const int r0 = 16 * NW * rb;
     const float* Wb = W + (size_t)b * N * N;
     const float* Zb = Z + (size_t)b * N * D;
     float* dZb = dZ + (size_t)b * N * D;
@@ -56,25 +65,25 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int row = 128 * p + 4 * jg + rr;
+                const int row = RPP * p + 4 * jg + rr;
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (in && row < N) ? (row * D + 4 * d4) * 4 : 0x7ffffff0, d0 * 4, 0);
                 rg[p][rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
     };
     // feature d = 4 d4 + t of the slab goes to LDS row 16 (d & 1) + (d >> 1): output tile tt = d & 1 holds the features {2 r + tt},
     // so the two accumulators of a lane are 2 consecutive features (8-byte stores of dZ)
-    auto lstore = [&](const float4 (&rg)[NPASS][4]) {
+    auto lstore = [&](const float4 (&rg)[NPASS][4], const int buf) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            if (128 * p + 4 * jg < KP) {
+            if (RPP * p + 4 * jg < KP) {
                 const float x[4][4] = {{rg[p][0].x, rg[p][1].x, rg[p][2].x, rg[p][3].x}, {rg[p][0].y, rg[p][1].y, rg[p][2].y, rg[p][3].y},
                                        {rg[p][0].z, rg[p][1].z, rg[p][2].z, rg[p][3].z}, {rg[p][0].w, rg[p][1].w, rg[p][2].w, rg[p][3].w}};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f16x4 h, m;
                     split2h(make_float4(x[t][0], x[t][1], x[t][2], x[t][3]), 32768.f, h, m);
-                    const int lrow = 16 * (t & 1) + 2 * d4 + (t >> 1);
-                    _Float16* dst = zt + lrow * RS + 128 * p + 4 * jg;
+                    const int lrow = NW == 4 ? 16 * (t & 1) + 2 * d4 + (t >> 1) : 16 * (t & 1) + d4 + 8 * (t >> 1);
+                    _Float16* dst = zt[buf] + lrow * RS + RPP * p + 4 * jg;
                     *reinterpret_cast<f16x4*>(dst) = h;
                     *reinterpret_cast<f16x4*>(dst + PLANE) = m;
                 }
@@ -134,12 +143,12 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
         }
     }
     gload(rg, 0);
-    lstore(rg);
+    lstore(rg, 0);
     __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
         if (sl + 1 < nslab) gload(rg, (sl + 1) * BD);
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const _Float16* base = zt + r16 * RS + 8 * q;
+        const _Float16* base = zt[NBUF == 2 ? (sl & 1) : 0] + r16 * RS + 8 * q;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
                 acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[tt], 0, 0, 0);
             }
         }
-        const int d = sl * BD + 2 * r16;
+        const int d = sl * BD + (NW == 4 ? 2 * r16 : 4 * (r16 & 7) + 2 * (r16 >> 3));
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int lr = 16 * wave + 4 * q + reg, row = r0 + lr;
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void gram_bwd_rows_f16x2_kernel(const float
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(dZb + (size_t)row * D + d));
             }
         }
-        __syncthreads();
-        if (sl + 1 < nslab) lstore(rg);
+        if constexpr (NBUF == 1) __syncthreads();
+        if (sl + 1 < nslab) lstore(rg, NBUF == 2 ? ((sl + 1) & 1) : 0);
         __syncthreads();
     }
 }
@@ -290,14 +299,160 @@ __global__ __launch_bounds__(256, SPL == 2 ? 3 : 2) void gram_sym_tiles_split_ke
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// EPISODE-RESIDENT symmetric Gram for 128 < N <= 432 with unit rows (round 4; DKT_GRAM_BIG_EP=0 restores the 64 x 64-tile kernel above).
+// The tile kernel stages every 64-row block of Z once per 64 x 64 output tile it takes part in -- 8 split-VALU instructions per MFMA, the matrix
+// pipe 20 % busy (profiles/r04/v0_gram_big_pmc.txt).  Here ONE workgroup of 8 waves owns an episode: all N rows of a 32-feature slab are split and
+// staged ONCE (two f16 planes, double-buffered), and all NT (NT + 1) / 2 lower 16 x 16 tiles (378 at N = 420) stay in the accumulators of the 8 waves
+// (a wave: a run of <= 48 consecutive tiles in row-major order, so the A fragment changes only at a row change).  LDS rows have NO padding (64 B per
+// row and plane: 2 x 2 x 27 KB); the 16-byte units of a row are XOR-swizzled with G[(row >> 2) & 3], G = {0, 2, 3, 1}, which makes the
+// ds_read_b128 fragment reads conflict-free (every 16-lane group of the instruction then covers all 16 bank quads).
+constexpr int BEP_MAXT = 48;
+__global__ __launch_bounds__(512, 1) void gram_sym_bigep_f16x2_kernel(const float* __restrict__ Z, float* __restrict__ E, int N, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bep_smem[];
+    const int b = blockIdx.x;
+    const float* Zb = Z + (size_t)b * N * D;
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = (N + 15) >> 4, NP = 16 * NT, PLANE = NP * 64, BUF = 2 * PLANE;
+    const int ntile = NT * (NT + 1) / 2, per = (ntile + 7) >> 3;
+    const int t0 = w * per, cnt = max(0, min(per, ntile - t0));
+    // first tile of the run: row-major lower triangle, t -> (i, j), j <= i
+    int is = 0, js = t0;
+    while (js > is) { js -= is + 1; ++is; }
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    constexpr int NPASS = 7;                               // 432 rows x 8 float4 / 512 threads
+    int voff[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int idx = tid + 512 * p, row = idx >> 3, c4 = idx & 7;
+        voff[p] = (row < N) ? (row * D + 4 * c4) * 4 : 0x7ffffff0;
+    }
+    // LDS offset of the staged float4 of pass p: row = row0 + 64 p (so (row >> 2) & 3 does not depend on p), 8-byte half (c4 & 1) of unit (c4 >> 1) ^ G
+    const int row0 = tid >> 3, c40 = tid & 7;
+    const int loff0 = row0 * 64 + ((((c40 >> 1) ^ ((0x78 >> (2 * ((row0 >> 2) & 3))) & 3))) << 4) + ((c40 & 1) << 3);
+    float4 rg[NPASS];
+    auto gload = [&](const int k0) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int c4 = (tid + 512 * p) & 7;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (k0 + 4 * c4 < D) ? voff[p] : 0x7ffffff0, k0 * 4, 0);
+            rg[p] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto lstore = [&](const int buf) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (row0 + 64 * p < NP) {
+                f16x4 h, m;
+                split2h(rg[p], 32768.f, h, m);
+                unsigned char* dst = bep_smem + buf * BUF + loff0 + 4096 * p;
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE) = m;
+            }
+        }
+    };
+    f32x4 acc[BEP_MAXT];
+#pragma unroll
+    for (int u = 0; u < BEP_MAXT; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fl = r16 * 64 + ((q ^ ((0x78 >> (2 * ((r16 >> 2) & 3))) & 3)) << 4);      // this lane's fragment offset inside a 16-row block
+    const int nk = (D + 31) >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * 32);
+        const unsigned char* base = bep_smem + buf * BUF + fl;
+        int i = is, j = js, cn = cnt;
+        asm volatile("" : "+s"(i), "+s"(j), "+s"(cn));      // (opaque: the per-tile coordinates / predicates are recomputed per slab on the SALU, not hoisted into 150 SGPRs)
+        f16x8 ah = *reinterpret_cast<const f16x8*>(base + i * 1024), am = *reinterpret_cast<const f16x8*>(base + i * 1024 + PLANE);
+#pragma unroll
+        for (int u = 0; u < BEP_MAXT; ++u) {
+            if (u < cn) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(base + j * 1024), bm = *reinterpret_cast<const f16x8*>(base + j * 1024 + PLANE);
+                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
+                acc[u] += t;                                // two-level accumulation, as the other split Gram kernels
+                if (++j > i) {
+                    ++i; j = 0;
+                    if (u + 1 < cn) {
+                        ah = *reinterpret_cast<const f16x8*>(base + i * 1024);
+                        am = *reinterpret_cast<const f16x8*>(base + i * 1024 + PLANE);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- store: tile (i, j) and its mirror; a diagonal tile from its lower half only (bitwise symmetric) ----
+    const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(E + (size_t)b * N * N, 0, (unsigned)((size_t)N * N * 4), 0x00020000);
+    {
+        int i = is, j = js;
+#pragma unroll
+        for (int u = 0; u < BEP_MAXT; ++u) {
+            if (u < cnt) {
+                const f32x4 v = acc[u] * DKT_F16_UNSCALE_BIG;
+                const int gn = 16 * j + r16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gm = 16 * i + 4 * q + reg;
+                    const bool ok = gm < N && gn < N && (i != j || gn <= gm);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[reg]), er, ok ? (gm * N + gn) * 4 : 0x7ffffff0, 0, 0);
+                    if (i == j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[reg]), er, (ok && gn < gm) ? (gn * N + gm) * 4 : 0x7ffffff0, 0, 0);
+                }
+                if (i != j) {                                // mirror: 4 consecutive columns of row gn (rows of tile row i > j: 16 i + 4 q + 3 < N unless ragged)
+                    const int gm0 = 16 * i + 4 * q;
+                    if (gm0 + 3 < N) {
+                        typedef unsigned bep_u4 __attribute__((ext_vector_type(4)));
+                        const bep_u4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(uv, er, (gn < N) ? (gn * N + gm0) * 4 : 0x7ffffff0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[reg]), er, (gn < N && gm0 + reg < N) ? (gn * N + gm0 + reg) * 4 : 0x7ffffff0, 0, 0);
+                    }
+                }
+                if (++j > i) { ++i; j = 0; }
+            }
+        }
+    }
+}
+
+static int g_bwd_rows8 = -1;
+static bool gram_bwd_rows8_enabled() {
+    if (g_bwd_rows8 < 0) { const char* v = getenv("DKT_GRAM_BWD_ROWS8"); g_bwd_rows8 = (v && v[0] == '0') ? 0 : 1; }
+    return g_bwd_rows8 != 0;
+}
+
 template <int KS>
 void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
+    if (KS >= 10 && gram_bwd_rows8_enabled()) {          // N > 256: three or more 128-row blocks per episode
+        const int nrb = (N + 127) / 128;
+        const int grid = 8 * ((B + 7) / 8) * nrb;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gram_bwd_rows_f16x2_kernel<KS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 8>), dim3(grid), dim3(512), 0, st, W, Z, dZ, B, N, D, sc, nrb);
+        return;
+    }
     const int nrb = (N + 63) / 64;
     const int grid = 8 * ((B + 7) / 8) * nrb;
-    hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS>), dim3(grid), dim3(256), 0, st, W, Z, dZ, B, N, D, sc, nrb);
+    hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 4>), dim3(grid), dim3(256), 0, st, W, Z, dZ, B, N, D, sc, nrb);
 }
 
 }  // namespace
+
+static int g_big_ep = -1;
+static bool gram_big_ep_enabled() {
+    if (g_big_ep < 0) { const char* v = getenv("DKT_GRAM_BIG_EP"); g_big_ep = (v && v[0] == '0') ? 0 : 1; }
+    return g_big_ep != 0;
+}
+void dkt_gram_big_reload_env();                          // dkt_reload_env(); defined below the switches
 
 // Returns true when the kernel was launched (128 < N <= 448, unit rows, symmetric W, D % 4 == 0, 16-byte aligned Z / dZ).
 bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, unsigned flags, hipStream_t st) {
@@ -312,9 +467,22 @@ bool dkt_gram_bwd_big_launch(const float* W, const float* Z, float* dZ, int B, i
     return true;
 }
 
+void dkt_gram_big_reload_env() { g_big_ep = -1; g_bwd_rows8 = -1; }
+
 // Returns true when the kernel was launched (symmetric linear Gram, N > 128, D % 4 == 0, 16-byte aligned Z).
 bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st) {
     if (N <= 128 || (D & 3) || ((uintptr_t)Z & 15) || !dkt_gram_split_enabled()) return false;
+    if (unit && N <= 432 && B >= 64 && gram_big_ep_enabled()) {               // one workgroup per episode: fills the GPU from a few hundred episodes on
+        const int NT16 = (N + 15) / 16;
+        const size_t lds = (size_t)4 * NT16 * 16 * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gram_sym_bigep_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 27 * 16 * 64);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gram_sym_bigep_f16x2_kernel, dim3(B), dim3(512), lds, st, Z, E, N, D);
+        return true;
+    }
     const int nt = (N + 63) / 64;
     const long grid = 8L * ((B + 7) / 8) * (nt * (nt + 1) / 2);
     if (grid > 0x7fffffffL) return false;

@@ -35,6 +35,7 @@ struct TiledScal {                            // per matrix, factor -> invert ->
     int msc, fail_at;
     float usc;                                // F16 pipeline: the power-of-two scale of the matrix' M = R^-T tiles in their f16-split storage (2^15 / bound)
     int erho;                                 // F16 pipeline: the augmented column (and row N of M, -alpha^T) carries an extra factor 2^-erho
+    float trp, asp;                           // resident invert: trace / sum-of-alpha partial sums handed from one column range's launch to the next
 };
 
 struct TiledArgs {
@@ -175,8 +176,12 @@ __device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Factorisation.  Wave w owns the tile columns j = i0 + w + 4 bb of block row I.
-template <int MC, bool F16>
-__global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
+// WGS = workgroups per CU the register budget is set for.  2: the operands of two K steps in registers (loads one step ahead).  3 (round 4, the F16
+// pipeline's default; DKT_MLL_TILED_WGS=2 restores 2): ONE step's operands (168 VGPRs) -- a lone workgroup of this kernel needs 147 us per N = 420
+// matrix and two co-resident ones 165 us each: the kernel is bound by the serial chain of a block row (sweep -> barrier -> panel -> barrier -> updates),
+// not by the matrix pipe or memory (profiles/r04/v4_factor_phase_clocks.log), so a third workgroup per CU fills idle pipes.
+template <int MC, bool F16, int WGS>
+__global__ __launch_bounds__(64 * TB, WGS) void tiled_factor_kernel(TiledArgs t) {
     __shared__ f32x4 mbuf[64];
     __shared__ f32x4 xbuf[TB][64];
     __shared__ float red[TB];
@@ -294,14 +299,23 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
             forme(Y1, 1);
             loade(Y1, 3);
             forme(Y0, 2);
-            loadk(X0, Y0, 0);
-            forme(Y1, 3);
-            TCLK(0);
-            for (int kt = 0; kt < i0; kt += 2) {
-                loadk(X1, Y1, kt + 1);
-                mulk(X0, Y0);
-                loadk(X0, Y0, kt + 2);
-                mulk(X1, Y1);
+            if constexpr (WGS <= 2) {
+                loadk(X0, Y0, 0);
+                forme(Y1, 3);
+                TCLK(0);
+                for (int kt = 0; kt < i0; kt += 2) {
+                    loadk(X1, Y1, kt + 1);
+                    mulk(X0, Y0);
+                    loadk(X0, Y0, kt + 2);
+                    mulk(X1, Y1);
+                }
+            } else {
+                forme(Y1, 3);
+                TCLK(0);
+                for (int kt = 0; kt < i0; ++kt) {                           // one step's operands at a time: the other workgroups of the CU cover the load
+                    loadk(X0, Y0, kt);
+                    mulk(X0, Y0);
+                }
             }
         }
         if constexpr (F16) {
@@ -398,14 +412,16 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_factor_kernel(TiledArgs t) {
         s.fail_at = fa;
         s.usc = usc;
         s.erho = erho;
+        s.trp = 0.f;
+        s.asp = 0.f;
         t.scal[m] = s;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // M = R^-T in place.  Wave w owns the tile rows i = w + 4 aa of block column J.
-template <int MC, bool GRAD, bool F16>
-__global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
+template <int MC, bool GRAD, bool F16, int WGS = 2>          // WGS: as tiled_factor_kernel (3: one K step's operands in registers, 3 workgroups per CU)
+__global__ __launch_bounds__(64 * TB, WGS) void tiled_invert_kernel(TiledArgs t) {
     __shared__ float tr_w[TB], as_w[TB];
     __shared__ f32x4 dblk[10][64];               // the diagonal block of the current block column: R_kj (k < j, slot j (j-1) / 2 + k), M_jj (6 + j)
     const MllArgs& a = t.a;
@@ -512,11 +528,18 @@ __global__ __launch_bounds__(64 * TB, 2) void tiled_invert_kernel(TiledArgs t) {
                     dblk[tt][lane] = v;
                 }
             }
-            for (int k = 0; k < j0; k += 2) {
-                loadk(X1, Y1, k + 1);
-                mulk(X0, Y0, k);
-                loadk(X0, Y0, k + 2);
-                mulk(X1, Y1, k + 1);
+            if constexpr (WGS <= 2) {
+                for (int k = 0; k < j0; k += 2) {
+                    loadk(X1, Y1, k + 1);
+                    mulk(X0, Y0, k);
+                    loadk(X0, Y0, k + 2);
+                    mulk(X1, Y1, k + 1);
+                }
+            } else {
+                for (int k = 0; k < j0; ++k) {
+                    mulk(X0, Y0, k);
+                    loadk(X0, Y0, k + 1);
+                }
             }
         }
         if constexpr (F16) {
@@ -1122,6 +1145,270 @@ inline WRanges wres_ranges(const int NT) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// M = R^-T with RESIDENT accumulators (round 4; F16 pipeline only; opt-in with DKT_MLL_TILED_INVRES=1 -- parity-tested, NOT faster than the
+// block-column tiled_invert_kernel it would replace: kept as the measured alternative).
+// Slot (i, j), i < j, becomes M_ji = (-V_jj)^T sum_{i <= k < j} R_kj^T M_ki: per k a product of the R ROW k (tiles R_kj, j > k) with the STRIP k of M
+// (tiles M_ki, i <= k) -- the structure of the W kernel with two operand images instead of one.  The block-column kernel re-reads the strips once per
+// block column (1176 tile reads + 351 writes per matrix at NT = 27, at the ceiling of that access pattern: profiles/r04/v0_tiled_traffic_ceiling.txt);
+// here a workgroup keeps a COLUMN RANGE of the slots in registers (the W kernel's ranges and 4 x 2 chunks), one launch per range, left to right:
+// a strip k < c0 comes from memory (the earlier launches finished it), a strip k >= c0 is the range's own column k, finalised at the start of step k
+// (scaled, multiplied by -V_kk^T on the fp32 pipe, counted into the trace / alpha, stored f16-split -- to memory for the W kernel and the later
+// launches, and into the step's LDS image for this one).  767 tile reads + 378 writes per matrix.
+// Step k: [finalise column k if k >= c0; barrier] products with image k; stage image k + 1 (registers -> LDS), issue the loads of image k + 2; barrier.
+// Image k = slots 0 .. k: the strip (tile k = the diagonal slot's M_kk) | slots k + 1 ..: R_kj for j = max(k + 1, c0) .. c1 - 1 | slot 28: zeros.
+template <int MAXC>
+__global__ __launch_bounds__(256, 2) void tiled_invres_kernel(TiledArgs t, WRanges rg, int gi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wres_smem[];
+    __shared__ float tr_w[TB], as_w[TB];
+    const MllArgs& a = t.a;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, NT = t.NT, C = a.C;
+    const int m = blockIdx.x, b = t.b0 + m / C, c = m % C;
+    const int c0 = rg.c0[gi], c1 = rg.c0[gi + 1];
+    const bool lastrange = gi == rg.ng - 1;
+    const Geo g = make_geo(tid, N, NT);
+    const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
+    const size_t ntt = (size_t)NT * (NT + 1) / 2;
+    constexpr int NST = 7, GT = 4 * NST, BUFT = GT + 4, ZT = GT;           // staged tiles per wave and step; image slots; per buffer; the zero tile
+    f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
+    const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
+    const size_t bc = (size_t)b * C + c;
+    const brsrc ar = mk_rsrc(a.alpha + bc * N, (unsigned)(N * 4));
+    const TiledScal sc = t.scal[m];
+    const float rsc = ldexpf(1.0f, -sc.msc + sc.erho);                      // row N of M is -alpha^T 2^msc 2^-erho
+    const float arow2 = -ldexpf(1.0f, 2 * sc.erho);
+    const float usc = sc.usc, uinv = 1.0f / usc, un = TWOM15 * uinv;        // the products accumulate (2^15 R)^T (usc M)
+    const float qnan = __int_as_float(0x7fc00000);
+    const bool failed = sc.fail_at != 0;
+    const bool arow = (g.ln.g == (pN >> 2));
+    const int qn = pN & 3;
+    float trpp = 0.f, asum = 0.f;
+    auto trace_tile = [&](const f32x4 v, const int i, const int j) {       // as in tiled_invert_kernel
+        const bool col_ok = 16 * i + c16 < N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * j + g4 + q;
+            const float sgn = (row == N) ? arow2 : 1.0f;
+            trpp += col_ok ? sgn * v[q] * v[q] : 0.f;
+        }
+    };
+    auto alpha_tile = [&](const f32x4 v, const int i) {
+        const float x = -(qn == 0 ? v[0] : qn == 1 ? v[1] : qn == 2 ? v[2] : v[3]) * rsc;
+        const bool ok = arow && (16 * i + c16 < N);
+        bstore1(ar, failed ? qnan : x, ok ? (16 * i + c16) * 4 : OOB, 0);
+        asum += ok ? x : 0.f;
+    };
+    // chunk table: as the W kernel (pairs of columns from c0, rows i0 = 0, 4, ... <= j0 + 1; the tiles on / below the diagonal never receive a product)
+    int tc[MAXC];
+    {
+        int i0 = 0, j0 = c0;
+        auto step1 = [&]() {
+            i0 += 4;
+            if (i0 > j0 + 1) { i0 = 0; j0 += 2; }
+        };
+        for (int x = 0; x < w; ++x) step1();
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            tc[u] = (j0 < c1) ? (i0 | (j0 << 8)) : (255 << 8);
+            step1(); step1(); step1(); step1();
+        }
+    }
+    f32x4 acc[MAXC][8];
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[u][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging table (lane = step k): item w + 4 x of image k -> tile slot in the matrix' array | image slot << 12 | valid << 20
+    int stab[NST];
+    {
+        const int k = lane;
+        const int nstrip = (k < c0) ? k + 1 : ((k <= NT - 2) ? 1 : 0);       // strip tiles from memory: all of it, or just the diagonal slot's M_kk
+        const int js = max(k + 1, c0), nrow = max(c1 - js, 0);
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int it = w + 4 * x;
+            int e = 0;
+            if (k <= c1 - 1 && it < nstrip + nrow) {
+                if (it < nstrip) {
+                    const int i = (k < c0) ? it : k;
+                    e = tslot(NT, i, k) | (i << 12) | (1 << 20);
+                } else {
+                    const int j = js + (it - nstrip);
+                    e = tslot(NT, k, j) | ((k + 1 + (j - js)) << 12) | (1 << 20);
+                }
+            }
+            stab[x] = e;
+        }
+    }
+    auto load_step = [&](f32x4 (&S)[NST], const int k) {
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int e = __builtin_amdgcn_readlane(stab[x], min(k, 63));
+            S[x] = bload4(Tr, (k < c1 && (e >> 20)) ? lane16 : OOB, (e & 0xfff) * 1024);
+        }
+    };
+    auto write_step = [&](const f32x4 (&S)[NST], const int k) {
+#pragma unroll
+        for (int x = 0; x < NST; ++x) {
+            const int e = __builtin_amdgcn_readlane(stab[x], min(k, 63));
+            if (k < c1 && (e >> 20)) sbuf[((k & 1) * BUFT + ((e >> 12) & 31)) * 64 + lane] = S[x];
+        }
+    };
+    // column k of the range: its accumulators are complete -> final tiles
+    auto finalize = [&](const int k) {
+        const int cur = k & 1;
+        int g4o = g4, c16o = c16;
+        asm volatile("" : "+v"(g4o), "+v"(c16o));                          // (rebuilt per call: 8 registers that need not live across the products)
+        f32x4 negI, keepv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { negI[q] = (g4o + q == c16o) ? -1.0f : 0.0f; keepv[q] = (g4o + q < pN) ? 1.0f : 0.0f; }
+        f32x4 Mkk;
+        if (k == NT - 1) Mkk = bload4(Tr, lane16, tslot(NT, k, k) * 1024);                       // the last diagonal tile is fp32 (row -alpha^T)
+        else Mkk = join_h2(sbuf[(cur * BUFT + k) * 64 + lane]) * uinv;
+        const f32x4 nV = xty0(Mkk, negI);
+        auto one = [&](const f32x4 av, int i) {
+            asm volatile("" : "+s"(i));                                     // (opaque: per-tile predicates / addresses must not be hoisted out of the step loop -- 400 spills)
+            if (i < k) {                                                    // uniform
+                const f32x4 v = xty0(nV, av * un);
+                trace_tile(v, i, k);
+                if (k == NT - 1) alpha_tile(v, i);
+                const f32x4 sp = split_h2((k == NT - 1) ? v * keepv : v, usc);
+                bstore4(Tr, sp, toff(NT, i, k, lane), 0);
+                sbuf[(cur * BUFT + i) * 64 + lane] = sp;
+                __builtin_amdgcn_sched_barrier(0);                          // one tile after the other: interleaving 8 of them costs 100 VGPRs
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            int p = tc[u];
+            asm volatile("" : "+s"(p));
+            const int i0 = p & 255, j0 = p >> 8;
+            // the chunk's tiles of column k, picked with selects (no control flow around the accumulators: branches that read them made the
+            // register allocator shuffle the whole set through scratch at the loop header)
+            const bool first = j0 == k, any = first || j0 + 1 == k;
+            f32x4 col[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) col[x][q] = first ? acc[u][2 * x][q] : acc[u][2 * x + 1][q];
+            if (any) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) one(col[x], i0 + x);
+            }
+        }
+        if (w == 0) {                                                       // the diagonal tile: trace / alpha once
+            trace_tile(Mkk, k, k);
+            if (k == NT - 1) {
+                alpha_tile(Mkk, k);
+                bstore4(Tr, split_h2(Mkk * keepv, usc), toff(NT, k, k, lane), 0);               // the last diagonal slot, now in W's format
+            }
+        }
+    };
+    auto mul_step = [&](const int k) {
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(sbuf) + (k & 1) * BUFT * 1024 + lane16;
+        const int js = max(k + 1, c0);
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            int p = tc[u];
+            asm volatile("" : "+s"(p));
+            const int j0 = p >> 8, i0 = p & 255;
+            // the chunk takes part while its second column is open (j0 + 1 > k).  Its first column may already be final (j0 == k) and its second one
+            // may lie outside the range: those accumulators are dead / never stored, so both columns are always multiplied (their row-image slots are
+            // stale but inside the buffer)
+            if (j0 + 1 > k && j0 < c1 && i0 <= k) {
+                const unsigned char* pr = sb + (k + 1 - js + j0) * 1024;   // the row image starts at slot k + 1 with column js
+                const f32x4 R0 = *reinterpret_cast<const f32x4*>(pr), R1 = *reinterpret_cast<const f32x4*>(pr + 1024);
+#pragma unroll
+                for (int hx = 0; hx < 4; hx += 2) {                         // two rows at a time: 16 operand registers instead of 24
+                    const f32x4 Sa = *reinterpret_cast<const f32x4*>(sb + ((i0 + hx <= k) ? i0 + hx : ZT) * 1024);
+                    const f32x4 Sb = *reinterpret_cast<const f32x4*>(sb + ((i0 + hx + 1 <= k) ? i0 + hx + 1 : ZT) * 1024);
+                    f32x4& a00 = acc[u][2 * hx], &a01 = acc[u][2 * hx + 1], &a10 = acc[u][2 * hx + 2], &a11 = acc[u][2 * hx + 3];
+                    a00 = xtyh1<0>(R0, Sa, a00); a01 = xtyh1<0>(R1, Sa, a01); a10 = xtyh1<0>(R0, Sb, a10); a11 = xtyh1<0>(R1, Sb, a11);
+                    a00 = xtyh1<1>(R0, Sa, a00); a01 = xtyh1<1>(R1, Sa, a01); a10 = xtyh1<1>(R0, Sb, a10); a11 = xtyh1<1>(R1, Sb, a11);
+                    a00 = xtyh1<2>(R0, Sa, a00); a01 = xtyh1<2>(R1, Sa, a01); a10 = xtyh1<2>(R0, Sb, a10); a11 = xtyh1<2>(R1, Sb, a11);
+                }
+            }
+        }
+    };
+    {
+        f32x4 S[NST];
+        if (w < 2) sbuf[(w * BUFT + ZT) * 64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        load_step(S, 0);
+        write_step(S, 0);
+        load_step(S, 1);
+        __syncthreads();
+        for (int k = 0; k < c1; ++k) {
+            if (k >= c0) {
+                finalize(k);
+                __syncthreads();
+            }
+            if (k <= c1 - 2) mul_step(k);
+            write_step(S, k + 1);
+            load_step(S, k + 2);
+            __syncthreads();
+        }
+    }
+    // ---- scalars: partial sums handed on in the matrix' TiledScal; the last range writes the outputs (as tiled_invert_kernel) ----
+    trpp = wave_allsum(trpp);
+    asum = wave_allsum(asum);
+    if (lane == 0) { tr_w[w] = trpp; as_w[w] = asum; }
+    __syncthreads();
+    if (tid == 0) {
+        const float trs = sc.trp + (tr_w[0] + tr_w[1] + tr_w[2] + tr_w[3]);
+        const float ass = sc.asp + (as_w[0] + as_w[1] + as_w[2] + as_w[3]);
+        if (!lastrange) {
+            t.scal[m].trp = trs;
+            t.scal[m].asp = ass;
+        } else {
+            const float tr = trs * ldexpf(1.0f, -2 * sc.msc);
+            const float svc = a.sv[c], nzc = a.noise[c];
+            const bool ok = !failed;
+            a.logp[bc] = ok ? (-0.5f * sc.quad - 0.34657359027997264f * sc.lsum2 - (float)N * DKT_HALF_LOG_2PI) : qnan;
+            a.jitter_used[bc] = 0.f;
+            a.info[bc] = sc.fail_at;
+            a.dmean[bc] = ok ? ass : qnan;
+            a.dnoise[bc] = ok ? -0.5f * tr : qnan;
+            a.dsv[bc] = ok ? 0.5f * ((sc.quad - (float)N) + nzc * tr) / svc : qnan;
+            const float cw = a.cls_weight ? a.cls_weight[c] : 1.0f;
+            t.scal[m].coef = ok ? -0.5f * cw * svc * ldexpf(1.0f, -2 * sc.msc) : qnan;
+        }
+    }
+}
+
+// every image of every range fits the GT = 28 slots of a buffer (strip + row tiles)
+inline bool invres_fits(const WRanges& r, const int NT) {
+    for (int gq = 0; gq < r.ng; ++gq) {
+        const int c0 = r.c0[gq], c1 = r.c0[gq + 1];
+        if (c1 - 1 > 63) return false;
+        for (int k = 0; k < c1; ++k) {
+            const int nstrip = (k < c0) ? k + 1 : ((k <= NT - 2) ? 1 : 0);
+            const int js = k + 1 > c0 ? k + 1 : c0, nrow = c1 - js > 0 ? c1 - js : 0;
+            if (nstrip + nrow > 28 || k + 1 + nrow > 28) return false;
+        }
+    }
+    return true;
+}
+
+int g_tiled_wgs = -1;
+inline int tiled_wgs() {
+    if (g_tiled_wgs < 0) {
+        const char* v = getenv("DKT_MLL_TILED_WGS");
+        g_tiled_wgs = (v && v[0] == '2') ? 2 : 3;
+    }
+    return g_tiled_wgs;
+}
+
+int g_tiled_invres = -1;
+inline bool tiled_invres() {
+    if (g_tiled_invres < 0) {
+        const char* v = getenv("DKT_MLL_TILED_INVRES");                      // default OFF: measured at parity with the block-column kernel (7.3 vs 6.5 ms at
+        g_tiled_invres = (v && v[0] == '1') ? 1 : 0;                           // N = 420, 4.0 vs 4.1 at N = 320: 65 short steps per matrix)
+    }
+    return g_tiled_invres != 0;
+}
+
 int g_tiled_wres = -1;
 inline bool tiled_wres() {
     if (g_tiled_wres < 0) {
@@ -1162,8 +1449,8 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
     const dim3 fgrid(8 * ((bcnt + 7) / 8) * t.a.C), blk(64 * TB);
     hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
-#if defined(DKT_TILED_CLOCKS) || defined(DKT_TILED_NOMATH)
-    constexpr bool SPLIT_OK = false;                                        // the measurement builds instrument the fp32 kernels
+#if defined(DKT_TILED_NOMATH)
+    constexpr bool SPLIT_OK = false;                                        // the traffic-only build instruments the fp32 kernels
 #else
     constexpr bool SPLIT_OK = true;
 #endif
@@ -1171,8 +1458,11 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     // W with resident accumulators.  DKT_MLL_TILED_WRES=0 -> round 3's kernels (fp32 factor / invert, block-column W on f16 products of fp32
     // tiles); DKT_MLL_TILED_F16=0 -> round 2's all-fp32 kernels.  A forward-only call (no W) runs the fp32 factor / invert.
     const bool msplit = SPLIT_OK && grad && tiled_f16() && tiled_wres() && t.a.C <= 64;
-    if (msplit) hipLaunchKernelGGL((tiled_factor_kernel<MC, true>), fgrid, blk, 0, st, t);
-    else hipLaunchKernelGGL((tiled_factor_kernel<MC, false>), fgrid, blk, 0, st, t);
+    // (MC = 7, i.e. N > 383, keeps 2: with one step's operands in 168 registers its 84-step K loops expose every load -- 7.0 vs 7.1 ms at N = 420;
+    //  MC <= 6 gains 20 %: 3.97 vs 4.94 ms at N = 320)
+    if (msplit && tiled_wgs() >= 3 && MC <= 6) hipLaunchKernelGGL((tiled_factor_kernel<MC <= 6 ? MC : 6, true, 3>), fgrid, blk, 0, st, t);
+    else if (msplit) hipLaunchKernelGGL((tiled_factor_kernel<MC, true, 2>), fgrid, blk, 0, st, t);
+    else hipLaunchKernelGGL((tiled_factor_kernel<MC, false, 2>), fgrid, blk, 0, st, t);
 #ifdef DKT_TILED_CLOCKS
     return;
 #endif
@@ -1181,13 +1471,20 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         return;
     }
     if (msplit) {
-        hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         const WRanges rg = wres_ranges(t.NT);
         const size_t lds = (size_t)2 * 32 * 1024 + 2 * 64 * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+            (void)hipFuncSetAttribute((const void*)tiled_invres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
             attr_set = true;
+        }
+        if (tiled_invres() && invres_fits(rg, t.NT)) {
+            for (int gq = 0; gq < rg.ng; ++gq) hipLaunchKernelGGL((tiled_invres_kernel<WRES_MAXC>), dim3(nmat), dim3(256), (size_t)2 * 32 * 1024, st, t, rg, gq);
+        } else if (tiled_wgs() >= 3 && MC <= 6) {
+            hipLaunchKernelGGL((tiled_invert_kernel<MC <= 6 ? MC : 6, true, true, 3>), dim3(nmat), blk, 0, st, t);
+        } else {
+            hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         }
         hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         return;
@@ -1202,7 +1499,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 
 }  // namespace
 
-void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; }      // dkt_reload_env()
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills

@@ -3,7 +3,9 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 K=${1:-mll}
-OUT=$ROOT/gpurun_out/pmc_$K
+shift
+ARGS="$@"
+OUT=$ROOT/gpurun_out/pmc_${K}${DKT_PMC_TAG:-}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -15,7 +17,7 @@ for pmc in "SQ_WAVES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_CYCLES G
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/p$i -- python $ROOT/tools/run_one_kernel.py $K > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $OUT/p$i -- python $ROOT/tools/run_one_kernel.py $K $ARGS > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
