@@ -491,6 +491,17 @@ def _kernel_report(cfg, m, unit_rows, traffic):
                          note="EXECUTED v_mfma_f32_16x16x16_f16 flops (%d tile products x 3 plane products per class matrix) / dense f16 peak; the kernel is "
                               "bound by VALU issue + the dependency chain of the diagonal-tile sweeps, not by this pipe (DESIGN.md 4.2)" % prods)
             other = dict(mat, note="algorithmic fp32-equivalent flops / fp32 MFMA peak (the pipe rounds 1-2 used; kept for comparison across rounds)")
+        if name == "dkt_mll_f32" and n + 1 > 128:
+            # tile-array path (127 < N <= 447): since round 4 the left-looking K loops of the factorisation / inverse and the whole K^-1 product run as
+            # f16-split tile products (3 v_mfma_f32_16x16x16_f16 each), the in-block panels / updates and the diagonal sweeps in fp32.  The kernels are
+            # bound by their tile streams (traffic-only builds: profiles/r04/v0_tiled_traffic_ceiling.txt), not by a matrix pipe: `fabric_gbs` = PMC
+            # bytes at the L2 <-> fabric boundary / time.
+            first = dict(bound="mfma", achieved=k["tflops"], peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / MFMA_F16_PEAK_TFLOPS, 4),
+                         note="algorithmic fp32-equivalent flops / dense f16 MFMA peak (the pipe the K loops and the K^-1 product run on); the kernels are bound by "
+                              "their tile streams, see traffic / fabric_gbs")
+            other = dict(mat, note="algorithmic fp32-equivalent flops / fp32 MFMA peak (the pipe rounds 1-3 used for the factorisation / inverse; kept for comparison)")
+            if tr:
+                first["fabric_gbs"] = round(tr / k["ms"] / 1e6, 1)
         r = dict(kernel=name, **first, traffic=tr, traffic_unit="bytes/launch (PMC: FETCH_SIZE + WRITE_SIZE at L2<->fabric)",
                  traffic_source=src, algorithmic_bytes_per_launch=alg[name]["bytes"] * b,
                  algorithmic_flops_per_launch=alg[name]["flops"] * b, avg_launch_ms=k["ms"], episodes_per_launch=b)

@@ -26,7 +26,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
 KERNEL_TABLE = {
     # dkt_gram_f32
     "gram_sym_ep_split_kernel": "dkt_gram_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_sym_tiles_split_kernel": "dkt_gram_f32",
-    "gram_sym_big_ep_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
+    "gram_sym_bigep_f16x2_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
     # dkt_gram_bwd_f32
     "gram_bwd_ep_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
     "gram_bwd_rows_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_big_ep_kernel": "dkt_gram_bwd_f32", "gram_small_bwd_kernel": "dkt_gram_bwd_f32",
@@ -34,7 +34,7 @@ KERNEL_TABLE = {
     # dkt_mll_f32
     "mll_h2e_kernel": "dkt_mll_f32", "mll_h2_kernel": "dkt_mll_f32", "mll_mfma_kernel": "dkt_mll_f32", "mll_generic_kernel": "dkt_mll_f32",
     "tiled_etile_kernel": "dkt_mll_f32", "tiled_factor_kernel": "dkt_mll_f32", "tiled_invert_kernel": "dkt_mll_f32", "tiled_w_kernel": "dkt_mll_f32",
-    "tiled_wres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
+    "tiled_wres_kernel": "dkt_mll_f32", "tiled_invres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
     "big_trmv_kernel": "dkt_mll_f32", "big_finish_kernel": "dkt_mll_f32",
     # the element-wise chain rules
     "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",

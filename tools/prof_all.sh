@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): for every BASELINE config a rocprofv3 kernel-trace + stats run of bench.py's own step and separate
 # PMC passes (FETCH_SIZE, WRITE_SIZE; for the headline config also the SQ / TCC counters); compact summaries ->
-# gpurun_out/prof_r04/<config>_summary.txt (copied to profiles/r03/ and condensed into profiles/pmc_traffic.json by
+# gpurun_out/prof_r04/<config>_summary.txt (copied to profiles/r04/ and condensed into profiles/pmc_traffic.json by
 # tools/make_traffic_json.py).   usage: tools/prof_all.sh [configs...]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
