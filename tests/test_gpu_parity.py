@@ -825,6 +825,79 @@ def test_mll_tile_array_w_kernel_class_weights_signs_and_hyper_ranges(cuda, n, c
     assert rel_l2(o32["w"].cpu().numpy(), w_ref) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("switch", ["DKT_MLL_TILED_WRES=0", "DKT_MLL_TILED_F16=0", "DKT_MLL_TILED_INVRES=1", "DKT_MLL_TILED_WGS=2"])
+@pytest.mark.parametrize("n,c", [(320, 20), (420, 3), (190, 5)])
+def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
+    """The tile-array marginal likelihood's alternative pipelines -- round 3's kernels (fp32 tile arrays, block-column W), round 2's all-fp32 products, the
+    resident-accumulator invert kernel (opt-in), two instead of three workgroups per CU -- against float64 and against the default (round 4: f16-split tile
+    arrays, W with resident accumulators) on the same inputs."""
+    rng = np.random.default_rng(n * c)
+    b = 9                                                       # more than one 8-episode XCD group
+    z = rng.standard_normal((b, n, 64))
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    e_np = np.einsum("bnd,bmd->bnm", z, z)
+    y = np.sign(rng.standard_normal((c, n)))
+    sv = 0.5 + 0.07 * np.arange(c)
+    mean = 0.03 * rng.standard_normal(c)
+    noise = np.full(c, 0.1)
+    cw = np.full(c, -1.0 / (c * n))
+    args = [dev_t(x, cuda) for x in (e_np, y, sv, mean, noise)]
+    ref = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    k, v = switch.split("=")
+    os.environ[k] = v
+    try:
+        o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    finally:
+        del os.environ[k]
+    assert int(o["info"].abs().max().item()) == 0 and torch.equal(o["w"], o["w"].transpose(1, 2))
+    assert rel_l2(o["w"].cpu().numpy(), ref["w"].cpu().numpy()) < 2e-5
+    np.testing.assert_allclose(o["logp"].cpu().numpy(), ref["logp"].cpu().numpy(), rtol=2e-5)
+    assert rel_l2(o["alpha"].cpu().numpy(), ref["alpha"].cpu().numpy()) < 2e-5
+    for key in ("dsv", "dmean", "dnoise"):
+        assert rel_l2(o[key].cpu().numpy(), ref[key].cpu().numpy()) < 1e-3, key
+    for bi in (0, b - 1):                                       # float64 on the first and the last episode
+        w_ref = np.zeros((n, n))
+        for kc in range(c):
+            kk = sv[kc] * e_np[bi] + noise[kc] * np.eye(n)
+            r = y[kc] - mean[kc]
+            alpha = np.linalg.solve(kk, r)
+            logp = -0.5 * r @ alpha - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+            assert abs(o["logp"][bi, kc].item() - logp) < MLL_RTOL * abs(logp)
+            w_ref += cw[kc] * sv[kc] * 0.5 * (np.outer(alpha, alpha) - np.linalg.inv(kk))
+        assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
+
+
+@pytest.mark.parametrize("n,d", [(190, 512), (320, 512), (420, 512), (431, 36)])
+def test_gram_large_n_kernel_twins(cuda, n, d):
+    """N > 128, unit rows, a batch that takes the round-4 kernels (episode-resident Gram for N <= 432, 128-row Gram backward for N > 256): against the round-2
+    kernels on the same inputs (DKT_GRAM_BIG_EP=0 / DKT_GRAM_BWD_ROWS8=0) and against float64 on sampled episodes; symmetric, unit diagonal."""
+    b = 72
+    g = torch.Generator(device=cuda).manual_seed(n + d)
+    z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda) * torch.exp(torch.randn(b, n, d, generator=g, device=cuda)), dim=2).contiguous()
+    w = torch.randn(b, n, n, generator=g, device=cuda)
+    w = (w + w.transpose(1, 2)).contiguous()
+    e_new = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+    dz_new = ops.gram_bwd(w, z, None, unit_rows=True, w_symmetric=True)
+    os.environ["DKT_GRAM_BIG_EP"] = "0"
+    os.environ["DKT_GRAM_BWD_ROWS8"] = "0"
+    try:
+        e_old = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
+        dz_old = ops.gram_bwd(w, z, None, unit_rows=True, w_symmetric=True)
+    finally:
+        del os.environ["DKT_GRAM_BIG_EP"], os.environ["DKT_GRAM_BWD_ROWS8"]
+    assert torch.equal(e_new, e_new.transpose(1, 2))
+    assert (torch.diagonal(e_new, dim1=1, dim2=2) - 1.0).abs().max().item() < 2e-6
+    assert (e_new - e_old).abs().max().item() < 1e-6
+    assert float((dz_new - dz_old).norm() / dz_old.norm()) < 1e-6
+    for bi in (0, b - 1):
+        z64 = z[bi].double().cpu().numpy()
+        ref = z64 @ z64.T
+        mag = np.abs(z64) @ np.abs(z64).T
+        assert (np.abs(e_new[bi].cpu().numpy() - ref) / mag).max() < 6e-7
+        dref = 2.0 * w[bi].double().cpu().numpy() @ z64
+        assert rel_l2(dz_new[bi].cpu().numpy(), dref) < 2e-6
+
+
 @pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (257, 100)])
 def test_gram_large_n_unit_rows_kernel(cuda, n, d):
     """Symmetric linear Gram at N > 128 with the unit-row promise: the 64 x 64-tile f16-split kernel (dkt_gram_big.hip) against float64
