@@ -4,5 +4,5 @@ O=gpurun_out/r04; mkdir -p $O
 ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $O/v9_pytest_gpu.log
 ( timeout 900 python bench.py 2>/dev/null | grep "^{" ) > $O/v9_bench_full.json
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $O/v9_smoke.log
-cp deep-kernel-transfer_amd/build/libdkt_hip.so.resource_usage.json $O/resource_usage.json 2>/dev/null
+# (build/ does not travel to the GPU box: copy deep-kernel-transfer_amd/build/libdkt_hip.so.resource_usage.json to profiles/r04/resource_usage.json in the build container)
 tail -3 $O/v9_pytest_gpu.log; cat $O/v9_smoke.log; tail -c 400 $O/v9_bench_full.json
