@@ -21,7 +21,7 @@ SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_smal
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
 DIAG_SOURCES = ["dkt_diag.hip"]
 DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
-HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "dkt_abi.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(INCLUDE, "dkt_abi.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 _c_p = ctypes.c_void_p

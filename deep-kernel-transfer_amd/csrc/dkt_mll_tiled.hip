@@ -177,7 +177,8 @@ __device__ __forceinline__ f32x4 neg_identity(const Geo& g) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // Factorisation.  Wave w owns the tile columns j = i0 + w + 4 bb of block row I.
 // WGS = workgroups per CU the register budget is set for.  2: the operands of two K steps in registers (loads one step ahead).  3 (round 4, the F16
-// pipeline's default; DKT_MLL_TILED_WGS=2 restores 2): ONE step's operands (168 VGPRs) -- a lone workgroup of this kernel needs 147 us per N = 420
+// pipeline's default; DKT_MLL_TILED_WGS=2 restores 2): ONE step's operands (168 VGPRs; the block rows after the first are instantiated with MC - 1 tile
+// columns per wave, see dkt_mll_tiled_factor_row.inc) -- a lone workgroup of this kernel needs 147 us per N = 420
 // matrix and two co-resident ones 165 us each: the kernel is bound by the serial chain of a block row (sweep -> barrier -> panel -> barrier -> updates),
 // not by the matrix pipe or memory (profiles/r04/v4_factor_phase_clocks.log), so a third workgroup per CU fills idle pipes.
 template <int MC, bool F16, int WGS>
@@ -252,141 +253,15 @@ __global__ __launch_bounds__(64 * TB, WGS) void tiled_factor_kernel(TiledArgs t)
 #define TCLK(i) do { } while (0)
 #endif
     for (int i0 = 0; i0 < NT; i0 += TB) {
-        f32x4 acc[TB][MC];
-        TCLK(5);
-        // ---- K loop over the finished tile rows, operands double-buffered; its first four steps are the block's own E tiles (one tile
-        //      row per step, S = -(sv E + noise I) / kappa formed by the VALU as they arrive), so that their latency is hidden too ----
-        auto loade = [&](f32x4 (&Y)[MC], const int r) {
-#pragma unroll
-            for (int bb = 0; bb < MC; ++bb) {
-                const int i = i0 + r, j = i0 + w + TB * bb;
-                Y[bb] = bload4(f.Et, lane16, ((i < NT && j < NT && j >= i) ? tslot(NT, i, j) : (int)ntt) * 1024);
-            }
-        };
-        auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int kt) {
-            const bool kin = kt < i0;
-#pragma unroll
-            for (int r = 0; r < TB; ++r) X[r] = tload(Tr, NT, kin && i0 + r < NT, kt, i0 + r, lane16);
-#pragma unroll
-            for (int bb = 0; bb < MC; ++bb) {
-                const int j = i0 + w + TB * bb;
-                Y[bb] = tload(Tr, NT, kin && j < NT, kt, j, lane16);
-            }
-        };
-        auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC]) {
-#pragma unroll
-            for (int bb = 0; bb < MC; ++bb) {
-                if (i0 + w + TB * bb < NT) {
-                    if constexpr (F16) xtyh4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
-                    else xty4_x(X, Y[bb], acc[0][bb], acc[1][bb], acc[2][bb], acc[3][bb]);
-                }
-            }
-        };
-        {
-            f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
-            auto forme = [&](const f32x4 (&Y)[MC], const int r) {               // r is a constant after unrolling
-#pragma unroll
-                for (int bb = 0; bb < MC; ++bb) {
-                    const int i = i0 + r, j = i0 + w + TB * bb;
-                    acc[r][bb] = (i < NT && j < NT && j >= i) ? form_from_e(f, g, i, j, Y[bb]) : zero4;
-                    if constexpr (F16) acc[r][bb] *= TWO30;                 // the K loop below accumulates (2^15 R)^T (2^15 R)
-                }
-            };
-            loade(Y0, 0);
-            loade(Y1, 1);
-            forme(Y0, 0);
-            loade(Y0, 2);
-            forme(Y1, 1);
-            loade(Y1, 3);
-            forme(Y0, 2);
-            if constexpr (WGS <= 2) {
-                loadk(X0, Y0, 0);
-                forme(Y1, 3);
-                TCLK(0);
-                for (int kt = 0; kt < i0; kt += 2) {
-                    loadk(X1, Y1, kt + 1);
-                    mulk(X0, Y0);
-                    loadk(X0, Y0, kt + 2);
-                    mulk(X1, Y1);
-                }
-            } else {
-                forme(Y1, 3);
-                TCLK(0);
-                for (int kt = 0; kt < i0; ++kt) {                           // one step's operands at a time: the other workgroups of the CU cover the load
-                    loadk(X0, Y0, kt);
-                    mulk(X0, Y0);
-                }
-            }
+        if (WGS >= 3 && MC >= 2 && i0 > 0 && 4 * (MC - 1) >= NT - TB) {
+#define MCB (MC >= 2 ? MC - 1 : 1)
+#include "dkt_mll_tiled_factor_row.inc"
+#undef MCB
+        } else {
+#define MCB MC
+#include "dkt_mll_tiled_factor_row.inc"
+#undef MCB
         }
-        if constexpr (F16) {
-#pragma unroll
-            for (int r = 0; r < TB; ++r)
-#pragma unroll
-                for (int bb = 0; bb < MC; ++bb) acc[r][bb] *= TWOM30;
-        }
-        TCLK(1);
-        // ---- the block's tile rows ----
-#pragma unroll
-        for (int r = 0; r < TB; ++r) {
-            const int i = i0 + r;
-            if (i < NT) {                                                   // uniform
-                if (w == r) {
-                    float x[16], dv;
-                    sweep_begin(acc[r][0], x, dv);
-                    const bool last = i == NT - 1;
-                    if (last) sweep_plain<0, true>(x, dv, g.ln, g.pN);
-                    else sweep_plain<0, false>(x, dv, g.ln, g.pN);
-                    const f32x4 M = sweep_end(x, g.ln);
-                    const bool valid = !last || (g.c16 < g.pN);
-                    const unsigned long long badm = __ballot(valid && !(dv > 0.f)) & 0xffffull;
-                    const int first = (int)__builtin_ctzll(badm | 0x10000ull);
-                    fail_at = (fail_at == 0 && badm != 0) ? 16 * i + first + 1 : fail_at;
-                    lsum += (valid && g.ln.g0) ? __builtin_amdgcn_logf(dv) : 0.f;
-                    if (last) quad = -__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dv), g.pN));
-                    mbuf[lane] = M;
-                    acc[r][0] = M;                                          // the diagonal slot keeps M_ii
-                }
-                TCLK(2);
-                __syncthreads();
-                TCLK(3);
-                const f32x4 nV = xty0(mbuf[lane], negI);
-#pragma unroll
-                for (int bb = 0; bb < MC; ++bb) {
-                    const int j = i0 + w + TB * bb;
-                    if (j > i && j < NT) acc[r][bb] = xty0(nV, acc[r][bb]);
-                }
-                if (w > r && i0 + w < NT) xbuf[w][lane] = acc[r][0];       // R(i, i0 + w): the X operand of block row w's update
-                __syncthreads();
-#pragma unroll
-                for (int r2 = r + 1; r2 < TB; ++r2) {
-                    if (i0 + r2 < NT) {
-                        const f32x4 X = xbuf[r2][lane];
-#pragma unroll
-                        for (int bb = 0; bb < MC; ++bb) {
-                            const int j = i0 + w + TB * bb;
-                            if (j >= i0 + r2 && j < NT) acc[r2][bb] = xty(X, acc[r][bb], acc[r2][bb]);
-                        }
-                    }
-                }
-                TCLK(4);
-            }
-        }
-        TCLK(4);
-        // ---- store the block row ----
-#pragma unroll
-        for (int r = 0; r < TB; ++r)
-#pragma unroll
-            for (int bb = 0; bb < MC; ++bb) {
-                const int i = i0 + r, j = i0 + w + TB * bb;
-                f32x4 v = acc[r][bb];
-                if constexpr (F16) {
-                    // R tiles split at 2^15, the diagonal slot's M_ii at usc -- except the last diagonal tile (row -alpha^T is unbounded): fp32
-                    if (j > i) v = split_h2(v, 32768.0f);
-                    else if (i != NT - 1) v = split_h2(v, usc);
-                }
-                bstore4(Tr, v, (i < NT && j < NT && j >= i) ? toff(NT, i, j, lane) : OOB, 0);
-            }
-        __syncthreads();                                                    // visible to every wave's loads of the next block row
     }
 #ifdef DKT_TILED_CLOCKS
     TCLK(5);
@@ -855,7 +730,12 @@ __global__ __launch_bounds__(64 * WB, WB == 4 ? DKT_TILED_W_WGS : 2) void tiled_
 // sigma U^2 sum_c coef_c M_c^T M_c and are negated when a class changes sigma (class weights of one sign: never).
 struct WRanges { int ng; int c0[10]; };          // column ranges [c0[g], c0[g + 1]) of W, g < ng
 
-template <int MAXC>
+// DMA (default; DKT_MLL_TILED_WDMA=0 restores the register-staged copy): the staged tiles go from memory straight into the LDS image with
+// global_load_lds_dwordx4 (they are already in W's format) -- no staging registers, no copy phase; the 28 VGPRs that frees hold a second set of a chunk's
+// operands, so the six ds_read_b128 of chunk u + 1 fly during the 24 MFMAs of chunk u.
+typedef __attribute__((address_space(3))) unsigned char wres_lds_u8;
+typedef __attribute__((address_space(1))) const unsigned char wres_glb_u8;
+template <int MAXC, bool DMA>
 __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges rg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wres_smem[];
     const MllArgs& a = t.a;
@@ -946,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         if (n.gi >= steps_per_class) { n.gi = 0; ++n.c; }
         return n;
     };
-    auto load_step = [&](f32x4 (&S)[NST], const Grp gr) {
+    auto load_step = [&](auto& S, const Grp gr) {
         const int cbase = min(gr.c, C - 1) * (int)(ntt + 1);
         const bool in = gr.c < C;
 #pragma unroll
@@ -955,11 +835,24 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
             S[x] = bload4(Tr, (in && (e & 0x2000)) ? lane16 : OOB, (cbase + (e & 0xfff)) * 1024);
         }
     };
-    auto write_step = [&](const f32x4 (&S)[NST], const Grp gr, const int bufi) {
+    auto write_step = [&](const auto& S, const Grp gr, const int bufi) {
 #pragma unroll
         for (int x = 0; x < NST; ++x) {
             const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
             if (e & 0x2000) sbuf[(bufi * BUFT + w + 4 * x) * 64 + lane] = S[x];
+        }
+    };
+    const unsigned char* tbase = reinterpret_cast<const unsigned char*>(t.tiles + (size_t)bl * C * (ntt + 1) * 256) + lane16;
+    auto dma_step = [&](const Grp gr, const int bufi) {
+        const int cbase = min(gr.c, C - 1) * (int)(ntt + 1);
+        if (gr.c < C) {
+#pragma unroll
+            for (int x = 0; x < NST; ++x) {
+                const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
+                if (e & 0x2000)
+                    __builtin_amdgcn_global_load_lds((wres_glb_u8*)(tbase + (size_t)(cbase + (e & 0xfff)) * 1024),
+                                                     (wres_lds_u8*)(wres_smem + (bufi * BUFT + w + 4 * x) * 1024), 16, 0, 0);
+            }
         }
     };
     float curkap = 0.0f;                                                    // the accumulators' unit (0: nothing accumulated yet)
@@ -986,6 +879,54 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         for (int k = gka; k < gkb; ++k) {
             // column j takes part in strip k when j <= k; the chunks are column-pair-major, so the participants are a prefix of the wave's list
             const int kk = min(k, c1 - 1);
+            if constexpr (DMA) {
+                // two operand sets: chunk u + 1's reads are issued before chunk u's products
+                f32x4 A[2][4], B0[2], B1[2];
+                auto fetch = [&](const int set, int p) {
+                    const unsigned char* pa = sb + (sbase + (p & 255)) * 1024;
+                    const unsigned char* pb = sb + (sbase + (p >> 8)) * 1024;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) A[set][x] = *reinterpret_cast<const f32x4*>(pa + x * 1024);
+                    B0[set] = *reinterpret_cast<const f32x4*>(pb);
+                    B1[set] = *reinterpret_cast<const f32x4*>(pb + 1024);      // (stale when column j0 + 1 does not take part: not used then)
+                };
+                int p0 = tc[0];
+                asm volatile("" : "+s"(p0));
+                if ((p0 >> 8) <= kk) fetch(0, p0);
+#pragma unroll
+                for (int u = 0; u < MAXC; ++u) {
+                    int p = tc[u];
+                    asm volatile("" : "+s"(p));
+                    const int j0 = p >> 8;
+                    if (j0 <= kk) {
+                        constexpr int cs = 0;
+                        const int set = u & 1;
+                        if (u + 1 < MAXC) {
+                            // UNCONDITIONAL (a chunk that does not take part re-reads this chunk's tiles): a branch around the reads would join
+                            // in front of the MFMAs and turn their s_waitcnt lgkmcnt(6) into lgkmcnt(0), i.e. no overlap
+                            int pn = tc[u + 1 < MAXC ? u + 1 : u];
+                            asm volatile("" : "+s"(pn));
+                            fetch(set ^ 1, ((pn >> 8) <= kk) ? pn : p);
+                        }
+                        (void)cs;
+                        if (j0 + 1 <= kk) {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<0>(A[set][x], B0[set], acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<0>(A[set][x], B1[set], acc[u][2 * x + 1]); }
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<1>(A[set][x], B0[set], acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<1>(A[set][x], B1[set], acc[u][2 * x + 1]); }
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) { acc[u][2 * x] = xtyh1<2>(A[set][x], B0[set], acc[u][2 * x]); acc[u][2 * x + 1] = xtyh1<2>(A[set][x], B1[set], acc[u][2 * x + 1]); }
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<0>(A[set][x], B0[set], acc[u][2 * x]);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<1>(A[set][x], B0[set], acc[u][2 * x]);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) acc[u][2 * x] = xtyh1<2>(A[set][x], B0[set], acc[u][2 * x]);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < MAXC; ++u) {
                 int p = tc[u];
@@ -1016,17 +957,22 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
                     }
                 }
             }
+            }
             sbase += lim(k);
         }
     };
     {
         // one staging array: the loads of step s + 2 are issued right after step s + 1 went to LDS and fly during the barrier and step s + 1's products
-        f32x4 S[NST];
+        f32x4 S[DMA ? 1 : NST];
         Grp gA{0, 0};                                                       // the group being multiplied
         Grp gB = next_group(gA), gC = next_group(gB);                       // ... being split into LDS, ... being loaded
-        load_step(S, gA);
-        write_step(S, gA, 0);
-        load_step(S, gB);
+        if constexpr (DMA) {
+            dma_step(gA, 0);
+        } else {
+            load_step(S, gA);
+            write_step(S, gA, 0);
+            load_step(S, gB);
+        }
         __syncthreads();
 #ifdef DKT_WRES_CLOCKS      // measurement build (tools/wres_phase_clocks.py): shader clocks of this wave per phase, summed over the steps
         unsigned long long ck[5] = {0, 0, 0, 0, 0}, tk0 = __builtin_amdgcn_s_memtime();
@@ -1035,6 +981,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
 #define WCLK(i) do { } while (0)
 #endif
         for (int s = 0; s < total; ++s) {
+            if constexpr (DMA) dma_step(gB, (s + 1) & 1);                   // step s + 1 lands in the other image while step s is multiplied
             mul_step(gA, s & 1);                                            // step s
 #ifdef DKT_WRES_CLOCKS
             __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): the step's LDS reads are back (its MFMAs may still run)
@@ -1044,9 +991,9 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
             __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);                    // vmcnt(0): how long the staged loads still needed
 #endif
             WCLK(1);
-            write_step(S, gB, (s + 1) & 1);                                 // step s + 1 (that buffer was read last in step s - 1, a barrier ago)
+            if constexpr (!DMA) write_step(S, gB, (s + 1) & 1);             // step s + 1 (that buffer was read last in step s - 1, a barrier ago)
             WCLK(2);
-            load_step(S, gC);                                               // step s + 2
+            if constexpr (!DMA) load_step(S, gC);                           // step s + 2
             gA = gB; gB = gC; gC = next_group(gC);
             WCLK(3);
             __syncthreads();
@@ -1391,6 +1338,15 @@ inline bool invres_fits(const WRanges& r, const int NT) {
     return true;
 }
 
+int g_tiled_wdma = -1;
+inline bool tiled_wdma() {
+    if (g_tiled_wdma < 0) {
+        const char* v = getenv("DKT_MLL_TILED_WDMA");
+        g_tiled_wdma = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_tiled_wdma != 0;
+}
+
 int g_tiled_wgs = -1;
 inline int tiled_wgs() {
     if (g_tiled_wgs < 0) {
@@ -1458,9 +1414,10 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     // W with resident accumulators.  DKT_MLL_TILED_WRES=0 -> round 3's kernels (fp32 factor / invert, block-column W on f16 products of fp32
     // tiles); DKT_MLL_TILED_F16=0 -> round 2's all-fp32 kernels.  A forward-only call (no W) runs the fp32 factor / invert.
     const bool msplit = SPLIT_OK && grad && tiled_f16() && tiled_wres() && t.a.C <= 64;
-    // (MC = 7, i.e. N > 383, keeps 2: with one step's operands in 168 registers its 84-step K loops expose every load -- 7.0 vs 7.1 ms at N = 420;
-    //  MC <= 6 gains 20 %: 3.97 vs 4.94 ms at N = 320)
-    if (msplit && tiled_wgs() >= 3 && MC <= 6) hipLaunchKernelGGL((tiled_factor_kernel<MC <= 6 ? MC : 6, true, 3>), fgrid, blk, 0, st, t);
+    // (3 workgroups per CU: 3.97 vs 4.94 ms at N = 320; at N = 420 -- MC = 7 -- only with the block-row body instantiated with MC - 1 columns from the second
+    //  block row on, dkt_mll_tiled_factor_row.inc: 6.46 vs 7.05 ms; with MC columns throughout 7.03.  Two K steps' operands at 3 workgroups, where they fit
+    //  (MC - 1 <= 5): 4.2 vs 4.0 ms, not used)
+    if (msplit && tiled_wgs() >= 3) hipLaunchKernelGGL((tiled_factor_kernel<MC, true, 3>), fgrid, blk, 0, st, t);
     else if (msplit) hipLaunchKernelGGL((tiled_factor_kernel<MC, true, 2>), fgrid, blk, 0, st, t);
     else hipLaunchKernelGGL((tiled_factor_kernel<MC, false, 2>), fgrid, blk, 0, st, t);
 #ifdef DKT_TILED_CLOCKS
@@ -1475,7 +1432,8 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         const size_t lds = (size_t)2 * 32 * 1024 + 2 * 64 * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+            (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+            (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
             (void)hipFuncSetAttribute((const void*)tiled_invres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
             attr_set = true;
         }
@@ -1486,7 +1444,8 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         } else {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         }
-        hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        else hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         return;
     }
     hipLaunchKernelGGL((tiled_invert_kernel<MC, true, false>), dim3(nmat), blk, 0, st, t);
@@ -1499,7 +1458,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 
 }  // namespace
 
-void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; }      // dkt_reload_env()
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; g_tiled_wdma = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
