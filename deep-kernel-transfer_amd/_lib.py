@@ -88,7 +88,7 @@ SPILL_BUDGET = {
     r"gram_sym_ep_split_kernelILi8E": 140,
     # tile-array factorisation at 3 workgroups per CU (168 VGPRs): ~28 values parked in scratch around the diagonal-tile sweep, none in the K loop
     r"tiled_factor_kernelILi\dELb1ELi3E": 40,
-    r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 16,
+    r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 32,
 }
 
 

@@ -349,19 +349,21 @@ __global__ __launch_bounds__(64 * TB, WGS) void tiled_invert_kernel(TiledArgs t)
 #pragma unroll
             for (int jj = 0; jj < TB; ++jj) acc[aa][jj] = zero4;
         // ---- K loop over the finished columns k < j0:  acc(i, j) += R_kj^T M_ki  (slot (i, k); the diagonal slot is M_ii) ----
-        auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MC], const int k) {
+        // (the K loop runs over k < j0 <= 4 (MC - 1), so its M operands are the rows i <= k < 4 (MC - 1): MC - 1 tiles per wave, whatever NT is)
+        constexpr int MCY = MC > 1 ? MC - 1 : 1;
+        auto loadk = [&](f32x4 (&X)[TB], f32x4 (&Y)[MCY], const int k) {
             const bool kin = k < j0;
 #pragma unroll
             for (int jj = 0; jj < TB; ++jj) X[jj] = tload(Tr, NT, kin && j0 + jj < NT, k, j0 + jj, lane16);
 #pragma unroll
-            for (int aa = 0; aa < MC; ++aa) {
+            for (int aa = 0; aa < MCY; ++aa) {
                 const int i = w + TB * aa;
                 Y[aa] = tload(Tr, NT, kin && i <= k, i, k, lane16);
             }
         };
-        auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MC], const int k) {
+        auto mulk = [&](const f32x4 (&X)[TB], const f32x4 (&Y)[MCY], const int k) {
 #pragma unroll
-            for (int aa = 0; aa < MC; ++aa) {
+            for (int aa = 0; aa < MCY; ++aa) {
                 if (w + TB * aa <= k) {
 #ifdef DKT_TILED_NOMATH
 #pragma unroll
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(64 * TB, WGS) void tiled_invert_kernel(TiledArgs t)
             dl[u] = tload(Tr, NT, tt < 10 && j0 + jj < NT, j0 + kk, j0 + jj, lane16);
         }
         {
-            f32x4 X0[TB], Y0[MC], X1[TB], Y1[MC];
+            f32x4 X0[TB], Y0[MCY], X1[TB], Y1[MCY];
             loadk(X0, Y0, 0);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -1439,8 +1441,8 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         }
         if (tiled_invres() && invres_fits(rg, t.NT)) {
             for (int gq = 0; gq < rg.ng; ++gq) hipLaunchKernelGGL((tiled_invres_kernel<WRES_MAXC>), dim3(nmat), dim3(256), (size_t)2 * 32 * 1024, st, t, rg, gq);
-        } else if (tiled_wgs() >= 3 && MC <= 6) {
-            hipLaunchKernelGGL((tiled_invert_kernel<MC <= 6 ? MC : 6, true, true, 3>), dim3(nmat), blk, 0, st, t);
+        } else if (tiled_wgs() >= 3) {
+            hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true, 3>), dim3(nmat), blk, 0, st, t);
         } else {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         }
