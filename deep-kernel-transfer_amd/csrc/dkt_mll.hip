@@ -244,8 +244,14 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     }
     hipStream_t st = (hipStream_t)stream;
     if (flags & DKT_MLL_E_PER_CLASS) {
-        // one base matrix per class model: served by the wave-per-matrix form of the f16-split kernel only (training call, N <= 111)
+        // one base matrix per class model: the wave-per-matrix form of the f16-split kernel (N <= 111) or the tile-array pipeline with one W per
+        // matrix (128 <= N <= 446); 112 <= N <= 127 is served by neither (the host falls back to one call per class there)
         if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
+        if (N + 1 > 128) {
+            if (!dkt_mll_tiled_supports(N, flags)) return DKT_ERR_TOO_LARGE;
+            if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes(B, C, N)) return DKT_ERR_WORKSPACE;
+            return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
+        }
         if (N + 1 > 112) return DKT_ERR_TOO_LARGE;
         return dkt_mll_h2_launch(a, st) ? (hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH) : DKT_ERR_BAD_ARG;
     }

@@ -44,6 +44,7 @@ struct TiledArgs {
     float* etiles;                            // [episodes of the chunk][NTT + 1][256]: E[b] in tile layout (+ a zero tile)
     TiledScal* scal;                          // [nmat]
     int b0, NT, bcnt;
+    int per_class;                            // DKT_MLL_E_PER_CLASS: E is [B,C,N,N] (etiles per MATRIX), W is [B,C,N,N] (the W kernel treats every matrix as an episode of one class)
 };
 
 __device__ __forceinline__ int tslot(const int NT, const int i, const int j) { return i * NT - (i * (i - 1)) / 2 + (j - i); }      // i <= j
@@ -74,7 +75,7 @@ struct FormRt {
 
 // E[b] -> tile layout, once per episode (shared by its C class matrices): tile (i, j), i <= j, element [4g+q][c] = E[16i + 4g + q][16j + c]
 // = E[16j + c][16i + 4g + q] (symmetric: one 16-byte load per lane), zero beyond N; written as one coalesced 1-KB tile.
-__global__ __launch_bounds__(256) void tiled_etile_kernel(const float* __restrict__ E, float* __restrict__ Et, int b0, int N, int NT) {
+__global__ __launch_bounds__(256) void tiled_etile_kernel(const float* __restrict__ E, float* __restrict__ Et, long b0, int N, int NT) {     // b0: first base matrix of the chunk
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
     const int ntt = NT * (NT + 1) / 2, bl = blockIdx.y, slot = blockIdx.x * 4 + wave;
     if (slot > ntt) return;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * TB, WGS) void tiled_factor_kernel(TiledArgs t)
     const int lane = g.lane, lane16 = g.lane * 16;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
     const brsrc Tr = mk_rsrc(t.tiles + (size_t)m * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
-    const float* Eb = a.E + (size_t)b * N * N;
+    const float* Eb = a.E + (t.per_class ? (size_t)b * C + c : (size_t)b) * N * N;
     // kappa = 4^msc >= max_i K_ii
     float emax = 0.f;
     for (int i = tid; i < N; i += 64 * TB) emax = fmaxf(emax, Eb[(size_t)i * (N + 1)]);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * TB, WGS) void tiled_factor_kernel(TiledArgs t)
         usc = scale_for(ldexpf(1.0f, msc) / __builtin_sqrtf(nzp), uinv_unused);
     }
     FormRt f;
-    f.Et = mk_rsrc(t.etiles + (size_t)bl * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
+    f.Et = mk_rsrc(t.etiles + (size_t)(t.per_class ? m : bl) * (ntt + 1) * 256, (unsigned)((ntt + 1) * 1024));
     f.yr = mk_rsrc(a.Y + (size_t)b * a.y_bstride + (size_t)c * N, (unsigned)(N * 4));
     f.nsv = -svc * ikap; f.dg = -nzc * ikap; f.mc = mc; f.rsc = ldexpf(1.0f, -msc - erho);
     const f32x4 negI = neg_identity(g);
@@ -743,12 +744,14 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     const MllArgs& a = t.a;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = a.N, NT = t.NT, C = a.C;
+    // DKT_MLL_E_PER_CLASS: every (episode, class) matrix has its own W -> a UNIT of this kernel is a matrix and its class "loop" has one entry
+    // (C, b, bl below then count units: b indexes alpha / scal / W rows of the flat [B C] arrays)
+    const int N = a.N, NT = t.NT, C = t.per_class ? 1 : a.C;
     const int ng = rg.ng;
     // workgroup -> (episode, range): the ranges of an episode read the same strips, so they get workgroup ids 8 apart (one XCD, one L2)
     const int bl = ((int)(blockIdx.x >> 3) / ng) * 8 + (int)(blockIdx.x & 7);
-    if (bl >= t.bcnt) return;
-    const int gi = (int)(blockIdx.x >> 3) % ng, b = t.b0 + bl;
+    if (bl >= (t.per_class ? t.bcnt * a.C : t.bcnt)) return;
+    const int gi = (int)(blockIdx.x >> 3) % ng, b = (t.per_class ? t.b0 * a.C : t.b0) + bl;
     const int c0 = rg.c0[gi], c1 = rg.c0[gi + 1];
     const Geo g = make_geo(tid, N, NT);
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
@@ -1406,7 +1409,8 @@ template <int MC>
 void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const int nmat = bcnt * t.a.C;
     const dim3 fgrid(8 * ((bcnt + 7) / 8) * t.a.C), blk(64 * TB);
-    hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, bcnt), dim3(256), 0, st, t.a.E, t.etiles, t.b0, t.a.N, t.NT);
+    hipLaunchKernelGGL(tiled_etile_kernel, dim3((t.NT * (t.NT + 1) / 2 + 1 + 3) / 4, t.per_class ? nmat : bcnt), dim3(256), 0, st, t.a.E, t.etiles,
+                       t.per_class ? (long)t.b0 * t.a.C : (long)t.b0, t.a.N, t.NT);
 #if defined(DKT_TILED_NOMATH)
     constexpr bool SPLIT_OK = false;                                        // the traffic-only build instruments the fp32 kernels
 #else
@@ -1415,7 +1419,8 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     // F16 pipeline (default for a call with gradients and C <= 64): f16-split tile arrays end to end -- factor and invert K loops on the f16 pipe,
     // W with resident accumulators.  DKT_MLL_TILED_WRES=0 -> round 3's kernels (fp32 factor / invert, block-column W on f16 products of fp32
     // tiles); DKT_MLL_TILED_F16=0 -> round 2's all-fp32 kernels.  A forward-only call (no W) runs the fp32 factor / invert.
-    const bool msplit = SPLIT_OK && grad && tiled_f16() && tiled_wres() && t.a.C <= 64;
+    // Per-class base matrices (DKT_MLL_E_PER_CLASS) with gradients exist in this pipeline only (W per matrix = the W kernel with one class per unit).
+    const bool msplit = SPLIT_OK && grad && (t.per_class || (tiled_f16() && tiled_wres() && t.a.C <= 64));
     // (3 workgroups per CU: 3.97 vs 4.94 ms at N = 320; at N = 420 -- MC = 7 -- only with the block-row body instantiated with MC - 1 columns from the second
     //  block row on, dkt_mll_tiled_factor_row.inc: 6.46 vs 7.05 ms; with MC columns throughout 7.03.  Two K steps' operands at 3 workgroups, where they fit
     //  (MC - 1 <= 5): 4.2 vs 4.0 ms, not used)
@@ -1439,17 +1444,19 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)tiled_invres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
             attr_set = true;
         }
-        if (tiled_invres() && invres_fits(rg, t.NT)) {
+        if (tiled_invres() && invres_fits(rg, t.NT) && !t.per_class) {
             for (int gq = 0; gq < rg.ng; ++gq) hipLaunchKernelGGL((tiled_invres_kernel<WRES_MAXC>), dim3(nmat), dim3(256), (size_t)2 * 32 * 1024, st, t, rg, gq);
         } else if (tiled_wgs() >= 3) {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true, 3>), dim3(nmat), blk, 0, st, t);
         } else {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         }
-        if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
-        else hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((bcnt + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        const int units = t.per_class ? nmat : bcnt;
+        if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+        else hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         return;
     }
+    if (t.per_class) return;                                                 // (unreachable outside the traffic-only measurement build)
     hipLaunchKernelGGL((tiled_invert_kernel<MC, true, false>), dim3(nmat), blk, 0, st, t);
     // Block-column W (rounds 2-3).  Block columns of 8 tile columns with 8 waves (WB = 8: 880 instead of 1232 tile reads per class matrix at
     // NT = 27) were measured in round 3 and are NOT used: 25.8 vs 22.2 ms per 1024 cfg4 episodes for the whole marginal likelihood.
@@ -1466,9 +1473,22 @@ bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
 }
 
+// DKT_MLL_E_PER_CLASS: the base matrices take as many tiles as the factors, so a pass covers half as many episodes (and at most 65535 matrices: the
+// conversion kernel's grid); the workspace of ANY call (the size does not depend on the flags) covers both forms.
+inline int tiled_pc_chunk(int B, int C, int limit) {
+    int bc = limit / 2 < 1 ? 1 : limit / 2;
+    if (bc > 65535 / C) bc = 65535 / C;
+    if (bc < 1) bc = 1;
+    return B < bc ? B : bc;
+}
+inline size_t tiled_pc_ws_floats(int Bc, int C, int N) {
+    const size_t nt = tiled_nt(N), ntt = nt * (nt + 1) / 2, nmat = (size_t)Bc * C;
+    return 2 * nmat * (ntt + 1) * 256 + nmat * (sizeof(TiledScal) / sizeof(float)) + 64;
+}
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N) {
     const int bc = B < TILED_CHUNK_MAX ? B : TILED_CHUNK_MAX;
-    return tiled_ws_floats(bc, C, N) * sizeof(float);
+    const size_t shared = tiled_ws_floats(bc, C, N), pc = C <= 65535 ? tiled_pc_ws_floats(tiled_pc_chunk(B, C, TILED_CHUNK_MAX), C, N) : 0;
+    return (shared > pc ? shared : pc) * sizeof(float);
 }
 
 // Returns 0 on success, a negative DKT status otherwise.
@@ -1476,13 +1496,16 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
     const int N = a.N, C = a.C;
     if (!workspace || ws_bytes < dkt_mll_tiled_workspace_bytes(a.B, C, N)) return DKT_ERR_WORKSPACE;
     const int NT = tiled_nt(N);
-    const int Bc = a.B < tiled_chunk_episodes() ? a.B : tiled_chunk_episodes();
+    const bool pc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    if (pc && C > 65535) return DKT_ERR_TOO_LARGE;
+    const int Bc = pc ? tiled_pc_chunk(a.B, C, tiled_chunk_episodes()) : (a.B < tiled_chunk_episodes() ? a.B : tiled_chunk_episodes());
     const size_t ntt = (size_t)NT * (NT + 1) / 2, nmat_max = (size_t)Bc * C;
     TiledArgs t;
     t.a = a;
+    t.per_class = pc ? 1 : 0;
     t.tiles = (float*)workspace;
     t.etiles = t.tiles + nmat_max * (ntt + 1) * 256;
-    t.scal = (TiledScal*)(t.etiles + (size_t)Bc * (ntt + 1) * 256);
+    t.scal = (TiledScal*)(t.etiles + (pc ? nmat_max : (size_t)Bc) * (ntt + 1) * 256);
     t.NT = NT;
     const bool grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     const int mc = (NT + TB - 1) / TB;
@@ -1501,9 +1524,11 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
         // fix-up: episodes with a failed matrix are redone by the generic kernel with the jitter ladder (its global working
         // matrices reuse the tile region, which is dead by now)
 #if !defined(DKT_TILED_CLOCKS) && !defined(DKT_TILED_NOMATH)
-        MllArgs f = a;
-        f.only_failed = a.info;
-        dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);
+        if (!pc) {                          // (per-class base matrices: no jitter ladder, as in the wave-per-matrix kernel -- a failed matrix reports info != 0 and NaN)
+            MllArgs f = a;
+            f.only_failed = a.info;
+            dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);
+        }
 #endif
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

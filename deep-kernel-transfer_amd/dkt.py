@@ -302,13 +302,13 @@ class DKT(MetaTemplate):
             # rbf / matern / polynomial: every class model owns its lengthscale / offset (one ExactGPLayer per class,
             # DKT.py:63-66), so the base matrix differs per class
             ls, off = self.model.lengthscale, self.model.offset
-            if n + 1 <= 112:
+            if ops.mll_per_class_supported(n, c):
                 # ONE contraction per episode (squared distances / Gram), the C class maps in one launch, ONE marginal-likelihood
                 # launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS), the chain rule back in two launches
                 obj, logp, alpha, info, jit, e = ops.episode_loss_class_kernel(zb, y, sv, mean, noise, cw, self.kernel_type, ls, off,
                                                                                self.jitter0, self.max_tries)
             else:
-                # larger episodes: one Gram + one single-model launch per class
+                # 112 <= N <= 127, N > 446 or more than 32 classes: one Gram + one single-model launch per class
                 objs, logps, alphas, infos, jits = [], [], [], [], []
                 for k in range(c):
                     e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
@@ -336,7 +336,7 @@ class DKT(MetaTemplate):
             mu, labels = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type), out["alpha"], sv, mean)
             return mu[0], labels[0], out
         # per-class base matrices (E depends on the class model's own, post-step, lengthscale / offset)
-        if zc.shape[1] + 1 <= 112:
+        if ops.mll_per_class_supported(zc.shape[1], y.shape[-2]):
             # one contraction for the conditioning set, one for the cross kernel; the class maps element-wise; one launch for all classes
             e_c = ops.kernel_matrix_per_class(zc, None, self.kernel_type, ls, off)               # [1, C, N, N]
             out = ops.mll(e_c, y, sv, mean, noise, jitter0=self.jitter0, max_tries=self.max_tries)

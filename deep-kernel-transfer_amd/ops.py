@@ -516,9 +516,16 @@ class _EpisodeLossClassKernelFn(torch.autograd.Function):
         return dz, None, gsv, gmean, gnoise, None, gparam, None, None, None, None, None
 
 
+def mll_per_class_supported(n: int, c: int) -> bool:
+    """Sizes the one-launch per-class path serves (DKT_MLL_E_PER_CLASS of dkt_mll_f32: N <= 111 wave-per-matrix kernel, 128 <= N <= 446
+    tile-array pipeline; dkt_class_kernel_bwd_f32: C <= 32).  Outside them the host runs one single-model call per class."""
+    return c <= 32 and (n + 1 <= 112 or 128 < n + 1 <= 448)
+
+
 def episode_loss_class_kernel(z, y, sv, mean, noise, cls_weight, kernel: str, lengthscale=None, offset=None,
                               jitter0: float = 1e-6, max_tries: int = 3):
-    """Training episode(s) z:[B,N,D] for rbf / matern / poli1 / poli2 with per-class lengthscale / offset [C], N + 1 <= 112.
+    """Training episode(s) z:[B,N,D] for rbf / matern / poli1 / poli2 with per-class lengthscale / offset [C], sizes of
+    mll_per_class_supported().
     Returns (obj[B], logp[B,C], alpha[B,C,N], info[B,C], jitter[B,C], E[B,C,N,N])."""
     cmap, power, param, base_kind = _classmap_of(kernel, lengthscale, offset)
     return _EpisodeLossClassKernelFn.apply(_req(z, "z", 3), y, sv, mean, noise, cls_weight, param, cmap, power, base_kind, jitter0, max_tries)

@@ -103,7 +103,9 @@ size_t dkt_mll_workspace_bytes(int B, int C, int N);
  *   flags & DKT_MLL_E_PER_CLASS : the class models do not share a base matrix (rbf / matern / polynomial kernels with per-class
  *        lengthscale / offset: one ExactGPLayer per class, methods/DKT.py:63-66, 352-365):  K_c = sv[c] * E[b,c] + noise[c] * I with
  *        E:[B,C,N,N], and W:[B,C,N,N] holds W[b,c] = cls_weight[c] * sv[c] * M_c = d obj_b / d E[b,c] per class.  One launch for all
- *        classes; N <= 111, without DKT_MLL_WANT_CHOL / DKT_MLL_FORCE_* (DKT_ERR_TOO_LARGE / DKT_ERR_BAD_ARG otherwise).
+ *        classes; N <= 111 (wave-per-matrix kernel) or 128 <= N <= 447 (tile-array pipeline, one W per matrix; needs the workspace of
+ *        dkt_mll_workspace_bytes; no jitter retry: a failed matrix reports info != 0 and NaN); without DKT_MLL_WANT_CHOL /
+ *        DKT_MLL_FORCE_* (DKT_ERR_TOO_LARGE for 112 <= N <= 127 and N > 447 / DKT_ERR_BAD_ARG otherwise).
  * Range contract of the default kernels for N <= 127 (scaled 2-way f16 splits on the f16 matrix pipe, 22 significand bits, fp32
  *   accumulate): every K_c = sv[c] E + noise[c] I must satisfy |K_ij| <= max_i K_ii, which every positive semi-definite E (any Gram /
  *   RBF / Matern / polynomial base matrix) does.  An E that violates it (not PSD, or user-supplied with off-diagonals beyond the

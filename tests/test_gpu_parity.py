@@ -568,6 +568,62 @@ def test_mll_per_class_base_matrices_one_launch(cuda, c, per, d):
         ops.mll(big, torch.ones(2, 120, device=cuda), torch.ones(2, device=cuda), torch.zeros(2, device=cuda), torch.full((2,), 0.1, device=cuda), want_grad=True)
 
 
+@pytest.mark.parametrize("b,c,per,chunk", [(2, 5, 30, None), (2, 20, 21, None), (5, 3, 100, "4"), (1, 2, 223, None)])
+def test_mll_per_class_base_matrices_tile_array(cuda, monkeypatch, b, c, per, chunk):
+    """DKT_MLL_E_PER_CLASS at 128 <= N <= 446: the tile-array pipeline with one base matrix, one factor and one W per (episode, class) matrix
+    (the 20-way rbf / matern / polynomial episode of 420 rows in ONE dkt_mll_f32 call).  Against the float64 oracle per matrix, the single-model
+    launch (shared-matrix pipeline with C = 1) it replaces, and the forward-only call (fp32 kernels); `chunk`: several passes over the workspace
+    (a per-class pass covers half the episodes of a shared-matrix pass) with a ragged last pass."""
+    if chunk is not None:
+        monkeypatch.setenv("DKT_MLL_TILED_CHUNK", chunk)
+    n = c * per
+    rng = np.random.default_rng(c * 1000 + per)
+    z = O.synthetic_features(b, n, 24, 500 + c, 0)
+    y = O.one_vs_rest_targets(c, per)
+    ls = np.linspace(0.8, 1.9, c)
+    sv = np.linspace(0.5, 2.0, c)
+    mean = 0.05 * rng.standard_normal(c)
+    noise = np.linspace(0.08, 0.3, c)
+    cw = np.full(c, -1.0 / (c * n))
+    cw[c // 2] *= -2.0                                                       # a class weight of the other sign
+    e64 = np.stack([np.stack([O.gram_rbf(z[i], None, ls[k]) for k in range(c)]) for i in range(b)])      # [B, C, N, N]
+    args = (dev_t(e64, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda))
+    out = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    fwd = ops.mll(*args)
+    torch.cuda.synchronize()
+    assert out["w"].shape == (b, c, n, n) and int(out["info"].abs().max().item()) == 0 and int(fwd["info"].abs().max().item()) == 0
+    assert rel_l2(fwd["logp"].cpu().numpy(), out["logp"].cpu().numpy()) < 1e-5
+    assert rel_l2(fwd["alpha"].cpu().numpy(), out["alpha"].cpu().numpy()) < 2e-4
+    w_all = out["w"].cpu().numpy()
+    assert (w_all == w_all.transpose(0, 1, 3, 2)).all()
+    for i in sorted({0, b - 1}):
+        for k in sorted({0, c // 2, c - 1}):
+            e = e64[i, k].astype(np.float32).astype(np.float64)
+            res = O.mll_terms(e, y[k:k + 1], sv[k:k + 1], mean[k:k + 1], noise[k:k + 1])
+            assert abs((out["logp"][i, k].item() - res.logp[0]) / res.logp[0]) < MLL_RTOL
+            assert rel_l2(out["alpha"][i, k].cpu().numpy(), res.alpha[0]) < 5e-4
+            w_ref, _, _, _ = O.mll_grads(e, res, sv[k:k + 1], noise[k:k + 1], cw[k:k + 1])
+            _, dsv1, dmean1, dnoise1 = O.mll_grads(e, res, sv[k:k + 1], noise[k:k + 1], np.ones(1))
+            assert rel_l2(w_all[i, k], w_ref) < GRAD_RTOL, (i, k, rel_l2(w_all[i, k], w_ref))
+            assert abs(out["dsv"][i, k].item() - dsv1[0]) < GRAD_RTOL * abs(dsv1[0]) + 1e-5
+            # (d logp / d mean = sum_i alpha_i cancels: the tolerance follows |alpha|_1, not the sum)
+            assert abs(out["dmean"][i, k].item() - dmean1[0]) < GRAD_RTOL * abs(dmean1[0]) + 1e-6 + 2e-6 * np.abs(res.alpha[0]).sum()
+            assert abs(out["dnoise"][i, k].item() - dnoise1[0]) < GRAD_RTOL * abs(dnoise1[0]) + 1e-5
+            one = ops.mll(dev_t(e64[i:i + 1, k], cuda), dev_t(y[k:k + 1], cuda), dev_t(sv[k:k + 1], cuda), dev_t(mean[k:k + 1], cuda),
+                          dev_t(noise[k:k + 1], cuda), want_grad=True, cls_weight=dev_t(cw[k:k + 1], cuda))
+            assert rel_l2(w_all[i, k], one["w"][0].cpu().numpy()) < 2e-5
+            assert abs(out["logp"][i, k].item() - one["logp"][0, 0].item()) < 5e-6 * abs(one["logp"][0, 0].item())
+    # a matrix that is not positive definite: reported per matrix (info != 0, NaN), the other matrices of the call untouched
+    bad = dev_t(e64, cuda).clone()
+    bad[0, c - 1] = -bad[0, c - 1]
+    o2 = ops.mll(bad, *args[1:], want_grad=True, cls_weight=dev_t(cw, cuda))
+    assert int(o2["info"][0, c - 1].item()) != 0 and torch.isnan(o2["logp"][0, c - 1])
+    keep = torch.ones(b, c, dtype=torch.bool, device=cuda)
+    keep[0, c - 1] = False
+    assert int(o2["info"][keep].abs().max().item()) == 0 and torch.equal(o2["logp"][keep], out["logp"][keep])
+    assert torch.equal(o2["w"][keep], out["w"][keep])
+
+
 def _class_kernel_ref(base, kernel, param):
     """float64 torch restatement of the per-class maps (gpytorch RBFKernel / MaternKernel(nu=2.5) / PolynomialKernel, DKT.py:352-365)."""
     p = param.reshape(1, -1, 1, 1)
@@ -1656,9 +1712,32 @@ def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, p
 def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
     """configs.kernel_type values of the reference's ExactGPLayer (DKT.py:352-370): loss, gradients w.r.t. every
     parameter (backbone, outputscale, mean, lengthscale / offset / variance) and predictions vs the float64 restatement."""
+    _every_kernel_type_check(cuda, kernel, per=12, n_support=5)
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern", "poli2"])
+def test_dkt_per_class_kernels_large_episode_one_launch(cuda, kernel):
+    """The same check on an episode of 150 rows (training) / a support set of 135 rows (prediction): the class models' own base matrices go
+    through the tile-array pipeline of dkt_mll_f32 in ONE call (DKT_MLL_E_PER_CLASS beyond N = 111) -- no per-class loop on the host."""
+    calls = []
+    orig = ops.mll
+
+    def spy(e, *a, **k):
+        calls.append(tuple(e.shape))
+        return orig(e, *a, **k)
+
+    ops.mll = spy
+    try:
+        _every_kernel_type_check(cuda, kernel, per=30, n_support=27)
+    finally:
+        ops.mll = orig
+    assert calls == [(1, 5, 150, 150), (1, 5, 135, 135)], calls
+
+
+def _every_kernel_type_check(cuda, kernel, per, n_support):
     import copy
     torch.manual_seed(1)
-    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type=kernel).to(cuda)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=n_support, kernel_type=kernel).to(cuda)
     with torch.no_grad():
         m.model.raw_outputscale.copy_(torch.tensor([0.3, -0.2, 0.1, 0.0, 0.5]))
         m.model.mean_constant.copy_(torch.tensor([0.05, -0.1, 0.0, 0.02, 0.1]))
@@ -1671,11 +1750,11 @@ def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
             m.model.raw_variance.copy_(torch.tensor([-0.4, 0.1, -0.8, 0.3, 0.0]))
     assert all(getattr(m.model, nm) is None or getattr(m.model, nm).shape == (5,) for nm in ("raw_lengthscale", "raw_offset", "raw_variance"))
     ref = copy.deepcopy(m).cpu().double()
-    x = torch.rand(5, 12, 3, 28, 28, generator=torch.Generator().manual_seed(2))
-    x_all = x.view(60, 3, 28, 28)
+    x = torch.rand(5, per, 3, 28, 28, generator=torch.Generator().manual_seed(2))
+    x_all = x.view(5 * per, 3, 28, 28)
     m.train()
     z = m._embed(x_all.to(cuda))
-    loss, aux = m._episode_loss(z, m._targets(5, 12, cuda))
+    loss, aux = m._episode_loss(z, m._targets(5, per, cuda))
     loss.backward()
     assert int(aux["info"].abs().max().item()) == 0
     ref.train()
@@ -1695,12 +1774,12 @@ def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
     # prediction through the same kernel (cross matrix, per-class parameters) vs the float64 restatement
     m.eval()
     ref.eval()
-    m.n_query = 7
+    m.n_query = per - n_support
     logits = m.get_logits(x)
-    assert logits.shape == (35, 5) and torch.isfinite(logits).all()
+    assert logits.shape == (5 * (per - n_support), 5) and torch.isfinite(logits).all()
     with torch.no_grad():
-        zs = ref._embed(x[:, :5].reshape(25, 3, 28, 28).double())
-        zq = ref._embed(x[:, 5:].reshape(35, 3, 28, 28).double())
+        zs = ref._embed(x[:, :n_support].reshape(5 * n_support, 3, 28, 28).double())
+        zq = ref._embed(x[:, n_support:].reshape(5 * (per - n_support), 3, 28, 28).double())
         kn = kernel if kernel != "cossim" else "linear"
         _, _, alpha_s = T.classification_loss(zs, 5, ref.model.outputscale, ref.model.mean, ref.model.noise, kn, extra, variance=var)
         mu_r = T.predict_mean(zs, zq, alpha_s, ref.model.outputscale, ref.model.mean, kn, extra, variance=var)
