@@ -98,20 +98,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_
     {
         const int row = r0 + 16 * wave + r16;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wb), 0, N * N * 4, 0x00020000);
+        // BRANCH-FREE (round 4): a 16-byte load that starts inside the row is issued whole -- what it reads past the row end is the next row (or, for the
+        // episode's last row, beyond the buffer: 0) and is masked after the load.  With the element-by-element tail behind a lane-dependent branch the
+        // compiler waited for every load before the next one was issued: 56 serialized round trips per wave, 0.3 of the kernel's 1.26 ms at N = 420
+        // (profiles/r04/v11_gram_bwd_variants.log).
         auto wload = [&](float (&v)[8], int ks) {
             const int k = 32 * ks + 8 * q;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int kk = k + 4 * hh;
-                if (kk + 3 < N || row >= N) {            // (a 16-byte load that would run past the row end is done element by element)
-                    const auto u = __builtin_amdgcn_raw_buffer_load_b128(wr, (row < N) ? (row * N + kk) * 4 : 0x7ffffff0, 0, 0);
+                const auto u = __builtin_amdgcn_raw_buffer_load_b128(wr, (row < N && kk < N) ? (row * N + kk) * 4 : 0x7ffffff0, 0, 0);
+                // (the launcher picks KS with 32 (KS - 2) < N: only the last two slices can reach past the row end -- masks for all of them cost 150 SGPR spills)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * hh + e] = s2 * __uint_as_float(u[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[4 * hh + e] = s2 * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, (kk + e < N) ? (row * N + kk + e) * 4 : 0x7ffffff0, 0, 0));
-                }
+                for (int e = 0; e < 4; ++e) v[4 * hh + e] = (ks < KS - 2 || kk + e < N) ? s2 * __uint_as_float(u[e]) : 0.f;
             }
         };
         float rmax = 0.f;
@@ -142,25 +141,63 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_
             }
         }
     }
+#ifdef DKT_GBW_CLOCKS       // measurement build (tools/gbw_phase_clocks.py): shader clocks of wave 0 per phase, summed over the slabs, left in the first row of the block
+    unsigned long long ck[6] = {0, 0, 0, 0, 0, 0}, tk0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long tk_start = tk0, rt_start = __builtin_amdgcn_s_memrealtime();      // (the second: a constant 100-MHz counter -> the shader clock of this run)
+#define GBW_CLK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); ck[i] += tk1 - tk0; tk0 = tk1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GBW_CLK(i) do { } while (0)
+#endif
     gload(rg, 0);
     lstore(rg, 0);
     __syncthreads();
+    GBW_CLK(0);                                              // prologue (A fragments) + first slab staged
     for (int sl = 0; sl < nslab; ++sl) {
         if (sl + 1 < nslab) gload(rg, (sl + 1) * BD);
+        GBW_CLK(1);                                          // issue of the next slab's loads
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const _Float16* base = zt[NBUF == 2 ? (sl & 1) : 0] + r16 * RS + 8 * q;
+        if (r0 + 16 * wave < N) {                            // (a wave of the episode's last block whose 16 rows lie past N only stages)
+            if constexpr (NW == 8) {
+                // B fragments (slice i >> 1, feature tile i & 1) read three steps (of 3 MFMAs) ahead into a ring of four register sets: left to itself the
+                // compiler issues a step's two ds_read_b128 right in front of its MFMAs
+                f16x8 rbh[4], rbm[4];
+                auto fload = [&](const int i, const int slot) {
+                    const _Float16* p = base + 16 * (i & 1) * RS + 32 * (i >> 1);
+                    rbh[slot] = *reinterpret_cast<const f16x8*>(p);
+                    rbm[slot] = *reinterpret_cast<const f16x8*>(p + PLANE);
+                };
+                fload(0, 0);
+                fload(1, 1);
+                fload(2, 2);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+                for (int i = 0; i < 2 * KS; ++i) {
+                    if (i + 3 < 2 * KS) fload(i + 3, (i + 3) % 4);
+                    const int ks = i >> 1, tt = i & 1;
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], rbm[i % 4], acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], rbh[i % 4], acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], rbh[i % 4], acc[tt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const _Float16* p = base + 16 * tt * RS + 32 * ks;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(p);
-                const f16x8 bm = *reinterpret_cast<const f16x8*>(p + PLANE);
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bm, acc[tt], 0, 0, 0);
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], bh, acc[tt], 0, 0, 0);
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[tt], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const _Float16* p = base + 16 * tt * RS + 32 * ks;
+                        const f16x8 bh = *reinterpret_cast<const f16x8*>(p);
+                        const f16x8 bm = *reinterpret_cast<const f16x8*>(p + PLANE);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bm, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am[ks], bh, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh, acc[tt], 0, 0, 0);
+                    }
+                }
             }
         }
+#ifdef DKT_GBW_CLOCKS
+        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]));  // the products are complete here
+#endif
+        GBW_CLK(2);                                          // products
         const int d = sl * BD + (NW == 4 ? 2 * r16 : 4 * (r16 & 7) + 2 * (r16 >> 3));
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -172,10 +209,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(dZb + (size_t)row * D + d));
             }
         }
+        GBW_CLK(3);                                          // dZ stores
         if constexpr (NBUF == 1) __syncthreads();
         if (sl + 1 < nslab) lstore(rg, NBUF == 2 ? ((sl + 1) & 1) : 0);
+        GBW_CLK(4);                                          // wait for the next slab's loads, split, transposing LDS stores
         __syncthreads();
+        GBW_CLK(5);                                          // barrier
     }
+#ifdef DKT_GBW_CLOCKS
+    if (tid == 0 && D >= 8) {
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int i = 0; i < 6; ++i) dZb[(size_t)r0 * D + i] = (float)ck[i];
+        dZb[(size_t)r0 * D + 6] = (float)(__builtin_amdgcn_s_memtime() - tk_start);
+        dZb[(size_t)r0 * D + 7] = (float)(__builtin_amdgcn_s_memrealtime() - rt_start);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -432,11 +480,6 @@ void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D,
     if (KS >= 10 && gram_bwd_rows8_enabled()) {          // N > 256: three or more 128-row blocks per episode
         const int nrb = (N + 127) / 128;
         const int grid = 8 * ((B + 7) / 8) * nrb;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gram_bwd_rows_f16x2_kernel<KS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-            attr_set = true;
-        }
         hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 8>), dim3(grid), dim3(512), 0, st, W, Z, dZ, B, N, D, sc, nrb);
         return;
     }

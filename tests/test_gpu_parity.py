@@ -923,35 +923,43 @@ def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
         assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
 
 
-@pytest.mark.parametrize("n,d", [(190, 512), (320, 512), (420, 512), (431, 36)])
+@pytest.mark.parametrize("n,d", [(190, 512), (320, 512), (420, 512), (431, 36), (290, 64), (447, 100)])
 def test_gram_large_n_kernel_twins(cuda, n, d):
-    """N > 128, unit rows, a batch that takes the round-4 kernels (episode-resident Gram for N <= 432, 128-row Gram backward for N > 256): against the round-2
-    kernels on the same inputs (DKT_GRAM_BIG_EP=0 / DKT_GRAM_BWD_ROWS8=0) and against float64 on sampled episodes; symmetric, unit diagonal."""
+    """N > 128, unit rows, a batch that takes the round-4 kernels (episode-resident Gram for N <= 432; Gram backward in 128-row blocks for N > 256): against the
+    round-2 kernels on the same inputs (DKT_GRAM_BIG_EP=0 / DKT_GRAM_BWD_ROWS8=0) and float64 on sampled episodes; symmetric, unit diagonal.  The rows of W differ in
+    scale by orders of magnitude (the kernels scale every row by its own power of two), N is not always a multiple of 4 (row ends inside a 16-byte load) and
+    the upstream gradient enters per episode."""
     b = 72
     g = torch.Generator(device=cuda).manual_seed(n + d)
     z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda) * torch.exp(torch.randn(b, n, d, generator=g, device=cuda)), dim=2).contiguous()
     w = torch.randn(b, n, n, generator=g, device=cuda)
-    w = (w + w.transpose(1, 2)).contiguous()
+    rs = torch.exp(2.0 * torch.randn(b, n, 1, generator=g, device=cuda))
+    w = ((w + w.transpose(1, 2)) * rs * rs.transpose(1, 2)).contiguous()
+    eps = torch.linspace(0.5, 2.0, b, device=cuda)
     e_new = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
-    dz_new = ops.gram_bwd(w, z, None, unit_rows=True, w_symmetric=True)
-    os.environ["DKT_GRAM_BIG_EP"] = "0"
-    os.environ["DKT_GRAM_BWD_ROWS8"] = "0"
+    dz_new = ops.gram_bwd(w, z, eps, unit_rows=True, w_symmetric=True)
     try:
+        os.environ["DKT_GRAM_BIG_EP"] = "0"
+        os.environ["DKT_GRAM_BWD_ROWS8"] = "0"
         e_old = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
-        dz_old = ops.gram_bwd(w, z, None, unit_rows=True, w_symmetric=True)
+        dz_old = ops.gram_bwd(w, z, eps, unit_rows=True, w_symmetric=True)
     finally:
-        del os.environ["DKT_GRAM_BIG_EP"], os.environ["DKT_GRAM_BWD_ROWS8"]
+        for key in ("DKT_GRAM_BIG_EP", "DKT_GRAM_BWD_ROWS8"):
+            os.environ.pop(key, None)
     assert torch.equal(e_new, e_new.transpose(1, 2))
     assert (torch.diagonal(e_new, dim1=1, dim2=2) - 1.0).abs().max().item() < 2e-6
     assert (e_new - e_old).abs().max().item() < 1e-6
     assert float((dz_new - dz_old).norm() / dz_old.norm()) < 1e-6
+    assert float(((dz_new - dz_old).norm(dim=2) / dz_old.norm(dim=2).clamp_min(1e-30)).max()) < 5e-6       # row by row: every row has its own scale
     for bi in (0, b - 1):
         z64 = z[bi].double().cpu().numpy()
         ref = z64 @ z64.T
         mag = np.abs(z64) @ np.abs(z64).T
         assert (np.abs(e_new[bi].cpu().numpy() - ref) / mag).max() < 6e-7
-        dref = 2.0 * w[bi].double().cpu().numpy() @ z64
+        dref = 2.0 * float(eps[bi].item()) * w[bi].double().cpu().numpy() @ z64
         assert rel_l2(dz_new[bi].cpu().numpy(), dref) < 2e-6
+        rows = np.linalg.norm(dz_new[bi].cpu().numpy() - dref, axis=1) / np.linalg.norm(dref, axis=1)
+        assert rows.max() < 1e-5, rows.max()
 
 
 @pytest.mark.parametrize("n,d", [(129, 64), (190, 512), (320, 512), (420, 512), (257, 100)])
