@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
 SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_small.hip", "dkt_classkernel.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_h2.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_predict.hip",
            "dkt_spectral.hip", "dkt_frontend.hip"]
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
-DIAG_SOURCES = ["dkt_diag.hip"]
+DIAG_SOURCES = ["dkt_diag.hip", "dkt_mll_reg_twin.hip"]
 DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(INCLUDE, "dkt_abi.h")]
 OBJ_DIR = os.path.join(_HERE, "build")

@@ -38,7 +38,7 @@ bool dkt_mll_h2_launch(const MllArgs& a, hipStream_t st);
 // The same structure on the exact-fp32 matrix instruction (dkt_mll_mfma.hip): DKT_MLL_FORCE_F32MFMA twin, and DKT_MLL_WANT_CHOL.
 // Returns false when N is out of range.
 bool dkt_mll_mfma_launch(const MllArgs& a, hipStream_t st);
-// Register-resident sweep (dkt_mll_reg.hip; the round-1 default, kept as the DKT_MLL_FORCE_REG validation twin): N + 1 <= 128.
+// Register-resident sweep (dkt_mll_reg_twin.hip; the round-1 default, a validation twin in libdkt_diag.so since round 4): N + 1 <= 128.
 bool dkt_mll_reg_launch(const MllArgs& a, hipStream_t st);
 
 // Batched factorisation + inversion of nb x nb diagonal blocks (nb <= 127) with the register-resident sweep (dkt_mll_reg.hip).

@@ -243,6 +243,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
         a.flags = flags;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (flags & DKT_MLL_FORCE_REG) return DKT_ERR_BAD_ARG;     // (the register-sweep twin lives in libdkt_diag.so since round 4: dkt_diag_mll_reg_f32)
     if (flags & DKT_MLL_E_PER_CLASS) {
         // one base matrix per class model: the wave-per-matrix form of the f16-split kernel (N <= 111) or the tile-array pipeline with one W per
         // matrix (128 <= N <= 446); 112 <= N <= 127 is served by neither (the host falls back to one call per class there)
@@ -257,7 +258,6 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     }
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
-    if (!(flags & DKT_MLL_FORCE_GENERIC) && dkt_mll_reg_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags) && workspace &&
         workspace_bytes >= dkt_mll_tiled_workspace_bytes(B, C, N))
         return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);

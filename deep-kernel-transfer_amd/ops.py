@@ -178,7 +178,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
-    flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_REG if force_reg else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
+    flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
              (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0))
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
@@ -192,6 +192,19 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
         dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     if cls_weight is not None:
         cls_weight = _req(cls_weight.reshape(-1), "cls_weight", 1)
+    if force_reg and n + 1 <= 128:                           # (beyond its range the call takes the default kernels, as DKT_MLL_FORCE_REG did)
+        # the round-1 register-sweep kernel: a validation twin in the measurement library (libdkt_diag.so) since round 4, not part of the product ABI
+        if per_class or force_generic or force_blocked or force_f32mfma:
+            raise RuntimeError("mll: force_reg combines with want_grad / want_chol only")
+        dlib = _lib.load_diag()
+        dlib.dkt_diag_mll_reg_f32.restype = ctypes.c_int
+        dlib.dkt_diag_mll_reg_f32.argtypes = ([ctypes.c_void_p] * 2 + [ctypes.c_long] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int, ctypes.c_uint] +
+                                              [ctypes.c_void_p] * 11)
+        st = dlib.dkt_diag_mll_reg_f32(_p(e), _p(y), y_bstride, _p(sv), _p(mean), _p(noise), b_, c_, n, float(jitter0), int(max_tries),
+                                       flags & (MLL_WANT_GRAD | MLL_WANT_CHOL), _p(cls_weight), _p(logp), _p(alpha), _p(chol), _p(w), _p(dsv), _p(dmean), _p(dnoise),
+                                       _p(jit), _p(info), _stream())
+        _lib.check(st, "dkt_diag_mll_reg_f32")
+        return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
     lib = _lib.load()
     _sync_env(lib)
     ws_bytes = int(lib.dkt_mll_workspace_bytes(b_, c_, n))

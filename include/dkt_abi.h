@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define DKT_ABI_VERSION 2 /* 2 (round 3-4): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA */
+#define DKT_ABI_VERSION 3 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
+                             3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG) */
 
 /* status codes */
 #define DKT_OK 0
@@ -55,7 +56,8 @@ extern "C" {
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
 #define DKT_MLL_WANT_CHOL 2u /* also write the Cholesky factors L[B,C,N,N]                  */
 #define DKT_MLL_FORCE_GENERIC 4u /* validation aid: take the generic LDS/global path for any N  */
-#define DKT_MLL_FORCE_REG 8u     /* validation aid: the register-sweep kernel instead of the MFMA wave-per-matrix kernel (N <= 127) */
+#define DKT_MLL_FORCE_REG 8u     /* RETIRED in ABI 3 (dkt_mll_f32 answers DKT_ERR_BAD_ARG): the round-1 register-sweep kernel is a validation twin in the
+                                    measurement library now (libdkt_diag.so: dkt_diag_mll_reg_f32), not part of the product */
 #define DKT_MLL_FORCE_BLOCKED 16u /* validation aid: the blocked batched-GEMM path instead of the tile-array kernels (N > 127) */
 #define DKT_MLL_FORCE_F32MFMA 32u /* validation aid: the exact-fp32 MFMA wave-per-matrix kernel instead of the f16-split one (N <= 127) */
 #define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */

@@ -32,7 +32,7 @@ def rel_l2(a, b):
 
 
 def test_loaded_native_library(cuda, lib):
-    assert lib.dkt_abi_version() == 2
+    assert lib.dkt_abi_version() == 3
     assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
