@@ -370,21 +370,17 @@ __global__ __launch_bounds__(512, 1) void gram_sym_bigep_f16x2_kernel(const floa
     while (js > is) { js -= is + 1; ++is; }
     const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
     constexpr int NPASS = 7;                               // 432 rows x 8 float4 / 512 threads
-    int voff[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int idx = tid + 512 * p, row = idx >> 3, c4 = idx & 7;
-        voff[p] = (row < N) ? (row * D + 4 * c4) * 4 : 0x7ffffff0;
-    }
     // LDS offset of the staged float4 of pass p: row = row0 + 64 p (so (row >> 2) & 3 does not depend on p), 8-byte half (c4 & 1) of unit (c4 >> 1) ^ G
     const int row0 = tid >> 3, c40 = tid & 7;
+    const int voff0 = (row0 * D + 4 * c40) * 4, vstep = 64 * D * 4;        // (per-pass offsets are re-derived in gload: 6 VGPRs the operand prefetch needs)
     const int loff0 = row0 * 64 + ((((c40 >> 1) ^ ((0x78 >> (2 * ((row0 >> 2) & 3))) & 3))) << 4) + ((c40 & 1) << 3);
     float4 rg[NPASS];
     auto gload = [&](const int k0) {
+        int vo = voff0;
+        asm volatile("" : "+v"(vo));                                       // (opaque: the seven predicated offsets are not hoisted out of the slab loop)
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int c4 = (tid + 512 * p) & 7;
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (k0 + 4 * c4 < D) ? voff[p] : 0x7ffffff0, k0 * 4, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (k0 + 4 * c40 < D && row0 + 64 * p < N) ? vo : 0x7ffffff0, k0 * 4 + p * vstep, 0);
             rg[p] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -415,16 +411,26 @@ __global__ __launch_bounds__(512, 1) void gram_sym_bigep_f16x2_kernel(const floa
         int i = is, j = js, cn = cnt;
         asm volatile("" : "+s"(i), "+s"(j), "+s"(cn));      // (opaque: the per-tile coordinates / predicates are recomputed per slab on the SALU, not hoisted into 150 SGPRs)
         f16x8 ah = *reinterpret_cast<const f16x8*>(base + i * 1024), am = *reinterpret_cast<const f16x8*>(base + i * 1024 + PLANE);
+        // the B fragments of tile u + 1 are read while tile u multiplies (two register sets; the accumulators take the three plane products directly --
+        // the registers of the two-level sum pay for the second set)
+        f16x8 bh[2], bm[2];
+        bh[0] = *reinterpret_cast<const f16x8*>(base + j * 1024);
+        bm[0] = *reinterpret_cast<const f16x8*>(base + j * 1024 + PLANE);
 #pragma unroll
         for (int u = 0; u < BEP_MAXT; ++u) {
             if (u < cn) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(base + j * 1024), bm = *reinterpret_cast<const f16x8*>(base + j * 1024 + PLANE);
-                f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
-                acc[u] += t;                                // two-level accumulation, as the other split Gram kernels
-                if (++j > i) {
-                    ++i; j = 0;
+                const bool rowchg = j + 1 > i;
+                const int jn = rowchg ? 0 : j + 1;
+                if (u + 1 < BEP_MAXT) {                     // (unconditional inside the block: a tile past the run re-reads a valid tile and is not used)
+                    bh[(u + 1) & 1] = *reinterpret_cast<const f16x8*>(base + jn * 1024);
+                    bm[(u + 1) & 1] = *reinterpret_cast<const f16x8*>(base + jn * 1024 + PLANE);
+                }
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm[u & 1], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh[u & 1], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u & 1], acc[u], 0, 0, 0);
+                j = jn;
+                if (rowchg) {
+                    ++i;
                     if (u + 1 < cn) {
                         ah = *reinterpret_cast<const f16x8*>(base + i * 1024);
                         am = *reinterpret_cast<const f16x8*>(base + i * 1024 + PLANE);
