@@ -241,7 +241,8 @@ class DKT(MetaTemplate):
             bn.bypass = False
 
     def _fused_front_end(self, n, d):
-        return (self.kernel_type in ("bncossim", "cossim") and n <= 128 and d % 4 == 0
+        # (n <= 128: the episode-resident kernels of dkt_frontend.hip; up to 448 rows: the streaming kernels of dkt_frontend_big.hip in front of the large-N Gram kernels)
+        return (self.kernel_type in ("bncossim", "cossim") and n <= 448 and d % 4 == 0
                 and os.environ.get("DKT_FUSED_FRONTEND", "1") != "0")
 
     def _episode_loss_from_trunk(self, x_feat, y, want_z=True):
@@ -377,7 +378,11 @@ class DKT(MetaTemplate):
         else:
             a = torch.ones(d, device=x_feat.device, dtype=torch.float32)
             s = torch.zeros(d, device=x_feat.device, dtype=torch.float32)
-        e_all, _ = ops.gram_bn(x_feat.unsqueeze(0).contiguous(), a.contiguous(), s.contiguous())
+        if ns + nq <= ops.FUSED_EP_MAX_N:
+            e_all, _ = ops.gram_bn(x_feat.unsqueeze(0).contiguous(), a.contiguous(), s.contiguous())
+        else:                                                 # (more than 128 rows: one normalisation kernel in front of the large-N Gram kernel)
+            zn, _ = ops.affine_normalize(x_feat.unsqueeze(0).contiguous(), a.contiguous(), s.contiguous())
+            e_all = ops.gram(zn, None, ops.KERNEL_LINEAR_UNIT)
         sv, mean, noise = self._hypers()
         out = ops.mll(e_all[:, :ns, :ns].contiguous(), y, sv.detach(), mean.detach(), noise.detach(), jitter0=self.jitter0,
                       max_tries=self.max_tries)

@@ -747,14 +747,80 @@ def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
     return dx, dg, db
 
 
+def affine_normalize(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
+    """Zn = y / max(|y|_2, 1e-12), y = a x + s, row by row; a, s: [D] or [B,D].  Returns (Zn [B,N,D], rnorm [B,N]) (dkt_affine_normalize_f32: the front end of
+    episodes with more than 128 rows, whose Gram kernels take unit rows as input)."""
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    a = _req(a, "a")
+    s = _req(s, "s")
+    stride = _ab_stride(a, s, b_, d)
+    zn = torch.empty_like(x)
+    rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_affine_normalize_f32"):
+        st = lib.dkt_affine_normalize_f32(_p(x), _p(a), _p(s), stride, _p(zn), _p(rnorm), b_, n, d, _stream())
+    _lib.check(st, "dkt_affine_normalize_f32")
+    return zn, rnorm
+
+
+def normalize_bn_bwd(dzn, zn, x, a, rnorm, mean=None, rstd=None):
+    """Backward of affine_normalize (+ the train-mode batch statistics behind a, s when mean / rstd are given): (dX, dgamma_part [B,D], dbeta_part [B,D]) --
+    the parts are None without statistics (dkt_normalize_bn_bwd_f32)."""
+    dzn = _req(dzn, "dzn", 3)
+    zn = _req(zn, "zn", 3)
+    x = _req(x, "x", 3)
+    b_, n, d = x.shape
+    a = _req(a, "a")
+    rnorm = _req(rnorm, "rnorm", 2)
+    stride = _ab_stride(a, a, b_, d)
+    train = mean is not None
+    if train:
+        mean = _req(mean, "mean", 2)
+        rstd = _req(rstd, "rstd", 2)
+    dx = torch.empty_like(x)
+    dg = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
+    db = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
+    ws = torch.empty((b_, n), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with _timed("dkt_normalize_bn_bwd_f32"):
+        st = lib.dkt_normalize_bn_bwd_f32(_p(dzn), _p(zn), _p(x), _p(a), stride, _p(mean), _p(rstd), _p(rnorm), _p(dx), _p(dg), _p(db), _p(ws), b_, n, d, _stream())
+    _lib.check(st, "dkt_normalize_bn_bwd_f32")
+    return dx, dg, db
+
+
+FUSED_EP_MAX_N = 128          # the episode-resident fused kernels of dkt_frontend.hip (Zn never written); above it: dkt_frontend_big.hip
+
+
 class _EpisodeLossBnFn(torch.autograd.Function):
     """Training episode straight from the trunk output X: [BatchNorm1d(train) +] F.normalize + linear Gram
     (dkt_gram_bn_train_f32; DKT_FUSED_STATS=0: dkt_bn_stats_f32 + dkt_gram_bn_f32) -> MLL (dkt_mll_f32) ; backward dkt_gram_bn_bwd_f32.  The normalised features are
-    never written to memory.  use_bn=False is the plain cossim kernel (no bn_out: affine map = identity)."""
+    never written to memory.  use_bn=False is the plain cossim kernel (no bn_out: affine map = identity).
+    More than 128 rows (the 20-way shapes): dkt_bn_stats_f32 -> dkt_affine_normalize_f32 (Zn written once: the large-N Gram kernels take unit rows as input) ->
+    dkt_gram_f32 -> dkt_mll_f32; backward dkt_gram_bwd_f32 -> dkt_normalize_bn_bwd_f32."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries):
         b_, n, d = x.shape
+        ctx.big = n > FUSED_EP_MAX_N
+        if ctx.big:
+            if use_bn:
+                st = bn_stats(x, gamma, beta, eps)
+                a, s, bmean, rstd, bvar = st["a"], st["s"], st["mean"], st["rstd"], st["var_unbiased"]
+            else:
+                a = torch.ones(d, device=x.device, dtype=torch.float32)
+                s = torch.zeros(d, device=x.device, dtype=torch.float32)
+                bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
+            zn, rnorm = affine_normalize(x, a, s)
+            e = gram(zn, None, KERNEL_LINEAR_UNIT)
+            out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
+            obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+            ctx.use_bn = bool(use_bn)
+            ctx.save_for_backward(x, zn, out["w"], a, s, bmean, rstd, rnorm, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
+            ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+            ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm)
+            ctx.set_materialize_grads(False)
+            return obj, out["logp"], out["alpha"], out["info"], out["jitter"], e, bmean, bvar, a, s, rnorm
         if use_bn and os.environ.get("DKT_FUSED_STATS", "1") != "0":
             e, rnorm, st = gram_bn_train(x, gamma, beta, eps)               # statistics + Gram in one pass over x
             a, s, bmean, rstd, bvar = st["a"], st["s"], st["mean"], st["rstd"], st["var_unbiased"]
@@ -782,7 +848,10 @@ class _EpisodeLossBnFn(torch.autograd.Function):
             return (None,) * 12
         x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        if ctx.use_bn:
+        if ctx.big:                                           # (the second saved tensor is Zn here)
+            dzn = gram_bwd(w, e, gobj, unit_rows=True, w_symmetric=True)
+            dx, dg, db = normalize_bn_bwd(dzn, e, x, a, rnorm, bmean if ctx.use_bn else None, rstd if ctx.use_bn else None)
+        elif ctx.use_bn:
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
         else:
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, None, None, gobj)

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DKT_ABI_VERSION 3 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
-                             3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG) */
+                             3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32 */
 
 /* status codes */
 #define DKT_OK 0
@@ -214,6 +214,24 @@ int dkt_gram_bn_train_f32(const float* X, const float* gamma, const float* beta,
 int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const float* a, const float* s, long ab_bstride,
                         const float* mean, const float* rstd, const float* rnorm, const float* ep_scale, float* dX,
                         float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream);
+
+/*
+ * ---- the same front end for episodes of MORE than 128 rows (round 4; the 20-way shapes of train.py:132-133) -----------------------
+ * The large-N Gram kernels take unit rows as their input, so Zn is written once:
+ *   forward : dkt_bn_stats_f32 (train mode; or the eval-mode / identity a, s)  ->  dkt_affine_normalize_f32  ->  dkt_gram_f32(DKT_KERNEL_LINEAR_UNIT)
+ *   backward: dkt_gram_bwd_f32 (dZn)  ->  dkt_normalize_bn_bwd_f32
+ *
+ * dkt_affine_normalize_f32 -- Zn[b,i,:] = y / max(||y||_2, 1e-12), y = a x + s; rnorm[b,i] = 1 / max(||y||, 1e-12).  a, s: [B,D] (ab_bstride = D) or [D]
+ *   (ab_bstride = 0).  Any N; D % 4 == 0.  Replaces bn_out (affine part) + F.normalize (methods/DKT.py:48, 141-142).
+ * dkt_normalize_bn_bwd_f32 -- given dZn = d obj / d Zn: dX = d obj / d X through F.normalize and the affine map, and -- when mean / rstd are given (train-mode
+ *   BatchNorm1d: the statistics depend on X) -- through the batch statistics too, with the per-episode parts dgamma_part[b,d] = sum_i dY_id xhat_id,
+ *   dbeta_part[b,d] = sum_i dY_id (the caller sums over b).  mean == NULL: the affine map is a constant (eval mode / no bn_out; X, rstd, dgamma_part, dbeta_part
+ *   unused).  a: [B,D] (a_bstride = D) or [D] (0).  rowdot_ws: [B,N] floats of scratch.  N <= 1024, D % 4 == 0.
+ *   Replaces autograd through F.normalize and BatchNorm1d (loss.backward(), methods/DKT.py:163).
+ */
+int dkt_affine_normalize_f32(const float* X, const float* a, const float* s, long ab_bstride, float* Zn, float* rnorm, int B, int N, int D, void* stream);
+int dkt_normalize_bn_bwd_f32(const float* dZn, const float* Zn, const float* X, const float* a, long a_bstride, const float* mean, const float* rstd,
+                             const float* rnorm, float* dX, float* dgamma_part, float* dbeta_part, float* rowdot_ws, int B, int N, int D, void* stream);
 
 /*
  * ---- per-class element-wise maps of the non-linear base kernels ------------------------------

@@ -1672,10 +1672,12 @@ def test_fused_gram_eval_mode_and_plain_cossim(cuda, b, n, d):
         assert np.abs(e1[i].cpu().numpy() - z1 @ z1.T).max() < 2e-5
 
 
-@pytest.mark.parametrize("b,c,per,d", [(2, 5, 5, 64), (2, 5, 21, 1600), (3, 5, 17, 512), (2, 3, 6, 40), (1, 2, 64, 128)])
+@pytest.mark.parametrize("b,c,per,d", [(2, 5, 5, 64), (2, 5, 21, 1600), (3, 5, 17, 512), (2, 3, 6, 40), (1, 2, 64, 128), (2, 5, 30, 64), (2, 20, 21, 128), (1, 3, 67, 36)])
 def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, per, d):
     """bn_out(train) + F.normalize + Gram + MLL and the whole backward (dX, dgamma, dbeta, hyper-parameters) in the fused
-    kernels vs float64 torch autograd of the reference formulation."""
+    kernels vs float64 torch autograd of the reference formulation.  N <= 128: the episode-resident kernels (the normalised features never leave the chip);
+    N = 150, 201, 420 (the 20-way shape): dkt_bn_stats_f32 -> dkt_affine_normalize_f32 -> the large-N Gram / marginal-likelihood kernels and back through
+    dkt_gram_bwd_f32 -> dkt_normalize_bn_bwd_f32."""
     n = c * per
     rng = np.random.default_rng(b * 100 + n + d)
     x = _relu_like(rng, b, n, d)
@@ -1714,6 +1716,19 @@ def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, p
     # the batch statistics returned for the running-estimate update
     assert rel_l2(bmean.cpu().numpy(), x.astype(np.float64).mean(1)) < 1e-5
     assert rel_l2(bvar.cpu().numpy(), x.astype(np.float64).var(1, ddof=1)) < 5e-5
+    # the pieces of the large-N front end on their own: Zn, rnorm and the backward with constant statistics (eval mode / no bn_out) vs float64
+    if n > 128:
+        a_ev = torch.linspace(0.5, 1.5, d, device=cuda)
+        s_ev = torch.linspace(-0.2, 0.3, d, device=cuda)
+        zn, rn = ops.affine_normalize(xt.detach(), a_ev, s_ev)
+        y64 = torch.tensor(x, dtype=torch.float64) * a_ev.double().cpu() + s_ev.double().cpu()
+        assert rel_l2(zn.cpu().numpy(), torch.nn.functional.normalize(y64, p=2, dim=2).numpy()) < 2e-6
+        assert rel_l2(rn.cpu().numpy(), (1.0 / y64.norm(dim=2)).numpy()) < 2e-6
+        gz = torch.randn(b, n, d, generator=torch.Generator().manual_seed(5))
+        xe = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        (torch.nn.functional.normalize(xe * a_ev.double().cpu() + s_ev.double().cpu(), p=2, dim=2) * gz.double()).sum().backward()
+        dx_ev, dg_ev, db_ev = ops.normalize_bn_bwd(gz.to(cuda), zn, xt.detach(), a_ev, rn)
+        assert dg_ev is None and db_ev is None and rel_l2(dx_ev.cpu().numpy(), xe.grad.numpy()) < 5e-6
 
 
 @pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2", "linear", "cossim"])
@@ -1897,20 +1912,23 @@ def test_dkt_failed_step_is_skipped_on_the_device_and_raised_at_the_next_print(c
         assert torch.isfinite(p).all(), name
 
 
-@pytest.mark.parametrize("kernel", ["bncossim", "cossim"])
+@pytest.mark.parametrize("kernel", ["bncossim", "cossim", "bncossim-large"])
 def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
     """correct() / get_logits() with bn_out (running statistics) + F.normalize folded into one Gram launch over the stacked
-    [support; query] trunk features, against torch's BatchNorm1d / F.normalize in front of the same GP kernels."""
+    [support; query] trunk features, against torch's BatchNorm1d / F.normalize in front of the same GP kernels.  `-large`: 150 rows per test episode --
+    one normalisation kernel (dkt_affine_normalize_f32) in front of the large-N Gram kernel."""
     torch.manual_seed(1)
+    large = kernel.endswith("-large")
+    kernel = kernel.split("-")[0]
     m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type=kernel).to(cuda)
     m.train()
     m.train_loop(0, _Loader(3, 5, 21, 28, 0), None)          # non-trivial running statistics and hyper-parameters
     m.eval()
-    x = _Loader(1, 5, 20, 28, 5).x[0]
-    m.n_query = 15
+    x = _Loader(1, 5, 30 if large else 20, 28, 5).x[0]
+    m.n_query = 25 if large else 15
     used = []
-    orig = ops.gram_bn
-    monkeypatch.setattr(ops, "gram_bn", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+    orig = ops.affine_normalize if large else ops.gram_bn
+    monkeypatch.setattr(ops, "affine_normalize" if large else "gram_bn", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
     logits_f = m.get_logits(x)
     top_f = m.correct(x)
     assert len(used) == 2, "the fused eval path must have run"
@@ -1928,8 +1946,8 @@ def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
 
 
 def test_dkt_20way_train_and_test_use_the_blocked_large_n_path(cuda, capsys):
-    """cfg4 shape through the drop-in class: 20-way 5-shot, 16 queries -> N = 420 in train_loop (blocked MLL path, unfused
-    front end), 100 support / 300 query at test time; the loss of one episode against the float64 restatement."""
+    """cfg4 shape through the drop-in class: 20-way 5-shot, 16 queries -> N = 420 in train_loop (tile-array MLL path, the streaming front end of
+    dkt_frontend_big.hip), 100 support / 300 query at test time; the loss of one episode against the float64 restatement."""
     torch.manual_seed(0)
     m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=20, n_support=5).to(cuda)
     m.train()
