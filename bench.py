@@ -316,14 +316,18 @@ def _workload(cfg, b, dev, rank, unit_rows):
                       n_backbone=n_backbone, kernel="bncossim")
 
 
-def _aux_paths(dev, b=2048, steps=5):
-    """The two other entries into the same hot path, at the headline shape (cfg2: N = 105, D = 1600, C = 5), driver-timed next to it:
-    `from_trunk_features` = what DKT.train_loop runs for bncossim (bn_out in train mode + F.normalize folded into the Gram kernels:
-    dkt_gram_bn_train_f32 -> dkt_mll_f32 -> dkt_gram_bn_bwd_f32), `rbf_per_class_lengthscales` = the non-linear kernels (dkt_gram_f32 SQDIST ->
-    dkt_class_kernel_f32 -> dkt_mll_f32 with DKT_MLL_E_PER_CLASS -> dkt_class_kernel_bwd_f32 -> dkt_gram_bwd_f32)."""
+def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
+    """The two other entries into the same hot path, driver-timed next to the graded one, at the headline shape (cfg2: N = 105, D = 1600, C = 5) and at the
+    20-way shape (cfg4: N = 420, D = 512, C = 20):
+    `from_trunk_features` = what DKT.train_loop runs for bncossim -- N <= 128: bn_out in train mode + F.normalize folded into the Gram kernels
+    (dkt_gram_bn_train_f32 -> dkt_mll_f32 -> dkt_gram_bn_bwd_f32); N > 128: dkt_bn_stats_f32 -> dkt_affine_normalize_f32 -> dkt_gram_f32 -> dkt_mll_f32 ->
+    dkt_gram_bwd_f32 -> dkt_normalize_bn_bwd_f32 --,
+    `rbf_per_class_lengthscales` = the non-linear kernels (dkt_gram_f32 SQDIST -> dkt_class_kernel_f32 -> dkt_mll_f32 with DKT_MLL_E_PER_CLASS ->
+    dkt_class_kernel_bwd_f32 -> dkt_gram_bwd_f32)."""
     from dkt_amd import ops
-    c, s, q, d = CONFIGS["cfg2"][:4]
+    c, s, q, d = CONFIGS[cfg][:4]
     n = c * (s + q)
+    b_rbf = b if b_rbf is None else b_rbf
     g = torch.Generator(device=dev).manual_seed(4321)
     x = (torch.randn(b, n, d, generator=g, device=dev).abs() + 1.0).requires_grad_(True)        # ReLU-like trunk output, common offset
     gamma = torch.ones(d, device=dev, requires_grad=True)
@@ -331,7 +335,7 @@ def _aux_paths(dev, b=2048, steps=5):
     raw_s, mean = perturbed_hypers(c, 99, dev)
     raw_s.requires_grad_(True)
     mean.requires_grad_(True)
-    ls = torch.linspace(25.0, 40.0, c, device=dev).requires_grad_(True)                         # ~ the distance scale of these features
+    ls = (torch.linspace(25.0, 40.0, c, device=dev) * (d / 1600.0) ** 0.5).requires_grad_(True)   # ~ the distance scale of these features
     noise = torch.full((c,), 0.1, device=dev)
     cls = torch.arange(c, device=dev).repeat_interleave(s + q)
     y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
@@ -348,12 +352,12 @@ def _aux_paths(dev, b=2048, steps=5):
     def rbf():
         for t in leaves:
             t.grad = None
-        outs = ops.episode_loss_class_kernel(x, y, torch.nn.functional.softplus(raw_s), mean, noise, cw, "rbf", ls)
+        outs = ops.episode_loss_class_kernel(x[:b_rbf], y, torch.nn.functional.softplus(raw_s), mean, noise, cw, "rbf", ls)
         outs[0].mean().backward()
         return outs[3]
 
     res = {}
-    for name, fn in (("from_trunk_features", trunk), ("rbf_per_class_lengthscales", rbf)):
+    for name, fn, nb in (("from_trunk_features", trunk, b), ("rbf_per_class_lengthscales", rbf, b_rbf)):
         for _ in range(2):
             info = fn()
         torch.cuda.synchronize()
@@ -365,7 +369,7 @@ def _aux_paths(dev, b=2048, steps=5):
         dt = (time.perf_counter() - t0) / steps
         kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
         ops.kernel_timing(False)
-        res[name] = {"value": round(b / dt, 1), "unit": "episodes/s", "episodes_per_step": b, "ms_per_step": round(1e3 * dt, 4),
+        res[name] = {"value": round(nb / dt, 1), "unit": "episodes/s", "episodes_per_step": nb, "ms_per_step": round(1e3 * dt, 4),
                      "valid": bool(int(info.abs().max().item()) == 0 and x.grad is not None and bool(torch.isfinite(x.grad).all().item())),
                      "kernels_ms": kt}
     return res
@@ -593,7 +597,8 @@ def run(args):
         roofline = roofline_all.get(dom)
         mll_arith = ("the factorisations, the triangular inverses and the K^-1 products as scaled 2-way f16 splits too (v_mfma_f32_16x16x16_f16, "
                      "fp32 accumulate; diagonal-tile sweeps in fp32 on the VALU)" if n + 1 <= 128 else
-                     "the factorisations / inverses on v_mfma_f32_16x16x4_f32, the K^-1 products as scaled 2-way f16 splits")
+                     "the tile-array factorisations, triangular inverses and K^-1 products on scaled 2-way f16-split tiles too (v_mfma_f32_16x16x16_f16 / "
+                     "16x16x32_f16, fp32 accumulate; diagonal tiles and the alpha column in fp32)")
         arith = ("f32 (results fp32-faithful; the two Gram contractions run as a scaled 2-way f16 split of every fp32 operand -- "
                  "22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16 products, fp32 accumulate; " + mll_arith + ")" if UNIT_ROWS else
                  "f32 (the two Gram contractions as an exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate; " + mll_arith + ")")
@@ -634,6 +639,8 @@ def run(args):
         del m
         torch.cuda.empty_cache()
         out["other_paths_cfg2"] = _aux_paths(dev)
+        torch.cuda.empty_cache()
+        out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 3)
         torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_test_time and args.config != "cfg0":
