@@ -340,7 +340,8 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
     cls = torch.arange(c, device=dev).repeat_interleave(s + q)
     y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
     cw = torch.full((c,), -1.0 / (c * n), device=dev)
-    leaves = (x, gamma, beta, raw_s, mean, ls)
+    x_rbf = x if b_rbf == b else x[:b_rbf].detach().clone().requires_grad_(True)               # (a leaf of its own: a slice inside the step would time autograd's zero-padding)
+    leaves = (x, x_rbf, gamma, beta, raw_s, mean, ls)
 
     def trunk():
         for t in leaves:
@@ -352,7 +353,7 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
     def rbf():
         for t in leaves:
             t.grad = None
-        outs = ops.episode_loss_class_kernel(x[:b_rbf], y, torch.nn.functional.softplus(raw_s), mean, noise, cw, "rbf", ls)
+        outs = ops.episode_loss_class_kernel(x_rbf, y, torch.nn.functional.softplus(raw_s), mean, noise, cw, "rbf", ls)
         outs[0].mean().backward()
         return outs[3]
 
@@ -370,7 +371,8 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
         kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
         ops.kernel_timing(False)
         res[name] = {"value": round(nb / dt, 1), "unit": "episodes/s", "episodes_per_step": nb, "ms_per_step": round(1e3 * dt, 4),
-                     "valid": bool(int(info.abs().max().item()) == 0 and x.grad is not None and bool(torch.isfinite(x.grad).all().item())),
+                     "valid": bool(int(info.abs().max().item()) == 0 and (x_rbf if fn is rbf else x).grad is not None
+                                   and bool(torch.isfinite((x_rbf if fn is rbf else x).grad).all().item())),
                      "kernels_ms": kt}
     return res
 

@@ -11,6 +11,7 @@
 // Memory-bound element-wise work: coalesced dword accesses, base read once per element for all classes.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 #include "dkt_common.h"
 #include "../../include/dkt_abi.h"
@@ -126,6 +127,130 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd(const float* __restric
     }
 }
 
+// The same chain rule for 128 < N <= 512 (round 4; the large episodes of the one-launch per-class path, N <= 447) with 16-byte accesses and the per-class parameter
+// partials in REGISTERS: the kernel above reads 4 bytes per lane and load, issues a class's load only after the previous class was consumed, and
+// read-modify-writes an LDS slot per element and class -- 1.0-1.5 TB/s of the W stream (0.91 of the 3.4 ms of a 20-way rbf step of 64 episodes).
+// A lane owns 4 consecutive columns of its wave's row (two such groups for N > 256); the classes go in groups of four -- four independent
+// 16-byte loads in flight per lane --; classes past C read through an out-of-range offset (0: no contribution), so a group has no branches.
+// A load that starts inside the row is issued whole (the row end may fall inside it; dword-aligned buffer loads): masked afterwards.
+template <int KIND>
+__global__ __launch_bounds__(CKB_T) void class_kernel_bwd_v4(const float* __restrict__ W, const float* __restrict__ base,
+                                                           const float* __restrict__ param, int power, float* __restrict__ Wp,
+                                                           float* __restrict__ dparam, int C, int N, int nsplit) {
+    __shared__ float red[32][8];
+    __shared__ float prm[32], prm_il2[32];
+    const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int rows_per = (N + nsplit - 1) / nsplit, row0 = sp * rows_per, row1 = min(N, row0 + rows_per);
+    const size_t nn = (size_t)N * N;
+    typedef __amdgpu_buffer_rsrc_t brs;
+    const brs wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (size_t)b * C * nn), 0, (unsigned)((size_t)C * nn * 4), 0x00020000);
+    const brs br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)b * nn), 0, (unsigned)(nn * 4), 0x00020000);
+    const brs pr = __builtin_amdgcn_make_buffer_rsrc(Wp + (size_t)b * nn, 0, (unsigned)(nn * 4), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    if (tid < 32) {
+        const float p = tid < C ? param[tid] : 1.0f;
+        prm[tid] = p;
+        prm_il2[tid] = 1.0f / (p * p);
+    }
+    __syncthreads();
+    float dp[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dp[c] = 0.f;
+    const int nch = (N + 255) >> 8;                                        // column groups of 256 (N <= 512: 1 or 2)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    for (int i = row0 + wave; i < row1; i += CKB_T / 64) {
+        float a[2][4];
+        float rowsum = 0.f, adiag = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[ch][e] = 0.f;
+            if (ch < nch) {                                                 // (uniform)
+                const int j = 256 * ch + 4 * lane;
+                const int off = (j < N) ? (i * N + j) * 4 : OOB;
+                const u4 vb = __builtin_amdgcn_raw_buffer_load_b128(br, off, 0, 0);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(vb[e]);
+#pragma unroll
+                for (int c0 = 0; c0 < 32; c0 += 4) {
+                    if (c0 < C) {                                           // (uniform)
+                        u4 w4[4];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)                      // (the class offset rides in the scalar offset: c nn 4 < 2^31 for C <= 32, N <= 512)
+                            w4[cc] = __builtin_amdgcn_raw_buffer_load_b128(wr, (c0 + cc < C) ? off : OOB, (int)((c0 + cc < C ? c0 + cc : 0) * nn * 4), 0);
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const int c = c0 + cc;
+                            const float p = prm[c], il2 = prm_il2[c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float w = (j + e < N) ? __uint_as_float(w4[cc][e]) : 0.f;       // (past the row end: the next row's values)
+                                float f, df;
+                                if constexpr (KIND == DKT_CLASSMAP_POLY) {
+                                    class_map<KIND>(v[e] + p, power, f, df);
+                                    const float g = w * df;
+                                    a[ch][e] += g;                          // d obj / d g_ij
+                                    dp[c] += g;                             // d obj / d offset_c
+                                } else {
+                                    const float u = v[e] * il2;
+                                    class_map<KIND>(u, power, f, df);
+                                    const float g = w * df;                 // d obj / d u_c,ij
+                                    a[ch][e] = __builtin_fmaf(2.0f * g, il2, a[ch][e]);             // A = 2 d obj / d d2
+                                    dp[c] = __builtin_fmaf(g, -2.0f * u / p, dp[c]);                // d u / d l = -2 u / l
+                                }
+                            }
+                        }
+                    }
+                }
+                if constexpr (KIND != DKT_CLASSMAP_POLY) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rowsum += a[ch][e];
+                        if (j + e == i) adiag = a[ch][e];
+                    }
+                }
+            }
+        }
+        if constexpr (KIND != DKT_CLASSMAP_POLY) {
+            rowsum = wave_allsum(rowsum);
+            adiag = wave_allsum(adiag);                                      // one lane held it
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (ch < nch) {
+                const int j = 256 * ch + 4 * lane;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (KIND == DKT_CLASSMAP_POLY) o[e] = a[ch][e];
+                    else o[e] = (j + e == i) ? rowsum - adiag : -a[ch][e];   // Wp = diag(A 1) - A
+                }
+                if (j + 3 < N) {
+                    const u4 ov = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, pr, (i * N + j) * 4, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[e]), pr, (j + e < N) ? (i * N + j + e) * 4 : OOB, 0, 0);
+                }
+            }
+        }
+    }
+    // parameter partials: wave sums -> a fixed-order sum over the 8 waves (deterministic)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c < C) {
+            const float s = wave_allsum(dp[c]);
+            if (lane == 0) red[c][wave] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        const float* d = red[tid];
+        dparam[(size_t)blockIdx.x * C + tid] = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    }
+}
+
 }  // namespace
 
 extern "C" int dkt_class_kernel_f32(const float* base, int kind, const float* param, int power, float* E, int B, int C, int NN,
@@ -144,6 +269,9 @@ extern "C" int dkt_class_kernel_f32(const float* base, int kind, const float* pa
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
+static int g_ck_v4 = -1;
+void dkt_classkernel_reload_env() { g_ck_v4 = -1; }                     // dkt_reload_env()
+
 extern "C" int dkt_class_kernel_bwd_nsplit(int B, int N) {
     if (B <= 0 || N <= 0) return 1;
     int ns = 1;
@@ -159,6 +287,17 @@ extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int k
     if (C > 32) return DKT_ERR_TOO_LARGE;                                // 32 x 512 floats of LDS partials (64 KB)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * nsplit), block(CKB_T);
+    if (g_ck_v4 < 0) { const char* v = getenv("DKT_CLASS_BWD_V4"); g_ck_v4 = (v && v[0] == '0') ? 0 : 1; }      // (0: the dword kernel, a measurement twin)
+    // (N <= 128: a row of 4-column groups leaves more than half of a wave's lanes idle -- 0.58 vs 0.28 ms at N = 105, C = 5, 2048 episodes: the dword kernel stays)
+    if (N > 128 && N <= 512 && g_ck_v4 != 0) {
+        switch (kind) {
+            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_RBF>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_POLY>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            default: return DKT_ERR_BAD_ARG;
+        }
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    }
     const size_t lds = (size_t)C * CKB_T * sizeof(float);
     switch (kind) {
         case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd<DKT_CLASSMAP_RBF>, grid, block, lds, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;

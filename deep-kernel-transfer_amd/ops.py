@@ -108,7 +108,7 @@ class _timed:
 # ------------------------------------------------------------------------------------------------
 _ENV_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_EP_MINB", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR",
                  "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_F16",
-                 "DKT_GRAM_DIST_EP", "DKT_MLL_F32MFMA", "DKT_MLL_P2_GUARD", "DKT_MLL_TILED_CHUNK", "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA")
+                 "DKT_GRAM_DIST_EP", "DKT_MLL_F32MFMA", "DKT_MLL_P2_GUARD", "DKT_MLL_TILED_CHUNK", "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA", "DKT_CLASS_BWD_V4")
 _env_seen = None
 
 
@@ -479,6 +479,7 @@ def class_kernel_bwd(w: torch.Tensor, base: torch.Tensor, cmap: int, power: int,
         raise RuntimeError("class_kernel_bwd: base must be [B,N,N] and param [C]")
     wp = torch.empty_like(base)
     lib = _lib.load()
+    _sync_env(lib)
     nsplit = int(lib.dkt_class_kernel_bwd_nsplit(b_, n))
     dparam = torch.empty((b_, nsplit, c), device=w.device, dtype=torch.float32)
     with _timed("dkt_class_kernel_bwd_f32"):

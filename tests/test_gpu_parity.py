@@ -637,7 +637,7 @@ def _class_kernel_ref(base, kernel, param):
 
 
 @pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2"])
-@pytest.mark.parametrize("b,c,n,d", [(3, 5, 25, 16), (2, 5, 105, 64), (2, 3, 64, 8), (1, 20, 33, 12)])
+@pytest.mark.parametrize("b,c,n,d", [(3, 5, 25, 16), (2, 5, 105, 64), (2, 3, 64, 8), (1, 20, 33, 12), (2, 20, 420, 16), (3, 7, 258, 8), (1, 32, 130, 8)])
 def test_class_kernel_maps_and_chain_rule(cuda, kernel, b, c, n, d):
     """dkt_class_kernel_f32 / dkt_class_kernel_bwd_f32: E[b,c] = f(base[b]; param_c) and, for a symmetric W[b,c] = d obj / d E[b,c], the matrix
     Wp with d obj / d Z = (Wp + Wp^T) Z and d obj / d param -- against float64 autograd of obj = sum W . f(base(z); param)."""
@@ -668,6 +668,13 @@ def test_class_kernel_maps_and_chain_rule(cuda, kernel, b, c, n, d):
     dz_ref = torch.autograd.grad(obj.sum(), z64)[0].numpy()
     assert rel_l2(dz.cpu().numpy(), dz_ref) < 1e-4, rel_l2(dz.cpu().numpy(), dz_ref)
     assert rel_l2(dpar.cpu().numpy(), dpar_ref) < 1e-4, rel_l2(dpar.cpu().numpy(), dpar_ref)
+    # N > 128 took the 16-byte kernel of round 4: the dword kernel (round 3; what serves N <= 128 and N > 512) on the same inputs
+    os.environ["DKT_CLASS_BWD_V4"] = "0"
+    try:
+        wp0, dpar0 = ops.class_kernel_bwd(dev_t(w, cuda), base, cmap, power, dev_t(param, cuda))
+    finally:
+        os.environ.pop("DKT_CLASS_BWD_V4")
+    assert rel_l2(wp.cpu().numpy(), wp0.cpu().numpy()) < 2e-6 and rel_l2(dpar.cpu().numpy(), dpar0.cpu().numpy()) < 2e-5
     # cross matrices (test time): [B, M, N] bases go through the same map
     ex = ops.kernel_matrix_per_class(zd[:, :7], zd, kernel, dev_t(param, cuda), dev_t(param, cuda))
     assert ex.shape == (b, c, 7, n) and rel_l2(ex.cpu().numpy(), e64.detach().numpy()[:, :, :7]) < 2e-5
