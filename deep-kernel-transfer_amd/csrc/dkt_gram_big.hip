@@ -483,7 +483,9 @@ static bool gram_bwd_rows8_enabled() {
 
 template <int KS>
 void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
-    if (KS >= 10 && gram_bwd_rows8_enabled()) {          // N > 256: three or more 128-row blocks per episode
+    // 128-row blocks: N > 256 always (three or more blocks per episode); 128 < N <= 256 when the slab loop is long enough to pay for the larger prologue (D >= 128:
+    // 0.34 vs 0.41 ms at N = 256, 0.21 vs 0.23 at N = 190, D = 512; at D = 64 the 64-row kernel wins, 0.11 vs 0.125 ms) and the batch fills the GPU with them
+    if (gram_bwd_rows8_enabled() && (KS >= 10 || (D >= 128 && (long)B * ((N + 127) / 128) >= 256))) {
         const int nrb = (N + 127) / 128;
         const int grid = 8 * ((B + 7) / 8) * nrb;
         hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 8>), dim3(grid), dim3(512), 0, st, W, Z, dZ, B, N, D, sc, nrb);

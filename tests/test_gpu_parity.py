@@ -930,13 +930,12 @@ def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
         assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
 
 
-@pytest.mark.parametrize("n,d", [(190, 512), (320, 512), (420, 512), (431, 36), (290, 64), (447, 100)])
-def test_gram_large_n_kernel_twins(cuda, n, d):
+@pytest.mark.parametrize("b,n,d", [(72, 190, 512), (72, 320, 512), (72, 420, 512), (72, 431, 36), (72, 290, 64), (72, 447, 100), (136, 190, 512), (130, 250, 128)])
+def test_gram_large_n_kernel_twins(cuda, b, n, d):
     """N > 128, unit rows, a batch that takes the round-4 kernels (episode-resident Gram for N <= 432; Gram backward in 128-row blocks for N > 256): against the
     round-2 kernels on the same inputs (DKT_GRAM_BIG_EP=0 / DKT_GRAM_BWD_ROWS8=0) and float64 on sampled episodes; symmetric, unit diagonal.  The rows of W differ in
     scale by orders of magnitude (the kernels scale every row by its own power of two), N is not always a multiple of 4 (row ends inside a 16-byte load) and
-    the upstream gradient enters per episode."""
-    b = 72
+    the upstream gradient enters per episode.  The last two cases: 128 < N <= 256 with a batch that fills the GPU with 128-row blocks (the 64-row kernel below that)."""
     g = torch.Generator(device=cuda).manual_seed(n + d)
     z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=cuda) * torch.exp(torch.randn(b, n, d, generator=g, device=cuda)), dim=2).contiguous()
     w = torch.randn(b, n, n, generator=g, device=cuda)

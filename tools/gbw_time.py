@@ -12,7 +12,7 @@ from dkt_amd import ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
-for (b, n, d) in [(1024, 420, 512), (1024, 320, 512), (1024, 264, 512), (256, 420, 1600)]:
+for (b, n, d) in [(1024, 420, 512), (1024, 320, 512), (1024, 256, 512), (1024, 190, 512), (1024, 150, 512), (2048, 190, 64)]:
     z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=dev), dim=2).contiguous()
     w = torch.randn(b, n, n, generator=g, device=dev)
     w = (w + w.transpose(1, 2)).contiguous()
