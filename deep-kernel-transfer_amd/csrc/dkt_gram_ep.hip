@@ -752,8 +752,11 @@ struct GramEnv {
     void load() {
         ep = get("DKT_GRAM_EP", 1); minb = get("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
         ep_bk = get("DKT_GRAM_EP_BK", 64); ep_bd = get("DKT_GRAM_EP_BD", 32);
-        unit_var = get("DKT_GRAM_UNIT_VAR", 2223); split_var = get("DKT_GRAM_SPLIT_VAR", 11);
-        bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 1222); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
+        // Round 4 (tools/sweep_ep_variants.py + the in-step A/B of tools/r4_run12.sh, profiles/r04/v14_ep_variant_sweep.log): the forward with non-temporal Z loads
+        // (22232: -1 % at D = 1600, -5 % at D = 512, -4 % at D = 64 against 2223) and, below D = 1024, the backward with ONE LDS image and prefetch depth 1
+        // (211: 0.20 vs 0.24 ms at cfg1, 0.57 vs 0.68 ms at cfg3; equal at D = 1600, where 1222 -- two images, non-temporal dZ stores -- stays): 0 = this choice by D.
+        unit_var = get("DKT_GRAM_UNIT_VAR", 22232); split_var = get("DKT_GRAM_SPLIT_VAR", 11);
+        bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 0); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
         bwd_unit_mind = get("DKT_GRAM_BWD_UNIT_MIND", 64); bwd_split_mind = get("DKT_GRAM_BWD_SPLIT_MIND", 1024);
     }
 };
@@ -792,7 +795,8 @@ template <int NT>
 void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, int bd, bool unit, hipStream_t st) {
     if (bd == 3) {
         // <LDS buffers><prefetch depth> of the bf16 split; 2xx = scaled-f16 split (unit-norm rows of Z only)
-        const int v = unit ? gram_env().bwd_unit_var : gram_env().bwd_split_var;
+        int v = unit ? gram_env().bwd_unit_var : gram_env().bwd_split_var;
+        if (unit && v == 0) v = D < 1024 ? 211 : 1222;
         if (v == 222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 2222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }

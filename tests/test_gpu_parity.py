@@ -161,13 +161,28 @@ def test_gram_unit_rows_f16_split(cuda, b, n, d, kind):
     assert (ops.gram(z[:2].contiguous(), None, ops.KERNEL_LINEAR_UNIT) - e[:2]).abs().max().item() < 4e-6
 
 
-@pytest.mark.parametrize("var", ["211", "212", "2611", "26113", "26122", "2223", "2213"])
+@pytest.mark.parametrize("var", ["211", "212", "2611", "26113", "26122", "2223", "2213", "22232"])
 def test_gram_unit_pipeline_variants_agree_bitwise(cuda, var, monkeypatch):
     z = _unit_rows(64, 105, 1632, 3, cuda, "plain")
     monkeypatch.setenv("DKT_GRAM_UNIT_VAR", "2223")
     ref = ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)
     monkeypatch.setenv("DKT_GRAM_UNIT_VAR", var)
     assert torch.equal(ops.gram(z, None, ops.KERNEL_LINEAR_UNIT), ref)
+    monkeypatch.delenv("DKT_GRAM_UNIT_VAR")
+    assert torch.equal(ops.gram(z, None, ops.KERNEL_LINEAR_UNIT), ref), "the default variant"
+
+
+@pytest.mark.parametrize("d", [64, 512, 1632])
+def test_gram_bwd_unit_pipeline_variants_agree_bitwise(cuda, d, monkeypatch):
+    """The staging variants of the f16-split Gram backward (DKT_GRAM_BWD_UNIT_VAR: LDS images / prefetch depth / store policy; the default picks by D) run the
+    same arithmetic in the same order."""
+    z = _unit_rows(64, 105, d, 5, cuda, "plain")
+    g = torch.Generator(device=cuda).manual_seed(d)
+    w = torch.randn(64, 105, 105, generator=g, device=cuda)
+    ref = ops.gram_bwd(w, z, None, unit_rows=True)
+    for var in ("211", "221", "212", "222", "1222", "2222", "3222"):
+        monkeypatch.setenv("DKT_GRAM_BWD_UNIT_VAR", var)
+        assert torch.equal(ops.gram_bwd(w, z, None, unit_rows=True), ref), var
 
 
 def test_gram_unit_rows_promise_violation_is_loud(cuda):
