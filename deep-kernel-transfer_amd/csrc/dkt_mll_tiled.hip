@@ -738,8 +738,10 @@ struct WRanges { int ng; int c0[10]; };          // column ranges [c0[g], c0[g +
 // operands, so the six ds_read_b128 of chunk u + 1 fly during the 24 MFMAs of chunk u.
 typedef __attribute__((address_space(3))) unsigned char wres_lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char wres_glb_u8;
-template <int MAXC, bool DMA>
-__global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges rg) {
+// NW = 8 (DKT_MLL_TILED_WNW): one 8-wave workgroup per CU instead of two of 4 waves -- twice the accumulators per workgroup, so wider column ranges
+// (NT = 27: [0,22) [22,27) instead of three ranges, 488 instead of 664 tile reads per matrix; NT = 21: ONE range, 231 instead of 311).
+template <int MAXC, bool DMA, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiled_wres_kernel(TiledArgs t, WRanges rg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wres_smem[];
     const MllArgs& a = t.a;
     const int tid = threadIdx.x;
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
     // LDS: [2][32] split tiles of 1 KB (28 slots for a step's group of strips + 4 that a diagonal chunk may read past it) | kap[C] | cr[C]
-    constexpr int NST = 7, GT = 4 * NST, BUFT = GT + 4;                     // staged tiles per wave and step; tile slots per group; per buffer
+    constexpr int NST = NW == 4 ? 7 : 4, GT = NW * NST, BUFT = GT + 4;      // staged tiles per wave and step; tile slots per group; per buffer
     f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
     float* kap_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * BUFT * 1024);
     float* cr_s = kap_s + 64;
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
     }
     __syncthreads();
     // this wave's chunks: the chunks of the range in column-pair-major order -- pair (j0, j0 + 1), j0 = c0, c0 + 2, ..., rows i0 = 0, 4, ... <= j0 + 1 --
-    // dealt round-robin to the 4 waves; chunk u of the wave = chunk number w + 4 u.  Packed i0 | j0 << 8 in SGPRs for the whole kernel; a slot past
+    // dealt round-robin to the NW waves; chunk u of the wave = chunk number w + NW u.  Packed i0 | j0 << 8 in SGPRs for the whole kernel; a slot past
     // the end of the list gets j0 = 255 (it never takes part).
     int tc[MAXC];
     {
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
 #pragma unroll
         for (int u = 0; u < MAXC; ++u) {
             tc[u] = (j0 < c1) ? (i0 | (j0 << 8)) : (255 << 8);
-            step1(); step1(); step1(); step1();
+            for (int x = 0; x < NW; ++x) step1();
         }
     }
     f32x4 acc[MAXC][8];                                                     // [chunk][4 rows x 2 columns: index 2 x + y]
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         gtab = ka | (kb << 8);
 #pragma unroll
         for (int x = 0; x < NST; ++x) {
-            int k = ka, i = w + 4 * x;
+            int k = ka, i = w + NW * x;
             while (k < kb && i >= lim(k)) { i -= lim(k); ++k; }
             const bool ok = gvalid && k < kb;
             stab[x] = ok ? (tslot(NT, i, k) | ((k == NT - 1) ? 0x1000 : 0) | 0x2000) : 0;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
 #pragma unroll
         for (int x = 0; x < NST; ++x) {
             const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
-            if (e & 0x2000) sbuf[(bufi * BUFT + w + 4 * x) * 64 + lane] = S[x];
+            if (e & 0x2000) sbuf[(bufi * BUFT + w + NW * x) * 64 + lane] = S[x];
         }
     };
     const unsigned char* tbase = reinterpret_cast<const unsigned char*>(t.tiles + (size_t)bl * C * (ntt + 1) * 256) + lane16;
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
                 const int e = __builtin_amdgcn_readlane(stab[x], gr.gi);
                 if (e & 0x2000)
                     __builtin_amdgcn_global_load_lds((wres_glb_u8*)(tbase + (size_t)(cbase + (e & 0xfff)) * 1024),
-                                                     (wres_lds_u8*)(wres_smem + (bufi * BUFT + w + 4 * x) * 1024), 16, 0, 0);
+                                                     (wres_lds_u8*)(wres_smem + (bufi * BUFT + w + NW * x) * 1024), 16, 0, 0);
             }
         }
     };
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void tiled_wres_kernel(TiledArgs t, WRanges
         for (int cb = 0; cb < C; cb += cgrp) {
             const int cn = min(cgrp, C - cb);
             __syncthreads();
-            for (int idx = tid; idx < cn * npad; idx += 256) {
+            for (int idx = tid; idx < cn * npad; idx += 64 * NW) {
                 const int c = idx / npad, r = idx - c * npad;
                 al_s[idx] = (r < N) ? a.alpha[((size_t)b * C + cb + c) * N + r] : 0.f;
             }
@@ -1083,14 +1085,14 @@ constexpr int WRES_MAXC = 5;                     // chunks (of 8 accumulator til
 
 // column ranges of W with at most 4 MAXC chunks each, cut at even distances from the start of a range (a chunk is a PAIR of columns):
 // NT = 27 -> [0,16) [16,22) [22,27); NT = 21 -> [0,16) [16,21)
-inline WRanges wres_ranges(const int NT) {
+inline WRanges wres_ranges(const int NT, const int waves = 4) {
     WRanges r;
     r.ng = 0;
     r.c0[0] = 0;
     int cnt = 0;
     for (int j0 = 0; j0 < NT; j0 += 2) {                                    // j0 - c0 is even: the pairs restart with every range
         const int ch = (j0 + 1) / 4 + 1;                                    // chunks of the pair (j0, j0 + 1): rows i0 = 0, 4, ... <= j0 + 1
-        if (cnt + ch > 4 * WRES_MAXC) { r.c0[++r.ng] = j0; cnt = 0; }
+        if (cnt + ch > waves * WRES_MAXC) { r.c0[++r.ng] = j0; cnt = 0; }
         cnt += ch;
     }
     r.c0[++r.ng] = NT;
@@ -1343,6 +1345,15 @@ inline bool invres_fits(const WRanges& r, const int NT) {
     return true;
 }
 
+int g_tiled_wnw = -1;
+inline int tiled_wnw() {                   // DKT_MLL_TILED_WNW: waves per workgroup of the W kernel (4: two workgroups per CU; 8: one, wider column ranges; 0 / unset: by NT)
+    if (g_tiled_wnw < 0) {
+        const char* v = getenv("DKT_MLL_TILED_WNW");
+        const int w = v ? atoi(v) : 0;
+        g_tiled_wnw = (w == 8 || w == 4) ? w : 0;
+    }
+    return g_tiled_wnw;
+}
 int g_tiled_wdma = -1;
 inline bool tiled_wdma() {
     if (g_tiled_wdma < 0) {
@@ -1452,6 +1463,19 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
         }
         const int units = t.per_class ? nmat : bcnt;
+        // 8 waves when that makes W ONE column range where 4 waves need two (17 <= NT <= 21, N = 256 .. 335): 231 instead of 311 tile reads per matrix at NT = 21,
+        // W 2.6 -> 1.9 ms per 1024 N = 320 episodes.  Where 8 waves still need two ranges the single workgroup per CU loses (NT = 27: W 4.0 -> 5.9 ms: each step's
+        // LDS-DMA is exposed at its barrier with no second workgroup to fill in).
+        const WRanges rg8 = wres_ranges(t.NT, 8);
+        if (tiled_wdma() && (tiled_wnw() == 8 || (tiled_wnw() == 0 && rg.ng > 1 && rg8.ng == 1))) {
+            static bool attr8 = false;
+            if (!attr8) {
+                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 36 * 1024 + 1024);
+                attr8 = true;
+            }
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true, 8>), dim3(8 * ((units + 7) / 8) * rg8.ng), dim3(512), (size_t)2 * 36 * 1024 + 2 * 64 * sizeof(float), st, t, rg8);
+            return;
+        }
         if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         else hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         return;
@@ -1467,7 +1491,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 
 }  // namespace
 
-void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; g_tiled_wdma = -1; }      // dkt_reload_env()
+void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; g_tiled_wdma = -1; g_tiled_wnw = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
