@@ -759,7 +759,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void tiled_wres_kernel(Ti
     const int lane = g.lane, lane16 = g.lane * 16, c16 = g.c16, g4 = g.g4, pN = g.pN;
     const size_t ntt = (size_t)NT * (NT + 1) / 2;
     // LDS: [2][32] split tiles of 1 KB (28 slots for a step's group of strips + 4 that a diagonal chunk may read past it) | kap[C] | cr[C]
-    constexpr int NST = NW == 4 ? 7 : 4, GT = NW * NST, BUFT = GT + 4;      // staged tiles per wave and step; tile slots per group; per buffer
+#ifndef DKT_WRES_NST8
+#define DKT_WRES_NST8 6
+#endif
+    constexpr int NST = NW == 4 ? 7 : DKT_WRES_NST8, GT = NW * NST, BUFT = GT + 4;      // staged tiles per wave and step; tile slots per group; per buffer
     f32x4* sbuf = reinterpret_cast<f32x4*>(wres_smem);
     float* kap_s = reinterpret_cast<float*>(wres_smem + (size_t)2 * BUFT * 1024);
     float* cr_s = kap_s + 64;
@@ -1470,10 +1473,10 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         if (tiled_wdma() && (tiled_wnw() == 8 || (tiled_wnw() == 0 && rg.ng > 1 && rg8.ng == 1))) {
             static bool attr8 = false;
             if (!attr8) {
-                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 36 * 1024 + 1024);
+                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8 * DKT_WRES_NST8 + 4) * 1024 + 1024);
                 attr8 = true;
             }
-            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true, 8>), dim3(8 * ((units + 7) / 8) * rg8.ng), dim3(512), (size_t)2 * 36 * 1024 + 2 * 64 * sizeof(float), st, t, rg8);
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true, 8>), dim3(8 * ((units + 7) / 8) * rg8.ng), dim3(512), (size_t)2 * (8 * DKT_WRES_NST8 + 4) * 1024 + 2 * 64 * sizeof(float), st, t, rg8);
             return;
         }
         if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
