@@ -1349,11 +1349,11 @@ inline bool invres_fits(const WRanges& r, const int NT) {
 }
 
 int g_tiled_wnw = -1;
-inline int tiled_wnw() {                   // DKT_MLL_TILED_WNW: waves per workgroup of the W kernel (4: two workgroups per CU; 8: one, wider column ranges; 0 / unset: by NT)
+inline int tiled_wnw() {                   // DKT_MLL_TILED_WNW: waves per workgroup of the W kernel (4: two workgroups per CU; 8: one, wider column ranges; 84: 8 for the first range, 4 for the rest; 0 / unset: by NT)
     if (g_tiled_wnw < 0) {
         const char* v = getenv("DKT_MLL_TILED_WNW");
         const int w = v ? atoi(v) : 0;
-        g_tiled_wnw = (w == 8 || w == 4) ? w : 0;
+        g_tiled_wnw = (w == 8 || w == 4 || w == 84) ? w : 0;
     }
     return g_tiled_wnw;
 }
@@ -1477,6 +1477,24 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
                 attr8 = true;
             }
             hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true, 8>), dim3(8 * ((units + 7) / 8) * rg8.ng), dim3(512), (size_t)2 * (8 * DKT_WRES_NST8 + 4) * 1024 + 2 * 64 * sizeof(float), st, t, rg8);
+            return;
+        }
+        // NT >= 23 (N >= 352: the 20-way episode of 420 rows): the wide first range [0, 22) in an 8-wave workgroup, the rest -- at most 20 chunks -- in a 4-wave
+        // workgroup of its own launch: 488 instead of 664 tile reads per matrix at NT = 27, W 4.0 -> 3.5 ms, the marginal likelihood 16.5 -> 15.95 ms per 1024 episodes
+        // (the narrow range is what made two 8-wave ranges slow: 2.5 chunks per wave behind every barrier).
+        int tail_chunks = 0;
+        for (int j0 = rg8.c0[1]; rg8.ng == 2 && j0 < t.NT; j0 += 2) tail_chunks += (j0 + 1) / 4 + 1;
+        if (tiled_wdma() && rg8.ng == 2 && tail_chunks <= 4 * WRES_MAXC && (tiled_wnw() == 84 || tiled_wnw() == 0)) {
+            static bool attr84 = false;
+            if (!attr84) {
+                (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8 * DKT_WRES_NST8 + 4) * 1024 + 1024);
+                attr84 = true;
+            }
+            WRanges ra, rb;
+            ra.ng = 1; ra.c0[0] = 0; ra.c0[1] = rg8.c0[1];
+            rb.ng = 1; rb.c0[0] = rg8.c0[1]; rb.c0[1] = t.NT;
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true, 8>), dim3(8 * ((units + 7) / 8)), dim3(512), (size_t)2 * (8 * DKT_WRES_NST8 + 4) * 1024 + 2 * 64 * sizeof(float), st, t, ra);
+            hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8)), dim3(256), lds, st, t, rb);
             return;
         }
         if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);

@@ -903,7 +903,7 @@ def test_mll_tile_array_w_kernel_class_weights_signs_and_hyper_ranges(cuda, n, c
     assert rel_l2(o32["w"].cpu().numpy(), w_ref) < GRAD_RTOL
 
 
-@pytest.mark.parametrize("switch", ["DKT_MLL_TILED_WRES=0", "DKT_MLL_TILED_F16=0", "DKT_MLL_TILED_INVRES=1", "DKT_MLL_TILED_WGS=2", "DKT_MLL_TILED_WNW=8", "DKT_MLL_TILED_WNW=4"])
+@pytest.mark.parametrize("switch", ["DKT_MLL_TILED_WRES=0", "DKT_MLL_TILED_F16=0", "DKT_MLL_TILED_INVRES=1", "DKT_MLL_TILED_WGS=2", "DKT_MLL_TILED_WNW=8", "DKT_MLL_TILED_WNW=4", "DKT_MLL_TILED_WNW=84"])
 @pytest.mark.parametrize("n,c", [(320, 20), (420, 3), (190, 5)])
 def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
     """The tile-array marginal likelihood's alternative pipelines -- round 3's kernels (fp32 tile arrays, block-column W), round 2's all-fp32 products, the
