@@ -1752,6 +1752,36 @@ def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, p
         assert dg_ev is None and db_ev is None and rel_l2(dx_ev.cpu().numpy(), xe.grad.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("b,c,per,d", [(2, 5, 30, 64), (1, 20, 21, 36), (2, 5, 12, 64)])
+def test_episode_loss_plain_cossim_from_features_matches_float64_autograd(cuda, b, c, per, d):
+    """The cossim kernel (no bn_out: F.normalize + Gram + MLL) through the same entry, small and large episodes: obj and d obj / d x vs float64 autograd."""
+    n = c * per
+    rng = np.random.default_rng(n + d)
+    x = _relu_like(rng, b, n, d)
+    xt = dev_t(x, cuda).requires_grad_(True)
+    raw_s = rng.normal(0.0, 0.5, c).astype(np.float32)
+    mean = rng.normal(0.0, 0.1, c).astype(np.float32)
+    rst, mt = dev_t(raw_s, cuda).requires_grad_(True), dev_t(mean, cuda).requires_grad_(True)
+    noise = torch.full((c,), 0.1, device=cuda)
+    cls = torch.arange(c, device=cuda).repeat_interleave(per)
+    y = torch.where(cls.unsqueeze(0) == torch.arange(c, device=cuda).unsqueeze(1), 1.0, -1.0).contiguous()
+    cw = torch.full((c,), -1.0 / (c * n), device=cuda)
+    out = ops.episode_loss_bn(xt, None, None, y, torch.nn.functional.softplus(rst), mt, noise, cw, use_bn=False)
+    obj, info = out[0], out[3]
+    assert int(info.abs().max().item()) == 0
+    obj.sum().backward()
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rs64, m64 = torch.tensor(raw_s, dtype=torch.float64, requires_grad=True), torch.tensor(mean, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for i in range(b):
+        loss_i, _, _ = T.classification_loss(x64[i], c, torch.nn.functional.softplus(rs64), m64, torch.full((c,), 0.1, dtype=torch.float64), normalize=True)
+        assert abs(obj[i].item() - loss_i.item()) < MLL_RTOL * abs(loss_i.item())
+        total = total + loss_i
+    total.backward()
+    assert rel_l2(xt.grad.cpu().numpy(), x64.grad.numpy()) < GRAD_RTOL
+    assert rel_l2(rst.grad.cpu().numpy(), rs64.grad.numpy()) < GRAD_RTOL and rel_l2(mt.grad.cpu().numpy(), m64.grad.numpy()) < GRAD_RTOL
+
+
 @pytest.mark.parametrize("kernel", ["rbf", "matern", "poli1", "poli2", "linear", "cossim"])
 def test_dkt_every_kernel_type_matches_float64_autograd(cuda, kernel):
     """configs.kernel_type values of the reference's ExactGPLayer (DKT.py:352-370): loss, gradients w.r.t. every
