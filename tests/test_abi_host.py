@@ -37,6 +37,22 @@ def test_argument_errors_do_not_launch(lib):
     assert lib.dkt_gram_f32(None, None, None, 1, 4, 4, 4, 0, None, None) == -1
     assert lib.dkt_gram_bwd_f32(None, None, None, 1, 4, 4, None, 0, None) == -1
     assert lib.dkt_predict_f32(None, None, None, None, None, None, 1, 1, 1, 1, None) == -1
+    # round 4: the front end of large episodes, the retired twin flag, the workspace of the per-class tile-array path
+    assert lib.dkt_affine_normalize_f32(None, None, None, 0, None, None, 1, 4, 4, None) == -1
+    assert lib.dkt_normalize_bn_bwd_f32(None, None, None, None, 0, None, None, None, None, None, None, None, 1, 4, 4, None) == -1
+    assert lib.dkt_mll_workspace_bytes(1, 20, 105) == 0 and lib.dkt_mll_workspace_bytes(1, 20, 420) > 0
+    # per-class base matrices need as many tiles again for E: a small batch reserves up to twice the shared-matrix workspace, a full chunk of 1024 episodes the same
+    assert lib.dkt_mll_workspace_bytes(2048, 20, 420) == lib.dkt_mll_workspace_bytes(1024, 20, 420)
+    assert lib.dkt_mll_workspace_bytes(1, 20, 420) >= 2 * 20 * (27 * 28 // 2) * 1024
+
+
+def test_per_class_path_sizes():
+    """Which (N, C) the one-launch per-class path serves (ops.mll_per_class_supported mirrors dkt_mll_f32 with DKT_MLL_E_PER_CLASS and dkt_class_kernel_bwd_f32)."""
+    ok = dkt_amd.ops.mll_per_class_supported
+    assert ok(105, 5) and ok(111, 5) and not ok(112, 5) and not ok(127, 5)
+    assert ok(128, 5) and ok(420, 20) and ok(447, 20) and not ok(448, 20)
+    assert ok(105, 32) and not ok(105, 33)
+    assert dkt_amd.ops.FUSED_EP_MAX_N == 128
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
