@@ -823,7 +823,7 @@ def test_jitter_retry_and_failure_info_blocked_path(cuda, n, path):
     assert np.allclose(g["jitter"].cpu().numpy(), jit)
 
 
-@pytest.mark.parametrize("n,c", [(128, 2), (143, 3), (144, 1), (257, 4), (320, 20), (447, 2), (460, 2)])      # 460: beyond the tile-array kernels -> blocked path
+@pytest.mark.parametrize("n,c", [(128, 2), (143, 3), (144, 1), (257, 4), (320, 20), (360, 2), (400, 3), (447, 2), (460, 2)])      # 460: beyond the tile-array kernels -> blocked path; 360 / 400 / 447: W as an 8-wave and a 4-wave launch
 def test_mll_tile_array_path_edges(cuda, n, c):
     """The tile-array kernels (N > 127) at the edges of their tiling -- the augmented row first / last in its tile (N = 128 / 143),
     a tile count that is not a multiple of the 4-tile blocks, the largest supported size -- against float64 and the blocked and
