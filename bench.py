@@ -86,11 +86,56 @@ def _physical_cores():
         return os.cpu_count() or 1
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of time the container's cgroup grants (cpu.max = "<quota> <period>" on cgroup v2, cfs_quota_us / cfs_period_us on v1);
+    None = unlimited.  psutil / os.cpu_count() see the HOST's cores and ignore this."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def _usable_cores():
+    """(cpu ids this process may run on -- one per PHYSICAL core where the SMT topology is readable --, facts dict).  The all-cores baseline
+    starts one pinned single-thread process per entry, capped by the cgroup quota."""
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(os.cpu_count() or 1))
+    seen, cpus = set(), []
+    for cpu in aff:                                   # one logical CPU per physical core (SMT siblings share the FP pipes)
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu).read().strip()
+        except OSError:
+            sib = str(cpu)
+        if sib not in seen:
+            seen.add(sib)
+            cpus.append(cpu)
+    quota = _cgroup_cpu_quota()
+    facts = {"host_cpus": os.cpu_count(), "affinity_cpus": len(aff), "physical_cores_in_affinity": len(cpus), "physical_cores_psutil": _physical_cores(),
+             "cgroup_cpu_quota": quota}
+    if quota is not None:
+        cpus = cpus[:max(1, int(quota))]
+    facts["cores_effective"] = len(cpus)
+    return cpus, facts
+
+
 def _cpu_worker(job):
     """One host process = one core: single-threaded torch, B = 1 sequential training episodes (the way the reference runs them) of the
     same synthetic workload, counted inside wall-clock windows that every worker shares (so the sum over the workers is a rate all
     cores sustained AT THE SAME TIME)."""
-    wid, n, d, n_way, raw_s, mean, t_open_v, ready_q, windows, window_s = job
+    wid, cpu, n, d, n_way, raw_s, mean, t_open_v, ready_q, windows, window_s = job
+    try:
+        os.sched_setaffinity(0, {cpu})               # one process per core, pinned (the parent exported OMP / MKL_NUM_THREADS = 1 before the spawn)
+    except (AttributeError, OSError):
+        pass
     import torch as _t
     _t.set_num_threads(1)
     from oracle import dkt_oracle_torch as T
@@ -131,14 +176,47 @@ def _cpu_worker_entry(job, q):
         q.put("worker %d failed: %r" % (job[0], e))
 
 
+class _QuietChildren:
+    """Children started inside this block inherit /dev/null as stdout / stderr, single-thread OpenMP / MKL pools and NO visible GPU: the
+    baseline processes are host-only, and their libdrm / HIP start-up chatter must never reach the bench's stdout (the JSON line is the
+    last -- and only -- line there) or fill the driver's stderr tail."""
+    ENV = {"OMP_NUM_THREADS": "1", "MKL_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": "",
+           "CUDA_VISIBLE_DEVICES": ""}
+
+    def __enter__(self):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        self.saved_env = {k: os.environ.get(k) for k in self.ENV}
+        os.environ.update(self.ENV)
+        self.fds = (os.dup(1), os.dup(2))
+        nul = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(nul, 1)
+        os.dup2(nul, 2)
+        os.close(nul)
+        return self
+
+    def __exit__(self, *exc):
+        os.dup2(self.fds[0], 1)
+        os.dup2(self.fds[1], 2)
+        os.close(self.fds[0])
+        os.close(self.fds[1])
+        for k, v in self.saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
 def cpu_baseline(z_cpu, n_way, raw_s, mean, warm=20, timed=200, repeats=5, windows=3, window_s=3.0):
     """BASELINE.md section 4 protocol: the oracle's fp32 GPyTorch-structured port (per-class loop, dense Cholesky, autograd
     backward), B = 1 sequential episodes as the reference runs them, on this box's host cores:
       * `1`: one process, one thread: `warm` untimed + `timed` timed episodes, median of up to `repeats` (<= 10 s);
-      * `all_cores`: P = physical cores independent single-thread PROCESSES, each running its own sequential episode stream; the
-        episodes all of them complete inside `windows` shared wall-clock windows of `window_s` seconds, summed (median window).  This is
-        the fair "all host cores" denominator: one B = 1 stream cannot use 128 threads (round 3 timed exactly that and got 22 x LESS
-        than one thread)."""
+      * `all_cores`: P = `cores_effective` independent single-thread PROCESSES (one per physical core of this process's affinity mask,
+        capped by the cgroup CPU quota; each pinned to its core, OMP / MKL_NUM_THREADS = 1), each running its own sequential episode
+        stream; the episodes all of them complete inside `windows` shared wall-clock windows of `window_s` seconds, summed (median
+        window).  This is the fair "all host cores" denominator: one B = 1 stream cannot use 128 threads (round 3 timed exactly that and
+        got 22 x LESS than one thread)."""
     from oracle import dkt_oracle_torch as T
 
     def episode(i):
@@ -146,7 +224,9 @@ def cpu_baseline(z_cpu, n_way, raw_s, mean, warm=20, timed=200, repeats=5, windo
         T.cpu_baseline_train_episode(zi, n_way, raw_s.clone().requires_grad_(True), mean.clone().requires_grad_(True))
 
     res = {}
-    phys = _physical_cores()
+    cpus, facts = _usable_cores()
+    res["cores"] = facts
+    nproc = len(cpus)
     torch.set_num_threads(1)
     for i in range(warm):
         episode(i)
@@ -159,34 +239,35 @@ def cpu_baseline(z_cpu, n_way, raw_s, mean, warm=20, timed=200, repeats=5, windo
         if time.perf_counter() - t_start > 10.0:          # bounded: the default run must stay within minutes
             break
     res["1"] = dict(episodes_per_s=round(statistics.median(rates), 2), repeats=len(rates), processes=1, threads_per_process=1)
-    torch.set_num_threads(min(phys, 8))
-    if phys > 1:
+    torch.set_num_threads(min(nproc, 8))
+    if nproc > 1:
         try:
             import multiprocessing as mp
             ctx = mp.get_context("spawn")
             n, d = int(z_cpu.shape[1]), int(z_cpu.shape[2])
             t_open_v = ctx.Value("d", 0.0)
             q, ready_q = ctx.Queue(), ctx.Queue()
-            jobs = [(w, n, d, n_way, raw_s.tolist(), mean.tolist(), t_open_v, ready_q, windows, window_s) for w in range(phys)]
+            jobs = [(w, cpus[w], n, d, n_way, raw_s.tolist(), mean.tolist(), t_open_v, ready_q, windows, window_s) for w in range(nproc)]
             procs = [ctx.Process(target=_cpu_worker_entry, args=(j, q), daemon=True) for j in jobs]
-            for pr in procs:
-                pr.start()
+            with _QuietChildren():
+                for pr in procs:
+                    pr.start()
             counts = []
             try:
                 t_lim = time.time() + 90.0                   # every worker imports torch first: the windows open when ALL of them are warm
                 nready = 0
-                while nready < phys and time.time() < t_lim:
+                while nready < nproc and time.time() < t_lim:
                     try:
                         ready_q.get(timeout=1.0)
                         nready += 1
                     except Exception:  # noqa: BLE001 -- queue.Empty
                         pass
-                if nready < phys:
+                if nready < nproc:
                     t_open_v.value = -1.0
-                    raise RuntimeError("only %d of %d baseline processes came up within 90 s" % (nready, phys))
+                    raise RuntimeError("only %d of %d baseline processes came up within 90 s" % (nready, nproc))
                 t_open_v.value = time.time() + 1.0
                 deadline = t_open_v.value + windows * window_s + 30.0
-                while len(counts) < phys:
+                while len(counts) < nproc:
                     counts.append(q.get(timeout=max(1.0, deadline - time.time())))
             finally:                                         # (never a hang: whatever has not answered by the deadline is killed)
                 for pr in procs:
@@ -196,9 +277,12 @@ def cpu_baseline(z_cpu, n_way, raw_s, mean, warm=20, timed=200, repeats=5, windo
             if any(isinstance(c, str) for c in counts):
                 raise RuntimeError([c for c in counts if isinstance(c, str)][0])
             per_window = [sum(c[wdw] for c in counts) / window_s for wdw in range(windows)]
-            res["all_cores"] = dict(episodes_per_s=round(statistics.median(per_window), 2), repeats=windows, processes=phys, threads_per_process=1,
+            allc = statistics.median(per_window)
+            res["all_cores"] = dict(episodes_per_s=round(allc, 2), repeats=windows, processes=nproc, threads_per_process=1,
                                     window_s=window_s, per_window=[round(v, 1) for v in per_window],
-                                    slowest_process_eps=round(min(statistics.median(c) for c in counts) / window_s, 2))
+                                    slowest_process_eps=round(min(statistics.median(c) for c in counts) / window_s, 2),
+                                    fastest_process_eps=round(max(statistics.median(c) for c in counts) / window_s, 2),
+                                    parallel_efficiency=round(allc / (nproc * res["1"]["episodes_per_s"]), 3))
         except Exception as e:  # noqa: BLE001 -- the baseline is a report, never a reason to lose the bench line
             res["all_cores"] = dict(error=repr(e)[:200])
     return res
@@ -528,12 +612,75 @@ def _default_batch(cfg):
     return 8192 if c * (s + q) <= 128 else 1024
 
 
+def _claim_stdout():
+    """The graded contract: ONE JSON line, the last (here: the only) thing on stdout.  Libraries write to fd 1 behind Python's back (RCCL's
+    version banner through C stdio, flushed at exit -- round 4 lost its bench record to exactly that; libdrm's amdgpu.ids complaint), so the
+    process keeps a private duplicate of the real stdout for the line and points fd 1 at stderr for everything else."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def _emit(real_fd, obj):
+    """Flush libc's and Python's buffers (whatever they hold goes to stderr now), then write the line to the real stdout in one write."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    data = (json.dumps(obj) + "\n").encode()
+    while data:
+        data = data[os.write(real_fd, data):]
+
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+              "algorithmic_flops_per_launch", "avg_launch_ms", "episodes_per_launch", "fabric_gbs", "fabric_frac", "executed_tflops", "executed_frac")
+
+
+def _compact_roof(r):
+    """The roofline object of the line: the contract's keys + what they were computed from; notes and the second roof stay in the detail file."""
+    if not r:
+        return r
+    out = {k: r[k] for k in _ROOF_KEYS if k in r}
+    if "other_roof" in r:
+        out["other_roof"] = {k: r["other_roof"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    if "executed_f16_mfma" in r:
+        out["executed_f16_mfma_frac"] = r["executed_f16_mfma"]["frac"]
+    return out
+
+
+def _dominant(kernels, roofs):
+    if not kernels:
+        return None
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    r = roofs.get(dom, {})
+    return {"kernel": dom, "ms": kernels[dom]["ms"], "bound": r.get("bound"), "frac": r.get("frac"),
+            "hbm_frac": round(kernels[dom]["gbs"] / HBM_PEAK_GBS, 4)}
+
+
+def _write_detail(detail):
+    """Everything the line used to carry (per-kernel rooflines of every config, notes, per-window baseline counts): gpurun_out/bench_detail.json,
+    merged back by gpurun; the judged copy is committed under profiles/r05/."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+            json.dump(detail, fh, indent=1)
+        return "gpurun_out/bench_detail.json"
+    except OSError as e:
+        return "not written: %r" % (e,)
+
+
 def run(args):
     import dkt_amd
     from dkt_amd import ops, distributed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    real_stdout = _claim_stdout()
     selftest = args.selftest_collective
     backend = "gloo" if selftest else "nccl"
     local = distributed.init_from_env(backend) if world > 1 else 0
@@ -558,11 +705,11 @@ def run(args):
         bucket.allreduce_mean()
         ok = ok and bucket.copies_last == 0 and bool(torch.allclose(backbone.grad, torch.full((n_backbone,), (world - 1) / 2.0)))
         ar_ms = _allreduce_ms(bucket, world, None)
-        if rank == 0:
-            print(json.dumps({"selftest": True, "n_gpus": distributed.world_size(), "bucket_floats": bucket.numel, "valid": ok,
-                              "collective": _collective_info(bucket, world, ar_ms, backend)}))
         if world > 1:
             torch.distributed.destroy_process_group()
+        if rank == 0:
+            _emit(real_stdout, {"selftest": True, "n_gpus": world, "bucket_floats": bucket.numel, "valid": ok,
+                                "collective": _collective_info(bucket, world, ar_ms, backend)})
         return
 
     if not torch.cuda.is_available():
@@ -692,30 +839,66 @@ def run(args):
             res = cpu_baseline(zs_cpu, c, raw_s.detach().cpu(), mean.detach().cpu())
             one = res["1"]["episodes_per_s"]
             allc = res.get("all_cores", {}).get("episodes_per_s")
-            out["cpu_baseline"] = {"value": one, "unit": "episodes/s", "cores": 1, "kind": "port",
-                                   "sample": "fp32 torch-CPU GPyTorch-structured port of the same training episode (per-class loop, "
-                                             "Cholesky, autograd backward), B=1 sequential, ONE thread: 20 warm-up + 200 timed "
-                                             "episodes (32 distinct synthetic Z), median of up to 5 repeats (<= 10 s); `by_threads.all_cores`: "
-                                             "one such single-thread process per physical core, episodes completed by all of them inside 3 shared "
-                                             "3-s windows, summed",
-                                   "by_threads": res, "all_cores_value": allc,
-                                   "cpu_model": _cpu_model(), "physical_cores": _physical_cores(), "host_cpus": os.cpu_count()}
-            out["speedup_vs_cpu"] = round(eps / one, 1)
-            if allc:
-                out["speedup_vs_cpu_all_cores"] = round(eps / allc, 1)
+            facts = res["cores"]
+            best, cores = (allc, res["all_cores"]["processes"]) if allc and allc > one else (one, 1)
+            out["cpu_baseline"] = {"value": best, "unit": "episodes/s", "cores": cores, "kind": "port",
+                                   "sample": "fp32 torch-CPU GPyTorch-structured port of the same training episode (per-class loop, Cholesky, autograd "
+                                             "backward), B=1 sequential streams over 32 distinct synthetic Z.  one_thread: 20 warm-up + 200 timed episodes, "
+                                             "median of up to 5 repeats (<= 10 s).  all_cores: one pinned single-thread process per effective core "
+                                             "(physical cores of the affinity mask, capped by the cgroup CPU quota), episodes all of them completed inside 3 "
+                                             "shared 3-s windows, summed.  value = the larger of the two",
+                                   "one_thread": one, "all_cores": allc, "cores_effective": facts["cores_effective"],
+                                   "parallel_efficiency": res.get("all_cores", {}).get("parallel_efficiency"),
+                                   "slowest_process_eps": res.get("all_cores", {}).get("slowest_process_eps"),
+                                   "cpu_model": _cpu_model(), "host_cpus": facts["host_cpus"], "affinity_cpus": facts["affinity_cpus"],
+                                   "physical_cores": facts["physical_cores_in_affinity"], "cgroup_cpu_quota": facts["cgroup_cpu_quota"],
+                                   "by_threads": res}
+            if "error" in res.get("all_cores", {}):
+                out["cpu_baseline"]["all_cores_error"] = res["all_cores"]["error"]
+            out["speedup_vs_cpu"] = round(eps / best, 1)                     # against the BEST host figure (all cores when that is the larger)
+            out["speedup_vs_cpu_1thread"] = round(eps / one, 1)
             gp = gpytorch_baseline(zs_cpu, c, raw_s.detach().cpu(), mean.detach().cpu())
             if gp is not None:
                 ref0 = O.train_episode(zs_cpu[0].double().numpy(), c, hyp)
                 gp["loss_abs_diff_vs_oracle_episode0"] = abs(gp.pop("loss_episode0") - float(ref0["loss"]))
-            out["gpytorch_reference"] = gp if gp is not None else "gpytorch not importable on this box (oracle parity stays unpinned, DESIGN.md section 2)"
-        if world == 1 and not args.no_rccl_selftest:
+            out["gpytorch_reference"] = gp if gp is not None else "not importable on this box (oracle parity stays unpinned, DESIGN.md section 2)"
+        if world == 1 and args.rccl_selftest:
             try:
                 out["rccl_selftest"] = _rccl_selftest(dev)
             except Exception as e:  # noqa: BLE001 -- a report, never a reason to lose the bench line
                 out["rccl_selftest"] = {"error": repr(e)[:300]}
-        print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        out["detail"] = _write_detail(out)
+        _emit(real_stdout, _line_of(out))
+
+
+def _line_of(out):
+    """The ONE line of the contract (< 8 KB): headline + roofline + roofline_gram_build + cpu_baseline, and one compact record per other config /
+    path.  The full per-kernel detail is the `detail` file."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data", "config", "timing", "valid", "deterministic")}
+    line["roofline"] = _compact_roof(out["roofline"])
+    line["roofline_gram_build"] = _compact_roof(out["roofline_gram_build"])
+    line["kernels_ms"] = {k: v["ms"] for k, v in out["kernels"].items()}
+    line["collective"] = {k: out["collective"][k] for k in ("bytes", "allreduce_ms", "backend", "ranks", "pack_copies_last_step")}
+    if "other_configs" in out:
+        line["other_configs"] = {cfg: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
+                                       "dominant": _dominant(o["kernels"], o["roofline_by_kernel"])} for cfg, o in out["other_configs"].items()}
+    for key in ("other_paths_cfg2", "other_paths_cfg4"):
+        if key in out:
+            line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
+                                "kernels_ms": o["kernels_ms"], **({"roofline": o["roofline"]} if "roofline" in o else {})}
+                         for name, o in out[key].items()}
+    if "test_time_forward" in out:
+        line["test_time_forward"] = {k: out["test_time_forward"][k] for k in ("value", "ms_per_step", "episodes_per_step")}
+    for k in ("mll_rel_err", "mll_rel_err_episodes", "speedup_vs_cpu", "speedup_vs_cpu_1thread", "gpytorch_reference", "rccl_selftest", "detail"):
+        if k in out:
+            line[k] = out[k]
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: v for k, v in out["cpu_baseline"].items() if k != "by_threads"}
+    return line
 
 
 def _rccl_selftest(dev):
@@ -831,8 +1014,9 @@ def main():
     ap.add_argument("--no-test-time", action="store_true",
                     help="skip the separately reported forward-only test-time episode (profiling runs: keeps the per-kernel "
                          "averages of the trace to the training step's launches)")
-    ap.add_argument("--no-rccl-selftest", action="store_true",
-                    help="skip the world-1 RCCL self-test of the gradient bucket (19.6 / 44.7 MB through GradBucket.allreduce_mean on this GPU)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="opt-in launch-plumbing check (NOT a measurement): a world-1 RCCL group on this GPU pushes the 19.6 / 44.7 MB gradient buckets "
+                         "through GradBucket.allreduce_mean (also: tools/rccl_sanity.py, tests -m gpu)")
     ap.add_argument("--selftest-collective", action="store_true",
                     help="CPU-only (gloo) check of the multi-rank plumbing: spawn, rendezvous, the flat gradient bucket; no kernels")
     args = ap.parse_args()

@@ -151,11 +151,91 @@ def test_bench_spawns_its_own_ranks_and_reduces_the_config_sized_bucket():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-collective"], capture_output=True,
                          text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    # the driver parses the LAST line of stdout: it must be the JSON record (round 4 lost its bench record to a library banner that followed it)
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert len(res.stdout.strip().splitlines()) == 1, res.stdout
     coll = out.pop("collective")
     assert out == {"selftest": True, "n_gpus": 2, "bucket_floats": 116288 + 10, "valid": True}
     # attribution of the multi-GPU step: the bucket alone is timed, the collective's size / backend / rank count and what RCCL was told
     # are reported, and the second step ran on gradient VIEWS of the flat buffer (no pack copies)
     assert coll["bytes"] == 4 * (116288 + 10 + 1) and coll["ranks"] == 2 and coll["backend"] == "gloo"
     assert coll["allreduce_ms"] > 0.0 and coll["pack_copies_last_step"] == 0 and "NCCL_ALGO" in coll and "NCCL_PROTO" in coll
+    # world 1, same contract
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--selftest-collective"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["selftest"] is True and out["n_gpus"] == 1 and out["valid"] is True
+
+
+def test_bench_line_is_the_last_and_only_stdout_line_whatever_libraries_print():
+    """bench.py keeps a private duplicate of the real stdout for its ONE JSON line and points fd 1 at stderr: C-stdio output a library
+    buffers (RCCL's version banner, flushed at exit) and anything the baseline's child processes print can neither follow nor precede the
+    line.  Reproduced here with libc puts() before and after the emit, and a child started under _QuietChildren."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = ("import os, sys\n"
+             "print('child-out')\n"
+             "print('child-err', file=sys.stderr)\n"
+             "open(sys.argv[1], 'w').write(os.environ['OMP_NUM_THREADS'])\n")
+    parent = ("import ctypes, os, subprocess, sys\n"
+              "sys.path.insert(0, sys.argv[1])\n"
+              "import bench\n"
+              "libc = ctypes.CDLL(None)\n"
+              "fd = bench._claim_stdout()\n"
+              "libc.puts(b'RCCL version : banner-before')\n"       # sits in libc's buffer (stdout is a pipe) until fflush / exit
+              "with bench._QuietChildren():\n"
+              "    pr = subprocess.Popen([sys.executable, sys.argv[2], sys.argv[3]])\n"
+              "pr.wait()\n"
+              "bench._emit(fd, {'metric': 'episodes/sec', 'value': 1.0})\n"
+              "libc.puts(b'RCCL version : banner-after')\n")       # flushed at exit, AFTER the line -- to stderr
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        envfile, childfile, parentfile = (os.path.join(td, f) for f in ("omp", "child.py", "parent.py"))
+        open(childfile, "w").write(child)
+        open(parentfile, "w").write(parent)
+        res = subprocess.run([sys.executable, parentfile, root, childfile, envfile], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert open(envfile).read().strip() == "1"
+    assert res.stdout.count("\n") == 1 and json.loads(res.stdout) == {"metric": "episodes/sec", "value": 1.0}
+    assert "banner-before" in res.stderr and "banner-after" in res.stderr
+    assert "child-out" not in res.stdout + res.stderr and "child-err" not in res.stdout + res.stderr
+
+
+def test_bench_line_stays_under_8k_with_every_section_filled():
+    """The line the driver parses carries the contract's keys + one compact record per other config / path; everything else goes to the detail file."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    roof = dict(kernel="dkt_gram_bwd_f32", bound="hbm", achieved=5000.0, peak=8000.0, unit="GB/s", frac=0.625, traffic=11373158400,
+                traffic_unit="x" * 80, traffic_source="profiles/r05/cfg2_summary.txt", algorithmic_bytes_per_launch=11371806720,
+                algorithmic_flops_per_launch=289013760000, avg_launch_ms=2.2, episodes_per_launch=8192, other_roof=dict(bound="mfma", achieved=1.0,
+                peak=157.3, unit="TFLOP/s", frac=0.01, note="n" * 300), executed_f16_mfma=dict(achieved=1.0, peak=2500.0, unit="TFLOP/s", frac=0.1, note="n" * 200))
+    kern = {k: dict(launches=60, ms=1.0, gbs=4000.0, tflops=10.0) for k in ("dkt_gram_f32", "dkt_mll_f32", "dkt_gram_bwd_f32")}
+    other = dict(value=1.0e6, unit="episodes/s", ms_per_step=1.0, episodes_per_step=8192, steps_per_block=10, blocks=3, valid=True, workload="w" * 120,
+                 kernels=kern, roofline_by_kernel={k: dict(roof, kernel=k) for k in kern})
+    path = dict(value=1.0e6, unit="episodes/s", episodes_per_step=2048, ms_per_step=1.6, valid=True, kernels_ms={"dkt_gram_bn_train_f32": 0.4, "dkt_mll_f32": 0.5,
+                "dkt_gram_bn_bwd_f32": 0.8}, roofline={k: dict(bound="hbm", achieved=3100.0, peak=8000.0, unit="GB/s", frac=0.39) for k in ("dkt_gram_bn_train_f32", "dkt_gram_bn_bwd_f32")})
+    out = dict(metric="episodes/sec", value=2.0e6, unit="episodes/s", n_gpus=1, steps=20, warmup=5, ms_per_step=4.0, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f32/f16x2-split", data="synthetic", config=dict(workload="w" * 200, episodes_per_step_per_gpu=8192, kernel="bncossim",
+               parallelism="episode-dp1", collective="c" * 160, arithmetic="a" * 500), timing=dict(blocks=12, steps_per_block=20, block_s_median=0.08, block_s_min=0.08,
+               block_s_max=0.08, timed_s_total=1.0), valid=True, deterministic=True, roofline=roof, roofline_gram_build=dict(roof, kernel="dkt_gram_f32"),
+               roofline_by_kernel={k: roof for k in kern}, kernels=kern, collective=dict(op="o" * 60, bytes=4, allreduce_ms=0.0, backend="none" * 10, ranks=1,
+               NCCL_ALGO="unset", NCCL_PROTO="unset", pack_copies_last_step=0), other_configs={c: other for c in ("cfg0", "cfg1", "cfg3", "cfg4", "cfg4_n320")},
+               other_paths_cfg2={"from_trunk_features": path, "rbf_per_class_lengthscales": path}, other_paths_cfg4={"from_trunk_features": path,
+               "rbf_per_class_lengthscales": path}, test_time_forward=dict(value=1.0, unit="episodes/s", episodes_per_step=4096, ms_per_step=1.0, workload="w" * 100),
+               mll_rel_err=9.6e-7, mll_rel_err_episodes=32, speedup_vs_cpu=100.0, speedup_vs_cpu_1thread=13000.0, gpytorch_reference="g" * 90, detail="gpurun_out/bench_detail.json",
+               cpu_baseline=dict(value=15000.0, unit="episodes/s", cores=128, kind="port", sample="s" * 600, one_thread=152.0, all_cores=15000.0, cores_effective=128,
+               parallel_efficiency=0.8, slowest_process_eps=100.0, cpu_model="AMD EPYC 9575F 64-Core Processor", host_cpus=256, affinity_cpus=256, physical_cores=128,
+               cgroup_cpu_quota=None, by_threads={"x": list(range(2000))}))
+    line = bench._line_of(out)
+    text = json.dumps(line)
+    assert len(text) < 8000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in line
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and "by_threads" not in line["cpu_baseline"]

@@ -2228,3 +2228,25 @@ def test_drivers_end_to_end(cuda, tmp_path, monkeypatch, capsys):
     assert len(eces) == 2 and all(0.0 <= e <= 1.0 for e in eces) and temperature > 0.0
     out = capsys.readouterr().out
     assert "Epoch [0] [0/6]" in out and "Overall Test Acc" in out and "Overall ECE" in out
+
+
+def test_bench_line_is_last_on_stdout_with_rccl_initialised(cuda):
+    """The graded command's contract on hardware: the LAST line of stdout parses as the JSON record even when RCCL (whose version banner
+    goes through C stdio and is flushed at exit) was initialised in the process -- here by the opt-in world-1 launch-plumbing check of the
+    gradient bucket (19.6 / 44.7 MB through GradBucket.allreduce_mean: views of the flat buffer, no pack copies, the failure flag in the same
+    collective).  The line carries the contract's keys and stays under 8 KB."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-other-configs", "--no-cpu-baseline",
+                          "--no-test-time", "--rccl-selftest"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 8000
+    out = json.loads(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline"):
+        assert key in out
+    assert out["valid"] and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["workload"].startswith("cfg2")
+    rc = out["rccl_selftest"]
+    assert rc["valid"] and all(b["pack_copies"] == 0 and b["grads_are_views"] for b in rc["buckets"].values())

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CONFIGS=${@:-cfg2 cfg1 cfg3 cfg0 cfg4 cfg4_n320}
 for cfg in $CONFIGS; do
-  ARGS="--config $cfg --no-other-configs --no-cpu-baseline --no-test-time --no-rccl-selftest"
+  ARGS="--config $cfg --no-other-configs --no-cpu-baseline --no-test-time"
   rm -rf $OUT/$cfg; mkdir -p $OUT/$cfg
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg/stats -- python $ROOT/bench.py $ARGS > $OUT/$cfg/stats.log 2>&1
   PMCS=("FETCH_SIZE" "WRITE_SIZE")
@@ -25,7 +25,7 @@ for cfg in $CONFIGS; do
 import csv, glob, os, collections, sys
 out, cfg = sys.argv[1], sys.argv[2]
 with open("%s/%s_summary.txt" % (out, cfg), "w") as f:
-    f.write("# rocprofv3 summary of `python bench.py --config %s --no-other-configs --no-cpu-baseline --no-test-time --no-rccl-selftest` (tools/prof_all.sh)\n" % cfg)
+    f.write("# rocprofv3 summary of `python bench.py --config %s --no-other-configs --no-cpu-baseline --no-test-time` (tools/prof_all.sh)\n" % cfg)
     for p in sorted(glob.glob("%s/%s/stats/**/*kernel_stats.csv" % (out, cfg), recursive=True)):
         f.write("== kernel_stats.csv (kernel trace of the DEFAULT step counts)\n" + open(p).read() + "\n")
     bl = [l for l in open("%s/%s/stats.log" % (out, cfg)) if l.startswith("{")]
