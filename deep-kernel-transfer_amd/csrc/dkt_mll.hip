@@ -33,12 +33,18 @@ inline bool mll_fits_lds(int N) { return (mll_vec_floats(N) + mll_mat_floats(N))
 template <bool GLOBAL>
 __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = a.b0 + blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int N = a.N, C = a.C, LD = a.LD, R = N + 1;
-    if (a.only_failed) {                       // fix-up pass of the blocked path: nothing to do for an episode without a failure
+    // DKT_MLL_E_PER_CLASS: a workgroup is ONE (episode, class) matrix -- its own E[b, c], its own W[b, c], a class "loop" of one entry
+    // (workgroup x = matrix b0 C + x); otherwise a workgroup is an episode (b0 + x) and walks its C classes
+    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    const size_t unit = epc ? (size_t)a.b0 * C + blockIdx.x : (size_t)a.b0 + blockIdx.x;
+    const int b = epc ? (int)(unit / (size_t)C) : (int)unit;
+    const int c_first = epc ? (int)(unit % (size_t)C) : 0, c_end = epc ? c_first + 1 : C;
+    if (a.only_failed) {                       // fix-up pass of the blocked / tile-array path: nothing to do for a unit without a failure
         bool need = false;
-        for (int c = 0; c < C; ++c) need = need || a.only_failed[(size_t)b * C + c] != 0;
+        for (int c = c_first; c < c_end; ++c) need = need || a.only_failed[(size_t)b * C + c] != 0;
         __syncthreads();                       // every thread has read the flags before anybody rewrites info[]
         if (!need) return;
     }
@@ -49,12 +55,12 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
     float* Mw = GLOBAL ? (a.ws + (size_t)blockIdx.x * R * LD) : (red + 32);
 #define MW(p, j) Mw[(p) * LD + (j)]
 
-    const float* Eb = a.E + (size_t)b * N * N;
+    const float* Eb = a.E + unit * N * N;
     const bool want_grad = (a.flags & DKT_MLL_WANT_GRAD) != 0;
     const bool want_chol = (a.flags & DKT_MLL_WANT_CHOL) != 0;
-    float* Wb = want_grad ? a.W + (size_t)b * N * N : nullptr;
+    float* Wb = want_grad ? a.W + unit * N * N : nullptr;
 
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_first; c < c_end; ++c) {
         const float svc = a.sv[c], mc = a.mean[c], nzc = a.noise[c];
         const float* yc = a.Y + (size_t)b * a.y_bstride + (size_t)c * N;
         int fail_at = 0;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
                     if (i == j) { dsv_part += mcv * e; tr_part += mcv; }
                     else dsv_part += 2.0f * mcv * e;
                     const float wv = coef * mcv;
-                    if (c == 0) {
+                    if (c == c_first) {
                         Wb[(size_t)i * N + j] = wv;
                         if (i != j) Wb[(size_t)j * N + i] = wv;
                     } else {
@@ -199,7 +205,8 @@ size_t dkt_mll_generic_global_floats(int count, int N) { return (size_t)count * 
 
 void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipStream_t st) {
     a.b0 = b0; a.ws = ws; a.LD = mll_ld(a.N);
-    hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(count), dim3(256), mll_vec_floats(a.N) * sizeof(float), st, a);
+    const int units = (a.flags & DKT_MLL_E_PER_CLASS) ? count * a.C : count;       // per-class base matrices: one workgroup (and one working matrix) per (episode, class)
+    hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(units), dim3(256), mll_vec_floats(a.N) * sizeof(float), st, a);
 }
 
 static int g_mll_env_read = 0, g_p2_guard = 1, g_force_f32mfma = 0;
@@ -245,24 +252,26 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     hipStream_t st = (hipStream_t)stream;
     if (flags & DKT_MLL_FORCE_REG) return DKT_ERR_BAD_ARG;     // (the register-sweep twin lives in libdkt_diag.so since round 4: dkt_diag_mll_reg_f32)
     if (flags & DKT_MLL_E_PER_CLASS) {
-        // one base matrix per class model: the wave-per-matrix form of the f16-split kernel (N <= 111) or the tile-array pipeline with one W per
-        // matrix (128 <= N <= 446); 112 <= N <= 127 is served by neither (the host falls back to one call per class there)
-        if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
-        if (N + 1 > 128) {
-            if (!dkt_mll_tiled_supports(N, flags)) return DKT_ERR_TOO_LARGE;
-            if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes(B, C, N)) return DKT_ERR_WORKSPACE;
-            return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
+        // one base matrix per class model: the f16-split kernels with one wave per matrix (N <= 127; jitter ladder inside the kernel) or the tile-array
+        // pipeline with one W per matrix (128 <= N <= 447; failed matrices redone with the jitter ladder by the generic kernel's fix-up launch);
+        // DKT_MLL_FORCE_GENERIC (the validation twin) and N > 447: the generic kernel, one workgroup per matrix
+        if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
+        if (!(flags & DKT_MLL_FORCE_GENERIC)) {
+            if (N + 1 > 128 && dkt_mll_tiled_supports(N, flags)) {
+                if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes(B, C, N)) return DKT_ERR_WORKSPACE;
+                return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
+            }
+            if (N + 1 <= 128) return dkt_mll_h2_launch(a, st) ? (hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH) : DKT_ERR_BAD_ARG;
         }
-        if (N + 1 > 112) return DKT_ERR_TOO_LARGE;
-        return dkt_mll_h2_launch(a, st) ? (hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH) : DKT_ERR_BAD_ARG;
     }
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags) && workspace &&
         workspace_bytes >= dkt_mll_tiled_workspace_bytes(B, C, N))
         return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
-    if (!(flags & DKT_MLL_FORCE_GENERIC) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))
+    if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_E_PER_CLASS)) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))
         return dkt_mll_big_launch(a, workspace, workspace_bytes, st);
+    const int upe = (flags & DKT_MLL_E_PER_CLASS) ? C : 1;                 // workgroups (= working matrices) per episode
     if (mll_fits_lds(N)) {
         const size_t lds = (mll_vec_floats(N) + mll_mat_floats(N)) * sizeof(float);
         if (lds > 48 * 1024) {
@@ -270,12 +279,14 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return DKT_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(mll_generic_kernel<false>, dim3(B), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(mll_generic_kernel<false>, dim3((unsigned)B * upe), dim3(256), lds, st, a);
     } else {
-        const size_t need = (size_t)B * mll_mat_floats(N) * sizeof(float);
-        if (!workspace || workspace_bytes < need) return DKT_ERR_WORKSPACE;
-        const size_t lds = mll_vec_floats(N) * sizeof(float);
-        hipLaunchKernelGGL(mll_generic_kernel<true>, dim3(B), dim3(256), lds, st, a);
+        // global working matrices: as many episodes per launch as the caller's workspace holds
+        const size_t per_ep = (size_t)upe * mll_mat_floats(N) * sizeof(float);
+        const size_t fit = workspace ? workspace_bytes / per_ep : 0;
+        if (fit < 1) return DKT_ERR_WORKSPACE;
+        const int cnt = fit < (size_t)B ? (int)fit : B;
+        for (int b0 = 0; b0 < B; b0 += cnt) dkt_mll_generic_global_launch(a, b0, (B - b0 < cnt) ? B - b0 : cnt, (float*)workspace, st);
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }

@@ -316,14 +316,19 @@ void mll_h2_kernel(MllArgs a, const int wpg) {
     const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave in the workgroup
     const int epl = wall / wpg;                                  // episode within the workgroup
     const int w = wall - epl * wpg;                              // wave within the episode
-    const int b = min(blockIdx.x * EPW + epl, a.B - 1);
-    const bool ep_ok = blockIdx.x * EPW + epl < a.B;             // an odd tail: the surplus waves only keep the barriers company
+    const int C = a.C;
+    // DKT_MLL_E_PER_CLASS (launched with wpg = 1: NT = 8, the sizes the wave-per-episode kernel does not serve): a "unit" is one (episode, class)
+    // matrix with its own E[b, c] and W[b, c] -- one round, class c_fix
+    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    const int nunits = epc ? a.B * C : a.B;
+    const int unit = min((int)blockIdx.x * EPW + epl, nunits - 1);
+    const int b = epc ? unit / C : unit, c_fix = epc ? unit % C : 0;
+    const bool ep_ok = blockIdx.x * EPW + epl < nunits;          // an odd tail: the surplus waves only keep the barriers company
     f32x4* const stage = stage_all[epl];
     f32x4* const myst = mst[wall];
     f32x4* const myys = yst[wall];
-    const int C = a.C;
     const float qnan = __int_as_float(0x7fc00000);
-    const int nrounds = (C + wpg - 1) / wpg;
+    const int nrounds = epc ? 1 : (C + wpg - 1) / wpg;
 
 #ifdef DKT_MFMA_CLOCKS
     unsigned long long clk[32] = {};
@@ -338,11 +343,11 @@ void mll_h2_kernel(MllArgs a, const int wpg) {
         ln.lane = lane; ln.g = g4 >> 2; ln.c = c16;
         ln.g0 = ln.g == 0; ln.g1 = ln.g == 1; ln.g2 = ln.g == 2;
         const int pN = N - 16 * (NT - 1);                        // local index of the augmented row / column in the last tile
-        const int c = round * wpg + w;
+        const int c = epc ? c_fix : round * wpg + w;
         const bool active = ep_ok && c < C;
         // ---- stage E[b] (the waves of the episode share the loads) and this wave's targets ----
         if (ep_ok) {
-            const brsrc Er = mk_rsrc(a.E + (size_t)b * N * N, (unsigned)(N * N * 4));
+            const brsrc Er = mk_rsrc(a.E + (size_t)unit * N * N, (unsigned)(N * N * 4));
             stage_e<NT, 0, 0>(stage, Er, N, pN, c16, g4, lane, w, wpg);
         }
         float r2 = 0.f;                                          // |y - m|^2, this lane's share
@@ -602,7 +607,7 @@ void mll_h2_kernel(MllArgs a, const int wpg) {
             c16 = tq & 15; g4 = (tq >> 2) & 12; lane = tq & 63;
             DKT_OPAQUE_S(N);
             const int pNs = N - 16 * (NT - 1);
-            const brsrc Wr = mk_rsrc(a.W + (size_t)b * N * N, (unsigned)(N * N * 4));
+            const brsrc Wr = mk_rsrc(a.W + (size_t)unit * N * N, (unsigned)(N * N * 4));
             const float* alf = reinterpret_cast<const float*>(myys);
             // this wave's scaled tile n = (i, j): coefK P_ij + (coefA alpha_row) alpha_col
             auto scaled_tile = [&](const f32x4 p, const int i, const int j) {
@@ -1290,10 +1295,11 @@ void launch_h2(const MllArgs& a, hipStream_t st) {
             return;
         }
     }
+    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;                  // (NT = 8 only: one wave per workgroup, one workgroup per matrix)
     const int rounds = (a.C + H2_MAX_WPG - 1) / H2_MAX_WPG;
-    const int wpg = (a.C + rounds - 1) / rounds;
+    const int wpg = epc ? 1 : (a.C + rounds - 1) / rounds;
     constexpr int EPW = h2_epw<NT>();
-    const dim3 grid((a.B + EPW - 1) / EPW), block(64 * wpg * EPW);
+    const dim3 grid(((epc ? a.B * a.C : a.B) + EPW - 1) / EPW), block(64 * wpg * EPW);
     if (g && wpg == 5) hipLaunchKernelGGL((mll_h2_kernel<NT, true, true>), grid, block, 0, st, a, wpg);
     else if (g) hipLaunchKernelGGL((mll_h2_kernel<NT, true, false>), grid, block, 0, st, a, wpg);
     else hipLaunchKernelGGL((mll_h2_kernel<NT, false, false>), grid, block, 0, st, a, wpg);
@@ -1307,7 +1313,6 @@ void dkt_mll_h2_reload_env() { g_h2e_minb = -1; }        // dkt_reload_env(): te
 bool dkt_mll_h2_launch(const MllArgs& a, hipStream_t st) {
     if (a.flags & DKT_MLL_WANT_CHOL) return false;
     const int nt = (a.N + 1 + 15) / 16;
-    if ((a.flags & DKT_MLL_E_PER_CLASS) && nt > 7) return false;
     switch (nt) {
         case 1: launch_h2<1>(a, st); return true;
         case 2: launch_h2<2>(a, st); return true;

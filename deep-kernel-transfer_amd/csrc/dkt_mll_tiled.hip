@@ -1515,7 +1515,7 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
 void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; g_tiled_wdma = -1; g_tiled_wnw = -1; }      // dkt_reload_env()
 
 bool dkt_mll_tiled_supports(int N, unsigned flags) {
-    return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 446: 4 x 7 register tiles per wave without spills
+    return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 447 (N + 1 <= 448 = 28 tiles): 4 x 7 register tiles per wave without spills
 }
 
 // DKT_MLL_E_PER_CLASS: the base matrices take as many tiles as the factors, so a pass covers half as many episodes (and at most 65535 matrices: the
@@ -1569,7 +1569,10 @@ int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hip
         // fix-up: episodes with a failed matrix are redone by the generic kernel with the jitter ladder (its global working
         // matrices reuse the tile region, which is dead by now)
 #if !defined(DKT_TILED_CLOCKS) && !defined(DKT_TILED_NOMATH)
-        if (!pc) {                          // (per-class base matrices: no jitter ladder, as in the wave-per-matrix kernel -- a failed matrix reports info != 0 and NaN)
+        {
+            // shared E: the generic kernel redoes the failed EPISODES (W[b] is a sum over the classes); per-class base matrices: the failed
+            // MATRICES, one workgroup each (E[b, c] -> W[b, c]).  Its (N + 1) x (N | 1) working matrices fit the dead tile + E-tile regions:
+            // 2 (NTT + 1) 256 = 256 NT^2 + 256 NT + 512 >= (N + 1)^2 floats per matrix (per-class), C (NTT + 1) 256 per episode (shared).
             MllArgs f = a;
             f.only_failed = a.info;
             dkt_mll_generic_global_launch(f, b0, bcnt, t.tiles, st);

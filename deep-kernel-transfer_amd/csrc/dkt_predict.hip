@@ -14,7 +14,7 @@ namespace {
 __global__ __launch_bounds__(256) void predict_mean_kernel(const float* __restrict__ Ex, const float* __restrict__ alpha,
                                                            const float* __restrict__ sv, const float* __restrict__ mean,
                                                            float* __restrict__ mu, int32_t* __restrict__ labels,
-                                                           int C, int M, int N) {
+                                                           int C, int M, int N, long ex_cstride) {
     extern __shared__ __attribute__((aligned(16))) float s_alpha[];
     const int b = blockIdx.y;
     const float* ab = alpha + (size_t)b * C * N;
@@ -22,11 +22,13 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const float* __restri
     __syncthreads();
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= M) return;
-    const float* ex = Ex + ((size_t)b * M + qi) * N;
+    // ex_cstride = 0: one base cross kernel shared by the class models (Ex [B,M,N]); M N: one per class model (Ex [B,C,M,N])
+    const float* ex0 = Ex + ((size_t)b * (ex_cstride ? C : 1) * M + qi) * N;
     float best = 0.f;
     int best_c = 0;
     for (int c = 0; c < C; ++c) {
         const float* ac = s_alpha + c * N;
+        const float* ex = ex0 + (size_t)c * ex_cstride;
         float s = 0.f;
         for (int n = 0; n < N; ++n) s += ex[n] * ac[n];
         const float v = mean[c] + sv[c] * s;
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(64) void predict_var_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int dkt_predict_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
-                               float* mu, int32_t* labels, int B, int C, int M, int N, void* stream) {
+static int predict_mean_launch(const float* Ex, const float* alpha, const float* sv, const float* mean,
+                               float* mu, int32_t* labels, int B, int C, int M, int N, long ex_cstride, void* stream) {
     if (!Ex || !alpha || !sv || !mean || !mu || B <= 0 || C <= 0 || M <= 0 || N <= 0) return DKT_ERR_BAD_ARG;
     const size_t lds = (size_t)C * N * sizeof(float);
     if (lds > 150 * 1024 || B > 65535) return DKT_ERR_TOO_LARGE;
@@ -71,8 +73,18 @@ extern "C" int dkt_predict_f32(const float* Ex, const float* alpha, const float*
         hipFuncSetAttribute((const void*)predict_mean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DKT_ERR_LAUNCH;
     hipLaunchKernelGGL(predict_mean_kernel, dim3((M + 255) / 256, B), dim3(256), lds, (hipStream_t)stream, Ex,
-                       alpha, sv, mean, mu, labels, C, M, N);
+                       alpha, sv, mean, mu, labels, C, M, N, ex_cstride);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
+extern "C" int dkt_predict_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
+                               float* mu, int32_t* labels, int B, int C, int M, int N, void* stream) {
+    return predict_mean_launch(Ex, alpha, sv, mean, mu, labels, B, C, M, N, 0, stream);
+}
+
+extern "C" int dkt_predict_per_class_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
+                                         float* mu, int32_t* labels, int B, int C, int M, int N, void* stream) {
+    return predict_mean_launch(Ex, alpha, sv, mean, mu, labels, B, C, M, N, (long)M * N, stream);
 }
 
 extern "C" int dkt_predict_var_f32(const float* Ex, const float* exx, const float* L, const float* sv,

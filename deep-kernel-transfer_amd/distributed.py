@@ -104,8 +104,16 @@ class GradBucket:
             off += p.numel()
 
     def zero_(self) -> None:
+        """Clear every gradient of the bucket's parameters: one fill of the flat buffer for the views, and an in-place zero_() for any
+        gradient that is NOT a view of it (a non-fp32 parameter, which attach() leaves alone, or a gradient somebody replaced) -- those
+        would otherwise accumulate over the steps, since the training loop no longer calls optimizer.zero_grad() in this mode."""
         if self._flat is not None:
             self._flat.zero_()
+        off = 0
+        for p in self.params:
+            if p.grad is not None and (self._flat is None or not self._is_view(p, off)):
+                p.grad.zero_()
+            off += p.numel()
 
     def allreduce_mean(self, flag: Optional[torch.Tensor] = None, force: bool = False) -> Optional[torch.Tensor]:
         """Average the gradients over the ranks.  `flag` (a 0-dim / 1-element tensor, e.g. max |info| of the step) rides in the

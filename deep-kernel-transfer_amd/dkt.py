@@ -309,7 +309,7 @@ class DKT(MetaTemplate):
                 obj, logp, alpha, info, jit, e = ops.episode_loss_class_kernel(zb, y, sv, mean, noise, cw, self.kernel_type, ls, off,
                                                                                self.jitter0, self.max_tries)
             else:
-                # 112 <= N <= 127, N > 446 or more than 32 classes: one Gram + one single-model launch per class
+                # N > 447 or more than 32 classes: one Gram + one single-model launch per class
                 objs, logps, alphas, infos, jits = [], [], [], [], []
                 for k in range(c):
                     e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
@@ -342,9 +342,7 @@ class DKT(MetaTemplate):
             e_c = ops.kernel_matrix_per_class(zc, None, self.kernel_type, ls, off)               # [1, C, N, N]
             out = ops.mll(e_c, y, sv, mean, noise, jitter0=self.jitter0, max_tries=self.max_tries)
             ex_c = ops.kernel_matrix_per_class(zs, zc, self.kernel_type, ls, off)                # [1, C, M, N]
-            mu = mean.reshape(1, -1, 1) + sv.reshape(1, -1, 1) * torch.einsum("bcmn,bcn->bcm", ex_c, out["alpha"])
-            cidx = torch.arange(mu.shape[1], device=mu.device, dtype=torch.int32).view(1, -1, 1)
-            labels = torch.where(mu == mu.max(1, keepdim=True).values, cidx, torch.full_like(cidx, mu.shape[1])).min(1).values
+            mu, labels = ops.predict(ex_c, out["alpha"], sv, mean)                               # dkt_predict_per_class_f32
             return mu[0], labels[0], {key: out[key] for key in ("logp", "alpha", "jitter", "info")}
         mus, outs = [], []
         for k in range(y.shape[-2]):

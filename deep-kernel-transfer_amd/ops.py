@@ -269,40 +269,43 @@ def sqdist_bwd(w: torch.Tensor, u: torch.Tensor, lengthscale: torch.Tensor):
 
 
 def _matern25(u: torch.Tensor) -> torch.Tensor:
-    """MaternKernel(nu=2.5) from the scaled squared distance (gpytorch clamps d2 >= 1e-30 before the sqrt)."""
+    """MaternKernel(nu=2.5) from the scaled squared distance (gpytorch clamps d2 >= 1e-30 before the sqrt).  Differentiable torch form, used by
+    base_matrix() under autograd; the no-autograd paths take the HIP class map (dkt_class_kernel_f32)."""
     r = torch.sqrt(5.0 * u.clamp_min(1e-30))
     return (1.0 + r + r * r / 3.0) * torch.exp(-r)
 
 
 def kernel_matrix(a: torch.Tensor, bm: Optional[torch.Tensor], kernel: str, lengthscale: Optional[torch.Tensor] = None,
                   offset: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Base kernel matrix k(a, bm) (no autograd): all kernel types of ExactGPLayer (reference DKT.py:352-370)."""
+    """Base kernel matrix k(a, bm) of ONE model (no autograd): all kernel types of ExactGPLayer (reference DKT.py:352-370).  Matern / polynomial:
+    the contraction (dkt_gram_f32) + the element-wise class map of a one-class "episode" (dkt_class_kernel_f32)."""
     if kernel in LINEAR_KINDS:
         return gram(a, bm, KERNEL_LINEAR)
     if kernel in RBF_KINDS:
         return gram(a, bm, KERNEL_RBF, lengthscale)
-    if kernel in MATERN_KINDS:
-        return _matern25(gram(a, bm, KERNEL_SQDIST, lengthscale))
-    if kernel in POLY_KINDS:
-        return (gram(a, bm, KERNEL_LINEAR) + offset.reshape(())) ** POLY_KINDS[kernel]
+    if kernel in MATERN_KINDS or kernel in POLY_KINDS:
+        return kernel_matrix_per_class(a, bm, kernel, None if lengthscale is None else lengthscale.reshape(-1)[:1],
+                                       None if offset is None else offset.reshape(-1)[:1])[:, 0]
     raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
 
 
 def predict(ex: torch.Tensor, alpha: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, want_labels: bool = True):
-    """mu[b,c,q] = mean[c] + sv[c] sum_n ex[b,q,n] alpha[b,c,n]; labels[b,q] = argmax_c mu."""
-    ex = _req(ex, "ex", 3)
+    """mu[b,c,q] = mean[c] + sv[c] sum_n ex[b,(c,)q,n] alpha[b,c,n]; labels[b,q] = argmax_c mu (first maximum wins).
+    ex: [B,M,N] (one base cross kernel shared by the class models: dkt_predict_f32) or [B,C,M,N] (one per class model: dkt_predict_per_class_f32)."""
+    per_class = ex.dim() == 4
+    ex = _req(ex, "ex", 4 if per_class else 3)
     alpha = _req(alpha, "alpha", 3)
-    b_, m, n = ex.shape
+    b_, m, n = ex.shape[0], ex.shape[-2], ex.shape[-1]
     c_ = alpha.shape[1]
-    if alpha.shape[0] != b_ or alpha.shape[2] != n:
-        raise RuntimeError("predict: alpha must be [B,C,N]")
+    if alpha.shape[0] != b_ or alpha.shape[2] != n or (per_class and ex.shape[1] != c_):
+        raise RuntimeError("predict: alpha must be [B,C,N] (and a per-class ex [B,C,M,N])")
     sv = _req(sv.reshape(-1), "sv", 1)
     mean = _req(mean.reshape(-1), "mean", 1)
     mu = torch.empty((b_, c_, m), device=ex.device, dtype=torch.float32)
     labels = torch.empty((b_, m), device=ex.device, dtype=torch.int32) if want_labels else None
     lib = _lib.load()
-    _lib.check(lib.dkt_predict_f32(_p(ex), _p(alpha), _p(sv), _p(mean), _p(mu), _p(labels), b_, c_, m, n, _stream()),
-               "dkt_predict_f32")
+    fn, name = (lib.dkt_predict_per_class_f32, "dkt_predict_per_class_f32") if per_class else (lib.dkt_predict_f32, "dkt_predict_f32")
+    _lib.check(fn(_p(ex), _p(alpha), _p(sv), _p(mean), _p(mu), _p(labels), b_, c_, m, n, _stream()), name)
     return mu, labels
 
 
@@ -531,9 +534,10 @@ class _EpisodeLossClassKernelFn(torch.autograd.Function):
 
 
 def mll_per_class_supported(n: int, c: int) -> bool:
-    """Sizes the one-launch per-class path serves (DKT_MLL_E_PER_CLASS of dkt_mll_f32: N <= 111 wave-per-matrix kernel, 128 <= N <= 446
-    tile-array pipeline; dkt_class_kernel_bwd_f32: C <= 32).  Outside them the host runs one single-model call per class."""
-    return c <= 32 and (n + 1 <= 112 or 128 < n + 1 <= 448)
+    """Sizes the one-launch per-class path serves: dkt_mll_f32 with DKT_MLL_E_PER_CLASS takes every N in one call (N <= 127 one wave per matrix,
+    128 <= N <= 447 the tile-array pipeline; both with the jitter ladder); beyond N = 447 its one-launch kernel is the generic one, and the host
+    prefers one single-model call per class there (the blocked path serves those).  dkt_class_kernel_bwd_f32: C <= 32."""
+    return c <= 32 and n + 1 <= 448
 
 
 def episode_loss_class_kernel(z, y, sv, mean, noise, cls_weight, kernel: str, lengthscale=None, offset=None,

@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define DKT_ABI_VERSION 3 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
-                             3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32 */
+#define DKT_ABI_VERSION 4 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
+                             3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32; \
+                             4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
+                                          + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_episode_lowrank_f32 (linear kernels, D < N) */
 
 /* status codes */
 #define DKT_OK 0
@@ -63,6 +65,11 @@ extern "C" {
 #define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */
 
 int dkt_abi_version(void);
+
+/* The library reads its measurement / validation switches (environment variables) once, at the first call that needs
+ * them; a host that changed one inside a running process (tests, A/B tools) calls this to have them re-read.  No effect on results of the
+ * default configuration.  (Exported since round 2; declared here since ABI 4.) */
+void dkt_reload_env(void);
 
 /* Device query used by the host side to fail loudly on a non-gfx950 box: returns the number of
  * compute units of the current HIP device (>0) or <0 on error. */
@@ -105,9 +112,11 @@ size_t dkt_mll_workspace_bytes(int B, int C, int N);
  *   flags & DKT_MLL_E_PER_CLASS : the class models do not share a base matrix (rbf / matern / polynomial kernels with per-class
  *        lengthscale / offset: one ExactGPLayer per class, methods/DKT.py:63-66, 352-365):  K_c = sv[c] * E[b,c] + noise[c] * I with
  *        E:[B,C,N,N], and W:[B,C,N,N] holds W[b,c] = cls_weight[c] * sv[c] * M_c = d obj_b / d E[b,c] per class.  One launch for all
- *        classes; N <= 111 (wave-per-matrix kernel) or 128 <= N <= 447 (tile-array pipeline, one W per matrix; needs the workspace of
- *        dkt_mll_workspace_bytes; no jitter retry: a failed matrix reports info != 0 and NaN); without DKT_MLL_WANT_CHOL /
- *        DKT_MLL_FORCE_* (DKT_ERR_TOO_LARGE for 112 <= N <= 127 and N > 447 / DKT_ERR_BAD_ARG otherwise).
+ *        classes, every N: N <= 127 the f16-split kernels with one wave per matrix (jitter ladder inside the kernel), 128 <= N <= 447 the
+ *        tile-array pipeline with one W per matrix (needs the workspace of dkt_mll_workspace_bytes; a matrix that fails attempt 0 is redone
+ *        with psd_safe_cholesky's jitter ladder by a fix-up launch of the generic kernel, as for a shared E), N > 447 the generic kernel
+ *        (one workgroup per matrix; working matrices in the workspace).  DKT_MLL_FORCE_GENERIC selects the generic kernel for any N (the
+ *        validation twin); DKT_MLL_WANT_CHOL and the other DKT_MLL_FORCE_* do not combine with it (DKT_ERR_BAD_ARG).
  * Range contract of the default kernels for N <= 127 (scaled 2-way f16 splits on the f16 matrix pipe, 22 significand bits, fp32
  *   accumulate): every K_c = sv[c] E + noise[c] I must satisfy |K_ij| <= max_i K_ii, which every positive semi-definite E (any Gram /
  *   RBF / Matern / polynomial base matrix) does.  An E that violates it (not PSD, or user-supplied with off-diagonals beyond the
@@ -162,6 +171,14 @@ int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* lengthscale,
  */
 int dkt_predict_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
                     float* mu, int32_t* labels, int B, int C, int M, int N, void* stream);
+
+/*
+ * dkt_predict_per_class_f32 -- the same with one base cross kernel PER CLASS MODEL (rbf / matern / polynomial kernels whose class models own
+ *   their lengthscale / offset, methods/DKT.py:63-66, 352-365):  Ex:[B,C,M,N],  mu[b,c,q] = mean[c] + sv[c] * sum_n Ex[b,c,q,n] alpha[b,c,n].
+ * Replaces: the same reference lines as dkt_predict_f32 for kernel_type in {rbf, matern, poli1, poli2}.
+ */
+int dkt_predict_per_class_f32(const float* Ex, const float* alpha, const float* sv, const float* mean,
+                              float* mu, int32_t* labels, int B, int C, int M, int N, void* stream);
 
 /*
  * dkt_predict_var_f32 -- diagonal of the predictive covariance (what confidence_region() reads,

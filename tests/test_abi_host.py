@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
         assert hasattr(lib, name), "libdkt_hip.so lacks %s" % name
         assert name in dkt_amd._lib.SIGNATURES, "no ctypes signature for %s" % name
     assert sorted(dkt_amd._lib.SIGNATURES) == declared
-    assert lib.dkt_abi_version() == 3
+    assert lib.dkt_abi_version() == 4
     # pure host queries (no GPU needed)
     assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # register resident
     # N > 127: blocked path, per (episode, class) four N x N matrices + two vectors + bookkeeping
@@ -49,7 +49,7 @@ def test_argument_errors_do_not_launch(lib):
 def test_per_class_path_sizes():
     """Which (N, C) the one-launch per-class path serves (ops.mll_per_class_supported mirrors dkt_mll_f32 with DKT_MLL_E_PER_CLASS and dkt_class_kernel_bwd_f32)."""
     ok = dkt_amd.ops.mll_per_class_supported
-    assert ok(105, 5) and ok(111, 5) and not ok(112, 5) and not ok(127, 5)
+    assert ok(105, 5) and ok(111, 5) and ok(112, 5) and ok(127, 5)
     assert ok(128, 5) and ok(420, 20) and ok(447, 20) and not ok(448, 20)
     assert ok(105, 32) and not ok(105, 33)
     assert dkt_amd.ops.FUSED_EP_MAX_N == 128

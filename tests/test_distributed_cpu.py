@@ -239,3 +239,21 @@ def test_bench_line_stays_under_8k_with_every_section_filled():
         assert key in line
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and "by_threads" not in line["cpu_baseline"]
+
+
+def test_grad_bucket_zero_clears_gradients_that_are_not_views():
+    """GradBucket.zero_() replaces optimizer.zero_grad() in distributed mode: besides the flat fp32 buffer it must clear the gradients that are
+    not views of it (attach() leaves non-fp32 parameters alone), or they would accumulate from step to step."""
+    import torch
+    import dkt_amd
+    p32 = torch.nn.Parameter(torch.zeros(5))
+    p64 = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))
+    bkt = dkt_amd.distributed.GradBucket([p32, p64])
+    bkt.attach()
+    (p32.sum() * 2.0 + p64.sum() * 3.0).backward()
+    assert p32.grad.data_ptr() == bkt._flat.data_ptr() and p64.grad is not None and float(p64.grad[0]) == 3.0
+    bkt.zero_()
+    assert float(p32.grad.abs().sum()) == 0.0 and float(p64.grad.abs().sum()) == 0.0
+    assert p32.grad.data_ptr() == bkt._flat.data_ptr()          # still a view
+    (p32.sum() + p64.sum()).backward()
+    assert float(p32.grad[0]) == 1.0 and float(p64.grad[0]) == 1.0

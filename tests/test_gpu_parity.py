@@ -32,7 +32,7 @@ def rel_l2(a, b):
 
 
 def test_loaded_native_library(cuda, lib):
-    assert lib.dkt_abi_version() == 3
+    assert lib.dkt_abi_version() == 4
     assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -532,7 +532,7 @@ def test_mll_wave_per_episode_class_weights_signs_and_units(cuda, monkeypatch, g
             assert rel_l2(out["dnoise"][i].cpu().numpy(), dnoise) < GRAD_RTOL
 
 
-@pytest.mark.parametrize("c,per,d", [(5, 21, 48), (5, 5, 32), (3, 37, 24), (7, 9, 16)])
+@pytest.mark.parametrize("c,per,d", [(5, 21, 48), (5, 5, 32), (3, 37, 24), (7, 9, 16), (5, 24, 16), (1, 127, 8), (2, 56, 8)])      # the last three: 112 <= N <= 127 (round 5)
 def test_mll_per_class_base_matrices_one_launch(cuda, c, per, d):
     """DKT_MLL_E_PER_CLASS: rbf / matern / polynomial class models own their lengthscale / offset (one ExactGPLayer per class,
     methods/DKT.py:63-66, 352-365), so K_c = sv_c E[b, c] + noise_c I with a base matrix per class.  One launch over all (episode,
@@ -573,19 +573,23 @@ def test_mll_per_class_base_matrices_one_launch(cuda, c, per, d):
                           dev_t(noise[k:k + 1], cuda), want_grad=True, cls_weight=dev_t(cw[k:k + 1], cuda))
             assert rel_l2(out["w"][i, k].cpu().numpy(), one["w"][0].cpu().numpy()) < 2e-5
             assert abs(out["logp"][i, k].item() - one["logp"][0, 0].item()) < 5e-6 * abs(one["logp"][0, 0].item())
-    # argument errors: the Cholesky output and the validation twins do not exist for per-class matrices; N > 111 is too large
+    # the generic kernel with one workgroup per matrix (DKT_MLL_FORCE_GENERIC: the validation twin of the per-class paths, ABI 4)
+    gen = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_generic=True)
+    assert int(gen["info"].abs().max().item()) == 0
+    assert rel_l2(out["logp"].cpu().numpy(), gen["logp"].cpu().numpy()) < 2e-6 and rel_l2(out["w"].cpu().numpy(), gen["w"].cpu().numpy()) < 5e-5
+    assert rel_l2(out["alpha"].cpu().numpy(), gen["alpha"].cpu().numpy()) < 5e-5
+    # argument errors: the Cholesky output and the other validation twins do not exist for per-class matrices
     with pytest.raises(RuntimeError):
         ops.mll(*args, want_chol=True)
     with pytest.raises(RuntimeError):
         ops.mll(*args, want_grad=True, force_reg=True)
-    big = torch.eye(120, device=cuda).repeat(1, 2, 1, 1)
     with pytest.raises(RuntimeError):
-        ops.mll(big, torch.ones(2, 120, device=cuda), torch.ones(2, device=cuda), torch.zeros(2, device=cuda), torch.full((2,), 0.1, device=cuda), want_grad=True)
+        ops.mll(*args, want_grad=True, force_blocked=True)
 
 
 @pytest.mark.parametrize("b,c,per,chunk", [(2, 5, 30, None), (2, 20, 21, None), (5, 3, 100, "4"), (1, 2, 223, None)])
 def test_mll_per_class_base_matrices_tile_array(cuda, monkeypatch, b, c, per, chunk):
-    """DKT_MLL_E_PER_CLASS at 128 <= N <= 446: the tile-array pipeline with one base matrix, one factor and one W per (episode, class) matrix
+    """DKT_MLL_E_PER_CLASS at 128 <= N <= 447: the tile-array pipeline with one base matrix, one factor and one W per (episode, class) matrix
     (the 20-way rbf / matern / polynomial episode of 420 rows in ONE dkt_mll_f32 call).  Against the float64 oracle per matrix, the single-model
     launch (shared-matrix pipeline with C = 1) it replaces, and the forward-only call (fp32 kernels); `chunk`: several passes over the workspace
     (a per-class pass covers half the episodes of a shared-matrix pass) with a ragged last pass."""
@@ -821,6 +825,105 @@ def test_jitter_retry_and_failure_info_blocked_path(cuda, n, path):
     g = ops.mll(dev_t(e_all, cuda), dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda), force_generic=True)
     assert (g["info"].cpu().numpy() != 0).tolist() == (info != 0).tolist()
     assert np.allclose(g["jitter"].cpu().numpy(), jit)
+
+
+@pytest.mark.parametrize("n", [8, 60, 105, 120, 150, 257])
+def test_jitter_retry_and_failure_info_per_class_base_matrices(cuda, n):
+    """DKT_MLL_E_PER_CLASS (rbf / matern / polynomial class models, methods/DKT.py:63-66, 352-365): every (episode, class) matrix retries on its
+    own with psd_safe_cholesky's ladder (total jitter 1e-6, 1e-5, 1e-4), on every path -- N <= 111 the wave-per-episode-form kernel, 112 <= N <= 127
+    the wave-per-matrix kernel (NT = 8), 128 <= N <= 447 the tile-array pipeline + the generic kernel's per-MATRIX fix-up launch (round 5; until
+    round 4 that pipeline reported info != 0 + NaN where the reference retries).  A call mixes healthy matrices, matrices that need 1e-5 / 1e-4
+    and a hopeless one; the healthy ones must come out exactly as in a call without the bad ones; the generic twin must agree."""
+    rng = np.random.default_rng(n)
+    qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    base = np.linspace(0.3, 2.0, n)
+    mins = np.array([[0.2, -0.1 - 5e-6, 0.25], [-0.1 - 5e-5, -0.5, 0.3]])          # [B = 2, C = 3]: smallest eigenvalue of E[b, c]; noise 0.1, sv 1
+    e_all = np.empty((2, 3, n, n))
+    for i in range(2):
+        for k in range(3):
+            ev = base.copy()
+            ev[n // 2] = mins[i, k]
+            e = qm @ np.diag(ev) @ qm.T
+            e_all[i, k] = 0.5 * (e + e.T)
+    y = np.sign(rng.standard_normal((3, n)))
+    sv, mean, noise, cw = np.ones(3), np.array([0.0, 0.1, -0.1]), np.full(3, 0.1), np.array([1.0, -0.5, 2.0])
+    args = (dev_t(y, cuda), dev_t(sv, cuda), dev_t(mean, cuda), dev_t(noise, cuda))
+    o = ops.mll(dev_t(e_all, cuda), *args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    fwd = ops.mll(dev_t(e_all, cuda), *args)
+    gen = ops.mll(dev_t(e_all, cuda), *args, want_grad=True, cls_weight=dev_t(cw, cuda), force_generic=True)
+    for res in (o, fwd, gen):
+        info, jit = res["info"].cpu().numpy(), res["jitter"].cpu().numpy()
+        assert (info[[0, 0, 0, 1, 1], [0, 1, 2, 0, 2]] == 0).all() and info[1, 1] > 0
+        assert jit[0, 0] == 0.0 and jit[0, 2] == 0.0 and jit[1, 2] == 0.0
+        assert np.isclose(jit[0, 1], 1e-5, rtol=1e-5) and np.isclose(jit[1, 0], 1e-4, rtol=1e-5)
+        assert torch.isnan(res["logp"][1, 1]) and torch.isnan(res["alpha"][1, 1]).all()
+    assert torch.isnan(o["w"][1, 1]).all() and torch.isnan(o["dsv"][1, 1])
+    for i in range(2):
+        for k in range(3):
+            if (i, k) == (1, 1):
+                continue
+            _, jref = O.psd_safe_cholesky(sv[k] * e_all[i, k] + noise[k] * np.eye(n), 1e-6, 3)
+            jit = o["jitter"][i, k].item()
+            assert np.isclose(jit, jref, rtol=1e-5, atol=0.0)
+            kk = sv[k] * e_all[i, k] + (noise[k] + jref) * np.eye(n)
+            l = np.linalg.cholesky(kk)
+            r = y[k] - mean[k]
+            alpha = np.linalg.solve(kk, r)
+            logp = -0.5 * r @ alpha - np.log(np.diag(l)).sum() - 0.5 * n * np.log(2 * np.pi)
+            tol = 1e-4 if jref == 0.0 else 5e-2            # jittered matrices are ill-conditioned (min eigenvalue ~5e-5): the accuracy fp32 allows there
+            assert abs(o["logp"][i, k].item() - logp) < tol * abs(logp)
+            if jref == 0.0:
+                assert rel_l2(o["alpha"][i, k].cpu().numpy(), alpha) < 5e-4
+                w_ref = cw[k] * sv[k] * 0.5 * (np.outer(alpha, alpha) - np.linalg.inv(kk))
+                assert rel_l2(o["w"][i, k].cpu().numpy(), w_ref) < GRAD_RTOL
+    # the healthy matrices are bitwise what a call made of healthy matrices only gives (a retry / the fix-up launch touches nothing else)
+    e_ok = e_all.copy()
+    e_ok[0, 1] = e_all[0, 0]
+    e_ok[1, 0] = e_all[0, 2]
+    e_ok[1, 1] = e_all[1, 2]
+    ok = ops.mll(dev_t(e_ok, cuda), *args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    for (i, k) in ((0, 0), (0, 2), (1, 2)):
+        assert torch.equal(ok["logp"][i, k], o["logp"][i, k]) and torch.equal(ok["w"][i, k], o["w"][i, k]) and torch.equal(ok["alpha"][i, k], o["alpha"][i, k])
+
+
+def test_predict_per_class_cross_kernels(cuda):
+    """dkt_predict_per_class_f32 (ABI 4): posterior means + first-maximum labels from one base cross kernel PER class model (Ex [B,C,M,N]) -- what
+    DKT._posterior runs for rbf / matern / polynomial kernels (methods/DKT.py:264-270, 352-365) instead of a torch einsum."""
+    rng = np.random.default_rng(5)
+    b, c, m, n = 3, 4, 37, 29
+    ex = rng.standard_normal((b, c, m, n))
+    alpha = rng.standard_normal((b, c, n))
+    sv, mean = np.linspace(0.5, 2.0, c), 0.1 * rng.standard_normal(c)
+    ex[0, :, 5] = 0.0
+    mean_t = mean.copy()
+    mu, labels = ops.predict(dev_t(ex, cuda), dev_t(alpha, cuda), dev_t(sv, cuda), dev_t(mean_t, cuda))
+    ref = mean[None, :, None] + sv[None, :, None] * np.einsum("bcmn,bcn->bcm", ex.astype(np.float32).astype(np.float64), alpha.astype(np.float32).astype(np.float64))
+    assert np.abs(mu.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    assert (labels.cpu().numpy() == mu.cpu().numpy().argmax(1)).all()
+    # ties: equal means -> the first class wins (np.argmax)
+    mu2, lab2 = ops.predict(torch.zeros(1, c, 3, n, device=cuda), dev_t(alpha[:1], cuda), dev_t(sv, cuda), torch.zeros(c, device=cuda))
+    assert (lab2.cpu().numpy() == 0).all() and float(mu2.abs().max()) == 0.0
+    # the shared-kernel entry on the same data repeated per class agrees bitwise
+    ex_sh = rng.standard_normal((b, m, n))
+    mu_a, lab_a = ops.predict(dev_t(ex_sh, cuda), dev_t(alpha, cuda), dev_t(sv, cuda), dev_t(mean, cuda))
+    mu_b, lab_b = ops.predict(dev_t(np.repeat(ex_sh[:, None], c, 1), cuda), dev_t(alpha, cuda), dev_t(sv, cuda), dev_t(mean, cuda))
+    assert torch.equal(mu_a, mu_b) and torch.equal(lab_a, lab_b)
+
+
+@pytest.mark.parametrize("kernel", ["matern", "poli1", "poli2", "rbf", "linear"])
+def test_kernel_matrix_single_model_maps_on_the_device(cuda, kernel):
+    """ops.kernel_matrix (one model: the regression head, the per-class host loop beyond N = 447 / C = 32): Matern-2.5 and the polynomial kernels
+    through dkt_gram_f32 + dkt_class_kernel_f32 (until round 4 the element-wise maps ran in torch), symmetric and cross."""
+    rng = np.random.default_rng(9)
+    a, bm = rng.standard_normal((2, 23, 12)) * 0.5, rng.standard_normal((2, 17, 12)) * 0.5
+    ls, off = np.array([1.3]), np.array([0.7])
+    ref = {"matern": lambda x, y_: O.gram_matern25(x, y_, ls[0]), "rbf": lambda x, y_: O.gram_rbf(x, y_, ls[0]), "linear": lambda x, y_: O.gram_linear(x, y_),
+           "poli1": lambda x, y_: O.gram_poly(x, y_, 1, off[0]), "poli2": lambda x, y_: O.gram_poly(x, y_, 2, off[0])}[kernel]
+    for second in (None, bm):
+        e = ops.kernel_matrix(dev_t(a, cuda), None if second is None else dev_t(second, cuda), kernel, dev_t(ls, cuda), dev_t(off, cuda)).cpu().numpy()
+        for i in range(2):
+            r = ref(a[i].astype(np.float32).astype(np.float64), None if second is None else second[i].astype(np.float32).astype(np.float64))
+            assert e[i].shape == r.shape and np.abs(e[i] - r).max() < 2e-5 * max(1.0, np.abs(r).max())
 
 
 @pytest.mark.parametrize("n,c", [(128, 2), (143, 3), (144, 1), (257, 4), (320, 20), (360, 2), (400, 3), (447, 2), (460, 2)])      # 460: beyond the tile-array kernels -> blocked path; 360 / 400 / 447: W as an 8-wave and a 4-wave launch
