@@ -461,9 +461,19 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
     return res
 
 
-def _algorithmic(cfg, n, d, c, unit_rows):
+def _algorithmic(cfg, n, d, c, unit_rows, lowrank=False):
     """Algorithmic bytes / flops per EPISODE, per ABI kernel of the step; `exec_f16`: the f16 MFMA flops the split Gram
-    kernels actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split)."""
+    kernels actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split).
+    `lowrank` (D <= 64 < N, ops.lowrank_applies): the step is dkt_lowrank_gram_f32 -> dkt_mll_f32 on the 64 x 64 models -> dkt_lowrank_finish_f32 ->
+    dkt_lowrank_bwd_f32; its bytes are what those calls have to move (Z three times, dZ once, the 64 x 64 matrices A and W' once each way)."""
+    if lowrank:
+        dp = 64
+        return {
+            "dkt_lowrank_gram_f32": dict(bytes=4 * (n * d + dp * dp + c * dp), flops=2 * n * d * (d + c), exec_f16=None),
+            "dkt_mll_f32": dict(bytes=4 * (2 * dp * dp + 3 * c * dp), flops=c * (dp ** 3 // 3 + 2 * dp * dp + dp ** 3), exec_f16=None),
+            "dkt_lowrank_finish_f32": dict(bytes=4 * (n * d + c * dp + 2 * c * n), flops=2 * n * d * c, exec_f16=None),
+            "dkt_lowrank_bwd_f32": dict(bytes=4 * (2 * n * d + dp * dp + c * n + c * dp), flops=2 * n * d * (d + c), exec_f16=None),
+        }
     nt16 = (n + 15) // 16
     nprod = 3 if unit_rows else 6
     alg = {
@@ -545,9 +555,13 @@ def _traffic_table():
 
 
 def _kernel_report(cfg, m, unit_rows, traffic):
+    from dkt_amd import ops
     st, b = m["st"], m["b"]
     n, d, c = st["n"], st["d"], st["c"]
-    alg = _algorithmic(cfg, n, d, c, unit_rows)
+    lowrank = st["kernel"] == "bncossim" and ops.lowrank_applies(n, d, c)
+    alg = _algorithmic(cfg, n, d, c, unit_rows, lowrank)
+    if lowrank:
+        n = ops.LOWRANK_DP                    # the size the marginal-likelihood kernel runs at (for its executed-flop count below)
     kernels = {}
     for name, (cnt, ms) in m["ktimes"].items():
         a = alg[name]

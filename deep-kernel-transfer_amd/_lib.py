@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
 SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_small.hip", "dkt_classkernel.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_h2.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_predict.hip",
-           "dkt_spectral.hip", "dkt_frontend.hip", "dkt_frontend_big.hip"]
+           "dkt_spectral.hip", "dkt_frontend.hip", "dkt_frontend_big.hip", "dkt_lowrank.hip"]
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
 DIAG_SOURCES = ["dkt_diag.hip", "dkt_mll_reg_twin.hip"]
 DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
@@ -54,6 +54,10 @@ SIGNATURES = {
     "dkt_class_kernel_f32": (_c_i, [_c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_class_kernel_bwd_nsplit": (_c_i, [_c_i, _c_i]),
     "dkt_class_kernel_bwd_f32": (_c_i, [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_lowrank_supported": (_c_i, [_c_i, _c_i, _c_i]),
+    "dkt_lowrank_gram_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_lowrank_finish_f32": (_c_i, [_c_p, _c_p, ctypes.c_long] + [_c_p] * 14 + [_c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_lowrank_bwd_f32": (_c_i, [_c_p] * 6 + [_c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
 }

@@ -286,7 +286,7 @@ class DKT(MetaTemplate):
             z_train = None
             if want_z:
                 z_train = (xb[0].detach() * a.reshape(-1, xb.shape[2])[0] + s.reshape(-1, xb.shape[2])[0]) * rnorm[0].unsqueeze(1)
-        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
+        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=None if e is None else e.detach())
         return obj.mean(), aux, z_train
 
     def _episode_loss(self, z, y):
@@ -318,7 +318,7 @@ class DKT(MetaTemplate):
                     objs.append(o); logps.append(lp); alphas.append(al); infos.append(inf); jits.append(jt)
                 obj = torch.stack(objs, 0).sum(0)
                 logp, alpha, info, jit = torch.cat(logps, 1), torch.cat(alphas, 1), torch.cat(infos, 1), torch.cat(jits, 1)
-        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=e.detach())
+        aux = dict(logp=logp, alpha=alpha, info=info, jitter=jit, e=None if e is None else e.detach())
         return obj.mean(), aux
 
     def _posterior(self, z_cond, y, z_star, e_cond=None):
@@ -534,7 +534,7 @@ class DKT(MetaTemplate):
                 continue
             if nb > 1 and not fused:
                 z_train = z_train[0].detach()
-            e_first = aux["e"][:1]
+            e_first = None if aux["e"] is None else aux["e"][:1]      # (None: the episode ran in feature space, ops.lowrank_applies)
             with torch.no_grad():
                 self.model.eval()
                 self.likelihood.eval()

@@ -656,6 +656,88 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+# Linear kernels in FEATURE space: D <= 64 < N (Conv4S / Omniglot; include/dkt_abi.h "dkt_lowrank_*", csrc/dkt_lowrank.hip)
+# ------------------------------------------------------------------------------------------------------
+LOWRANK_DP = 64               # DKT_LOWRANK_DP
+LOWRANK_MIN_N = 80            # below it the D x D problem (5 x 5 tiles) is no smaller than the N x N one
+
+
+def lowrank_applies(n: int, d: int, c: int) -> bool:
+    """Shapes the feature-space path serves AND wins on: K_c = sv_c Z Z^T + noise_c I with D <= 64, D % 4 == 0, C <= 32 and an episode of at least
+    80 rows (the Omniglot / Conv4S episodes: D = 64, N = 105 or 420).  DKT_LOWRANK=0 keeps every call on the N x N kernels (the twin the tests compare)."""
+    return (os.environ.get("DKT_LOWRANK", "1") != "0" and d <= LOWRANK_DP and d % 4 == 0 and c <= 32 and n >= LOWRANK_MIN_N)
+
+
+class _EpisodeLossLowRankFn(torch.autograd.Function):
+    """Training episode of the linear / cossim / bncossim kernel in feature space (D <= 64 < N):
+       forward : A = Z^T Z, P = Z^T (Y - m) (dkt_lowrank_gram_f32) -> the D x D model K'_c = sv_c A + noise_c I through dkt_mll_f32 (jitter ladder and all)
+                 -> alpha, logp, hyper-parameter gradients, V (dkt_lowrank_finish_f32)
+       backward: dZ = g_b (V^T T + 2 Z W') (dkt_lowrank_bwd_f32).
+    Neither E[B,N,N] nor W[B,N,N] is ever formed (reference lines replaced: methods/DKT.py:375-378, 161-163)."""
+
+    @staticmethod
+    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+        z = _req(z, "z", 3)
+        b_, n, d = z.shape
+        y = _req(y, "y")
+        if y.dim() == 2:
+            c_, y_bstride = y.shape[0], 0
+        elif y.dim() == 3 and y.shape[0] == b_:
+            c_, y_bstride = y.shape[1], y.shape[1] * n
+        else:
+            raise RuntimeError("episode_loss_linear: y must be [C,N] or [B,C,N]")
+        sv_ = _req(sv.reshape(-1), "sv", 1)
+        mean_ = _req(mean.reshape(-1), "mean", 1)
+        noise_ = _req(noise.reshape(-1), "noise", 1)
+        cw_ = _req(cls_weight.reshape(-1), "cls_weight", 1)
+        dev = z.device
+        lib = _lib.load()
+        a = torch.empty((b_, LOWRANK_DP, LOWRANK_DP), device=dev, dtype=torch.float32)
+        p = torch.empty((b_, c_, LOWRANK_DP), device=dev, dtype=torch.float32)
+        with _timed("dkt_lowrank_gram_f32"):
+            st = lib.dkt_lowrank_gram_f32(_p(z), _p(y), y_bstride, _p(mean_), _p(a), _p(p), b_, c_, n, d, _stream())
+        _lib.check(st, "dkt_lowrank_gram_f32")
+        zero = torch.zeros(c_, device=dev, dtype=torch.float32)
+        out = mll(a, p, sv_, zero, noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
+        logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
+        v = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
+        dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        with _timed("dkt_lowrank_finish_f32"):
+            st = lib.dkt_lowrank_finish_f32(_p(z), _p(y), y_bstride, _p(sv_), _p(mean_), _p(noise_), _p(cw_), _p(out["alpha"]), _p(out["logp"]), _p(out["dnoise"]),
+                                            _p(out["jitter"]), _p(logp), _p(alpha), _p(v), _p(dsv), _p(dmean), _p(dnoise), b_, c_, n, d, _stream())
+        _lib.check(st, "dkt_lowrank_finish_f32")
+        obj = (logp * cw_.reshape(1, -1)).sum(1)
+        ctx.save_for_backward(z, v, out["alpha"], out["w"], dsv, dmean, dnoise, cw_)
+        ctx.shapes = (sv.shape, mean.shape, noise.shape)
+        ctx.mark_non_differentiable(logp, alpha, out["info"], out["jitter"])
+        ctx.set_materialize_grads(False)
+        return obj, logp, alpha, out["info"], out["jitter"]
+
+    @staticmethod
+    def backward(ctx, gobj, *_unused):
+        if gobj is None:
+            return (None,) * 8
+        z, v, t, wd, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        gobj = gobj.contiguous()
+        dz = None
+        if ctx.needs_input_grad[0]:
+            b_, n, d = z.shape
+            dz = torch.empty_like(z)
+            lib = _lib.load()
+            with _timed("dkt_lowrank_bwd_f32"):
+                st = lib.dkt_lowrank_bwd_f32(_p(z), _p(v), _p(t), _p(wd), _p(_req(gobj.reshape(-1), "gobj", 1)), _p(dz), b_, v.shape[1], n, d, _stream())
+            _lib.check(st, "dkt_lowrank_bwd_f32")
+        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
+        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
+        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
+        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        return dz, None, gsv, gmean, gnoise, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
 # BNCosSim front half fused into the Gram build (reference methods/DKT.py:48,141-142,375-378)
 # ------------------------------------------------------------------------------------------------------
 def bn_stats(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-5) -> dict:
@@ -882,5 +964,8 @@ def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float =
 def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3, unit_rows: bool = False):
     """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E).
     unit_rows=True: z went through F.normalize (cossim / bncossim), |z| <= 1 element-wise -- the Gram kernels may then use
-    the scaled 2-way f16 split (same fp32-level accuracy, less staging work)."""
+    the scaled 2-way f16 split (same fp32-level accuracy, less staging work).
+    D <= 64 < N (lowrank_applies: the Conv4S / Omniglot episodes): the episode runs in feature space and E is None -- no N x N matrix exists."""
+    if z.dim() == 3 and lowrank_applies(z.shape[1], z.shape[2], y.shape[-2]):
+        return _EpisodeLossLowRankFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries) + (None,)
     return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows)

@@ -31,7 +31,7 @@ extern "C" {
 #define DKT_ABI_VERSION 4 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
                              3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32; \
                              4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
-                                          + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_episode_lowrank_f32 (linear kernels, D < N) */
+                                          + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_lowrank_* (linear kernels in feature space, D <= 64 < N) */
 
 /* status codes */
 #define DKT_OK 0
@@ -187,6 +187,36 @@ int dkt_predict_per_class_f32(const float* Ex, const float* alpha, const float* 
  */
 int dkt_predict_var_f32(const float* Ex, const float* exx, const float* L, const float* sv,
                         const float* noise, float* var, int B, int C, int M, int N, void* stream);
+
+/*
+ * ---- Linear kernels in FEATURE space: D <= 64 < N (round 5; Conv4S / Omniglot, backbone.py:287-310, train.py:85-93, 132) ----------
+ * K_c = sv_c Z Z^T + noise_c I has rank D + the noise floor: with A = Z^T Z, p_c = Z^T (y_c - m_c) and K'_c = sv_c A + noise_c I (D x D)
+ *     log det K_c = (N - D) log noise_c + log det K'_c,   alpha_c = K_c^-1 r_c = (r_c - sv_c Z t_c) / noise_c,   t_c = K'_c^-1 p_c = Z^T alpha_c,
+ *     d obj / d Z = sum_c cw_c sv_c (alpha_c - Z t_c) t_c^T + 2 Z W',   W' = 0.5 sum_c cw_c sv_c (t_c t_c^T - K'_c^-1),
+ * and K'_c is the matrix family dkt_mll_f32 factorises (base matrix A, targets p_c, zero mean, the same sv / noise / cls_weight / jitter ladder --
+ * the jitter lands on noise_c exactly as psd_safe_cholesky's does on K_c's diagonal).  The training episode is then
+ *     dkt_lowrank_gram_f32 -> dkt_mll_f32 (B, C, N' = DKT_LOWRANK_DP, y_bstride = C * DKT_LOWRANK_DP, mean = 0, DKT_MLL_WANT_GRAD) -> dkt_lowrank_finish_f32
+ *     backward: dkt_lowrank_bwd_f32
+ * and neither E[B,N,N] nor W[B,N,N] exists.  Z:[B,N,D] row-major, D % 4 == 0, D <= DKT_LOWRANK_DP (zero-padded to it), C <= 32, any N
+ * (DKT_ERR_TOO_LARGE otherwise: the caller takes dkt_gram_f32 / dkt_mll_f32 / dkt_gram_bwd_f32).  A:[B,DP,DP], P and T:[B,C,DP], Wd:[B,DP,DP] hold the
+ * D x D problem in a FIXED PERMUTED feature order (index 16 q + m stands for column 4 m + q), private to these four calls.
+ * Replaces, for these shapes: methods/DKT.py:375-378 (LinearKernel), 161-163 (marginal likelihood + backward) -- the same lines as the three
+ * N x N kernels; results identical to them to fp32 accuracy (tests: both paths against the float64 oracle, and against each other).
+ */
+#define DKT_LOWRANK_DP 64
+int dkt_lowrank_supported(int C, int N, int D); /* 1 when the three calls below accept (C, N, D) */
+/* A[b] = Zp^T Zp (exactly symmetric), P[b,c,:] = Zp^T (Y[b,c,:] - mean[c]);  Y: [*,C,N], episode b reads Y + b * y_bstride */
+int dkt_lowrank_gram_f32(const float* Z, const float* Y, long y_bstride, const float* mean, float* A, float* P,
+                         int B, int C, int N, int D, void* stream);
+/* from the D x D call's outputs T = alpha', logp_d = logp', dnoise_d = dnoise', jitter_used:  logp[B,C], alpha[B,C,N], dsv / dmean / dnoise [B,C]
+ * (the conventions of dkt_mll_f32) and V[B,C,N] = cls_weight_c sv_c (alpha_c - Z t_c) for the backward.  A failed class (NaN in T / logp_d) comes out NaN. */
+int dkt_lowrank_finish_f32(const float* Z, const float* Y, long y_bstride, const float* sv, const float* mean, const float* noise,
+                           const float* cls_weight, const float* T, const float* logp_d, const float* dnoise_d, const float* jitter_used,
+                           float* logp, float* alpha, float* V, float* dsv, float* dmean, float* dnoise,
+                           int B, int C, int N, int D, void* stream);
+/* dZ[b] = ep_scale[b] * (V[b]^T T[b] + 2 Z[b] Wd[b])  (= ep_scale[b] (W + W^T) Z of the N x N formulation);  ep_scale: [B] device or NULL (= 1) */
+int dkt_lowrank_bwd_f32(const float* Z, const float* V, const float* T, const float* Wd, const float* ep_scale, float* dZ,
+                        int B, int C, int N, int D, void* stream);
 
 /*
  * ---- BNCosSim front half fused into the Gram build ------------------------------------
