@@ -45,6 +45,9 @@ CONFIGS = {
     # RBF kernel, learned noise (DKT_regression.py:45-64, qmul_loader.py); bucket = Conv3 (24 408) + 4 GP hyper-parameters
     "cfg0": (1, 5, 14, 2916, "QMUL regression, Conv3 features, RBF kernel: one task = one (19, 2916) GP", 24408),
     "cfg1": (5, 5, 16, 64, "Omniglot 5-way 5-shot, Conv4S features", 112064),
+    # Omniglot 20-way (train.py:85-93 forces Conv4S: D = 64; --train_n_way 20: N = 420): not a BASELINE config; the shape where the feature-space path
+    # (ops.lowrank_applies: twenty 64 x 64 models instead of twenty 420 x 420 ones) matters most
+    "cfg1_20way": (20, 5, 16, 64, "Omniglot 20-way 5-shot, Conv4S features (N = 420, D = 64: feature-space path)", 112064),
     "cfg2": (5, 5, 16, 1600, "CUB 5-way 5-shot, Conv4 features (headline)", 116288),
     "cfg3": (5, 1, 16, 512, "miniImagenet 5-way 1-shot, ResNet10 features", 4906816),
     # 20-way: N = 420 is what train_loop builds (20 x (5 + 16)); BASELINE.json quotes a 320 x 320 Gram
@@ -623,7 +626,7 @@ def _kernel_report(cfg, m, unit_rows, traffic):
 
 def _default_batch(cfg):
     c, s, q = CONFIGS[cfg][:3]
-    return 8192 if c * (s + q) <= 128 else 1024
+    return 8192 if c * (s + q) <= 128 else (2048 if cfg == "cfg1_20way" else 1024)
 
 
 def _claim_stdout():

@@ -56,7 +56,8 @@ SIGNATURES = {
     "dkt_class_kernel_bwd_f32": (_c_i, [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "dkt_lowrank_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "dkt_lowrank_gram_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
-    "dkt_lowrank_finish_f32": (_c_i, [_c_p, _c_p, ctypes.c_long] + [_c_p] * 14 + [_c_i, _c_i, _c_i, _c_i, _c_p]),
+    "dkt_lowrank_noise_floor_f32": (_c_i, [_c_p, _c_p, _c_p, _c_f, _c_i, _c_p, _c_p, _c_i, _c_p]),
+    "dkt_lowrank_finish_f32": (_c_i, [_c_p, _c_p, ctypes.c_long] + [_c_p] * 17 + [_c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_lowrank_bwd_f32": (_c_i, [_c_p] * 6 + [_c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "dkt_smk_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),

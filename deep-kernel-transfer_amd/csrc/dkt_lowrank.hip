@@ -35,6 +35,7 @@ using namespace dkt_mfma;
 
 constexpr int LR_DP = DKT_LOWRANK_DP;          // 64: feature dimension of the D x D problem (include/dkt_abi.h)
 constexpr float LR_LOG_2PI = 1.8378770664093454836f;
+constexpr int LR_U = 8;                         // K steps (of 4 rows) whose loads a wave of the Gram kernel keeps in flight
 
 __device__ __forceinline__ f32x4 mfma4(const float a, const float b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -58,29 +59,52 @@ __global__ __launch_bounds__(64) void lowrank_gram_kernel(const float* __restric
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) accp[ct][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K steps of 4 rows, LR_U at a time: the loads of the next chunk are issued before the products of the current one (a wave keeps
+    // LR_U 1-KB row groups of Z in flight; without it the kernel ran one load per wave at a time: 0.098 -> ms per 8192 cfg1 episodes)
     const int nks = (N + 3) >> 2;
-#pragma unroll 4
-    for (int ks = 0; ks < nks; ++ks) {
-        const int row = 4 * ks + kk;
-        const f32x4 v = bload4(Zr, (col_ok && row < N) ? (row * D + 4 * m) * 4 : OOB, 0);
-        float r[NCT];
+    f32x4 va[LR_U];
+    float ra[LR_U][NCT];
+    auto load_chunk = [&](const int k0, f32x4 (&v)[LR_U], float (&r)[LR_U][NCT]) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int n = 16 * ct + m;
-            const bool ok = n < C && row < N;
-            const float yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, ok ? (n * N + row) * 4 : OOB, 0, 0));
-            r[ct] = ok ? yv - mc[ct] : 0.f;
+        for (int u = 0; u < LR_U; ++u) {
+            const int row = 4 * (k0 + u) + kk;
+            v[u] = bload4(Zr, (col_ok && row < N) ? (row * D + 4 * m) * 4 : OOB, 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                // unconditional load (an out-of-range offset returns 0) and no select on the value: written as `ok ? y - m : 0` hipcc branches around
+                // the load and waits vmcnt(0) inside the branch, which serialises every Z load of the chunk behind it (measured: 0.13 vs ms).  Rows
+                // beyond N multiply zero rows of Z, classes beyond C have mc = 0 and are never stored.
+                const int n = 16 * ct + m;
+                const int off = (n < C && row < N) ? (n * N + row) * 4 : OOB;
+                r[u][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, off, 0, 0)) - mc[ct];
+            }
         }
-        int t = 0;
+    };
+    load_chunk(0, va, ra);
+    for (int k0 = 0; k0 < nks; k0 += LR_U) {
+        f32x4 vb[LR_U];
+        float rb[LR_U][NCT];
+        load_chunk(k0 + LR_U, vb, rb);                              // (beyond the episode: every offset is out of range, the loads return 0)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int u = 0; u < LR_U; ++u) {
+            const f32x4 v = va[u];
+            int t = 0;
 #pragma unroll
-            for (int q2 = q; q2 < 4; ++q2, ++t) acc[t] = mfma4(v[q], v[q2], acc[t]);
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int q2 = q; q2 < 4; ++q2, ++t) acc[t] = mfma4(v[q], v[q2], acc[t]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accp[ct][q] = mfma4(v[q], ra[u][ct], accp[ct][q]);
         }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int u = 0; u < LR_U; ++u) {
+            va[u] = vb[u];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) accp[ct][q] = mfma4(v[q], r[ct], accp[ct][q]);
+            for (int ct = 0; ct < NCT; ++ct) ra[u][ct] = rb[u][ct];
+        }
     }
     // accumulator lane (g, c), register r: element [16 q + 4 g + r][16 q2 + c]
     const int g4 = 4 * kk, c = m;
@@ -121,6 +145,8 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
                                                             const float* __restrict__ noise, const float* __restrict__ cls_weight,
                                                             const float* __restrict__ T, const float* __restrict__ logp_d,
                                                             const float* __restrict__ dnoise_d, const float* __restrict__ jitter,
+                                                            const float* __restrict__ pre_jitter, float* __restrict__ jitter_total,
+                                                            float* __restrict__ obj,
                                                             float* __restrict__ logp, float* __restrict__ alpha, float* __restrict__ V,
                                                             float* __restrict__ dsv, float* __restrict__ dmean, float* __restrict__ dnoise,
                                                             const int C, const int N, const int D) {
@@ -156,19 +182,35 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) sa[ct] = saa[ct] = srr[ct] = srs[ct] = 0.f;
     const int nrt = (N + 15) >> 4;
-    for (int rt = 0; rt < nrt; ++rt) {
-        const int arow = 16 * rt + m;                          // a operand: row of this lane
-        f32x4 za[4];
+    auto load_rows = [&](const int rt, f32x4 (&z4)[4]) {       // a operand: row 16 rt + m of this lane, columns 16 j + 4 kk .. + 3
+        const int arow = 16 * rt + m;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) za[j] = bload4(Zr, (arow < N && 16 * j + 4 * kk < D) ? (arow * D + 16 * j + 4 * kk) * 4 : OOB, 0);
+        for (int j = 0; j < 4; ++j) z4[j] = bload4(Zr, (arow < N && 16 * j + 4 * kk < D) ? (arow * D + 16 * j + 4 * kk) * 4 : OOB, 0);
+    };
+    f32x4 za[4];
+    load_rows(0, za);
+    for (int rt = 0; rt < nrt; ++rt) {
+        f32x4 zn[4];
+        load_rows(rt + 1, zn);                                 // the next row tile's loads fly during this tile's products and stores
+        float yv[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * ct + c, row = 16 * rt + g4 + r;
+                yv[ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, (n < C && row < N) ? (n * N + row) * 4 : OOB, 0, 0));
+            }
         f32x4 S[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            S[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 sj[4];                                       // four independent accumulator chains (a single one is 16 dependent MFMAs), summed in a fixed order
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) sj[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) S[ct] = mfma4(za[j][q], tb[ct][j][q], S[ct]);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sj[j] = mfma4(za[j][q], tb[ct][j][q], sj[j]);
+            S[ct] = (sj[0] + sj[1]) + (sj[2] + sj[3]);
         }
         // accumulator lane (g, c), register r: S[row 16 rt + 4 g + r][class 16 ct + c]
 #pragma unroll
@@ -179,8 +221,7 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
                 const int row = 16 * rt + g4 + r;
                 const bool ok = n < C && row < N;
                 const int off = ok ? (n * N + row) * 4 : OOB;
-                const float yv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, off, 0, 0));
-                const float rr = ok ? yv - mc[ct] : 0.f;
+                const float rr = ok ? yv[ct][r] - mc[ct] : 0.f;
                 const float s = ok ? S[ct][r] : 0.f;
                 const float al = (rr - svc[ct] * s) / nz[ct];
                 bstore1(Alr, al, off, 0);
@@ -191,7 +232,10 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
                 srs[ct] = fmaf(rr, s, srs[ct]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) za[j] = zn[j];
     }
+    float objp = 0.f;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         const float a1 = colsum(sa[ct]), a2 = colsum(saa[ct]), r2 = colsum(srr[ct]), rs = colsum(srs[ct]);
@@ -204,12 +248,44 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
             const float quad = (r2 - s * rs) / z;
             const float trk_d = tt[ct] - 2.0f * dnoise_d[bc];                          // tr K'_c^-1
             const float trk = (float)(N - LR_DP) / z + trk_d;
-            logp[bc] = -0.5f * quad - 0.5f * ((float)(N - LR_DP) * logf(z) + logdet_d) - (float)N * DKT_HALF_LOG_2PI;
+            const float lp = -0.5f * quad - 0.5f * ((float)(N - LR_DP) * logf(z) + logdet_d) - (float)N * DKT_HALF_LOG_2PI;
+            logp[bc] = lp;
+            objp += (cls_weight ? cls_weight[n] : 1.f) * lp;
+            if (jitter_total) jitter_total[bc] = jitter[bc] + (pre_jitter ? pre_jitter[n] : 0.f);
             dmean[bc] = a1;
             dnoise[bc] = 0.5f * (a2 - trk);
             dsv[bc] = 0.5f * (tt[ct] - ((float)LR_DP - z * trk_d) / s);
         }
     }
+    // obj[b] = sum_c cls_weight_c logp[b, c]: the classes sit on lanes 0 .. 15 (row group 0) of each class tile; fixed order
+    if (obj) {
+        float o = (kk == 0) ? objp : 0.f;
+#pragma unroll
+        for (int sft = 8; sft > 0; sft >>= 1) o += __shfl_xor(o, sft, DKT_WAVE);
+        if (lane == 0) obj[b] = o;
+    }
+}
+
+// Which rung of psd_safe_cholesky's ladder (0, j0, 10 j0, ...: TOTAL jitter) the N x N matrix K_c = sv_c Z Z^T + noise_c I needs before it is numerically
+// positive definite at all.  With D < N that matrix has N - D eigenvalues equal to noise_c, so its fp32 Cholesky fails -- and the reference retries -- when
+// the noise floor drowns in the rounding of the diagonal: noise_c + jitter < 2^-22 max_i K_ii = 2^-22 (sv_c zmax2 + noise_c).  The D x D models never see that
+// rank deficiency (sv_c Z^T Z is positive definite on its own), so the rung is chosen here, per class; the D x D call's own ladder runs on top of it.
+// NaN where no rung clears the floor: the class then fails in the D x D call (info != 0, NaN outputs).
+__global__ void lowrank_noise_floor_kernel(const float* __restrict__ sv, const float* __restrict__ noise, const float* __restrict__ zmax2, const float jitter0,
+                                           const int max_tries, float* __restrict__ noise_eff, float* __restrict__ pre_jitter, const int C) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C) return;
+    const float nz = noise[n], zm = zmax2 ? zmax2[0] : 1.0f;
+    const float thresh = (sv[n] * zm + nz) * 2.384185791015625e-07f;          // 2^-22
+    float pre = __int_as_float(0x7fc00000), jit = 0.f;
+    for (int attempt = 0; attempt <= max_tries; ++attempt) {
+        if (attempt == 1) jit = jitter0;
+        if (attempt > 1) jit *= 10.f;
+        const float lifted = nz + jit;
+        if (lifted >= thresh && lifted > 0.f) { pre = jit; break; }
+    }
+    pre_jitter[n] = pre;
+    noise_eff[n] = nz + pre;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -243,17 +319,23 @@ __global__ __launch_bounds__(64) void lowrank_bwd_kernel(const float* __restrict
         }
     const int g4 = 4 * kk, c = m;
     const int nrt = (N + 15) >> 4;
-    for (int rt = 0; rt < nrt; ++rt) {
+    auto load_rows = [&](const int rt, f32x4 (&z4)[4], float (&v1)[NKC]) {
         const int arow = 16 * rt + m;
-        f32x4 za[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) za[j] = bload4(Zr, (arow < N && 16 * j + 4 * kk < D) ? (arow * D + 16 * j + 4 * kk) * 4 : OOB, 0);
-        float va[NKC];
+        for (int j = 0; j < 4; ++j) z4[j] = bload4(Zr, (arow < N && 16 * j + 4 * kk < D) ? (arow * D + 16 * j + 4 * kk) * 4 : OOB, 0);
 #pragma unroll
         for (int ks = 0; ks < NKC; ++ks) {
             const int n = 4 * ks + kk;
-            va[ks] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Vr, (n < C && arow < N) ? (n * N + arow) * 4 : OOB, 0, 0));
+            v1[ks] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Vr, (n < C && arow < N) ? (n * N + arow) * 4 : OOB, 0, 0));
         }
+    };
+    f32x4 za[4];
+    float va[NKC];
+    load_rows(0, za, va);
+    for (int rt = 0; rt < nrt; ++rt) {
+        f32x4 zn[4];
+        float vn[NKC];
+        load_rows(rt + 1, zn, vn);                             // the next row tile's operands fly during this tile's 64 + 4 NKC products
         f32x4 out[4];
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
@@ -272,6 +354,10 @@ __global__ __launch_bounds__(64) void lowrank_bwd_kernel(const float* __restrict
             const f32x4 o = {out[0][r], out[1][r], out[2][r], out[3][r]};
             bstore4(dZr, o, (row < N && 4 * c < D) ? (row * D + 4 * c) * 4 : OOB, 0);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) za[j] = zn[j];
+#pragma unroll
+        for (int ks = 0; ks < NKC; ++ks) va[ks] = vn[ks];
     }
 }
 
@@ -294,8 +380,16 @@ extern "C" int dkt_lowrank_gram_f32(const float* Z, const float* Y, long y_bstri
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
+extern "C" int dkt_lowrank_noise_floor_f32(const float* sv, const float* noise, const float* zmax2, float jitter0, int max_tries, float* noise_eff,
+                                           float* pre_jitter, int C, void* stream) {
+    if (!sv || !noise || !noise_eff || !pre_jitter || C <= 0 || max_tries < 0 || max_tries > 8) return DKT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(lowrank_noise_floor_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sv, noise, zmax2, jitter0, max_tries, noise_eff, pre_jitter, C);
+    return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+}
+
 extern "C" int dkt_lowrank_finish_f32(const float* Z, const float* Y, long y_bstride, const float* sv, const float* mean, const float* noise,
                                       const float* cls_weight, const float* T, const float* logp_d, const float* dnoise_d, const float* jitter_used,
+                                      const float* pre_jitter, float* jitter_total, float* obj,
                                       float* logp, float* alpha, float* V, float* dsv, float* dmean, float* dnoise,
                                       int B, int C, int N, int D, void* stream) {
     if (!Z || !Y || !sv || !mean || !noise || !T || !logp_d || !dnoise_d || !jitter_used || !logp || !alpha || !V || !dsv || !dmean || !dnoise || y_bstride < 0)
@@ -305,10 +399,10 @@ extern "C" int dkt_lowrank_finish_f32(const float* Z, const float* Y, long y_bst
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16)
         hipLaunchKernelGGL((lowrank_finish_kernel<1>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
-                           logp, alpha, V, dsv, dmean, dnoise, C, N, D);
+                           pre_jitter, jitter_total, obj, logp, alpha, V, dsv, dmean, dnoise, C, N, D);
     else
         hipLaunchKernelGGL((lowrank_finish_kernel<2>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
-                           logp, alpha, V, dsv, dmean, dnoise, C, N, D);
+                           pre_jitter, jitter_total, obj, logp, alpha, V, dsv, dmean, dnoise, C, N, D);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 

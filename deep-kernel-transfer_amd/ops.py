@@ -668,6 +668,18 @@ def lowrank_applies(n: int, d: int, c: int) -> bool:
     return (os.environ.get("DKT_LOWRANK", "1") != "0" and d <= LOWRANK_DP and d % 4 == 0 and c <= 32 and n >= LOWRANK_MIN_N)
 
 
+_lowrank_zeros = {}
+
+
+def _zeros_cached(c: int, dev) -> torch.Tensor:
+    """[C] zeros (the mean of the D x D models), one tensor per (device, C): never written."""
+    key = (dev, int(c))
+    t = _lowrank_zeros.get(key)
+    if t is None:
+        t = _lowrank_zeros[key] = torch.zeros(c, device=dev, dtype=torch.float32)
+    return t
+
+
 class _EpisodeLossLowRankFn(torch.autograd.Function):
     """Training episode of the linear / cossim / bncossim kernel in feature space (D <= 64 < N):
        forward : A = Z^T Z, P = Z^T (Y - m) (dkt_lowrank_gram_f32) -> the D x D model K'_c = sv_c A + noise_c I through dkt_mll_f32 (jitter ladder and all)
@@ -676,7 +688,7 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
     Neither E[B,N,N] nor W[B,N,N] is ever formed (reference lines replaced: methods/DKT.py:375-378, 161-163)."""
 
     @staticmethod
-    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries):
+    def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows):
         z = _req(z, "z", 3)
         b_, n, d = z.shape
         y = _req(y, "y")
@@ -688,38 +700,45 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
             raise RuntimeError("episode_loss_linear: y must be [C,N] or [B,C,N]")
         sv_ = _req(sv.reshape(-1), "sv", 1)
         mean_ = _req(mean.reshape(-1), "mean", 1)
-        noise_ = _req(noise.reshape(-1), "noise", 1)
+        noise_in = _req(noise.reshape(-1), "noise", 1)
         cw_ = _req(cls_weight.reshape(-1), "cls_weight", 1)
         dev = z.device
         lib = _lib.load()
+        # the rung of the jitter ladder that lifts the noise floor of the (rank-deficient) N x N matrix above fp32 rounding -- 0 for any sane noise; rows that
+        # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T
+        zmax2 = None if unit_rows else z.square().sum(2).amax().reshape(1).contiguous()
+        noise_ = torch.empty_like(noise_in)
+        pre = torch.empty_like(noise_in)
+        _lib.check(lib.dkt_lowrank_noise_floor_f32(_p(sv_), _p(noise_in), _p(zmax2), float(jitter0), int(max_tries), _p(noise_), _p(pre), c_, _stream()),
+                   "dkt_lowrank_noise_floor_f32")
         a = torch.empty((b_, LOWRANK_DP, LOWRANK_DP), device=dev, dtype=torch.float32)
         p = torch.empty((b_, c_, LOWRANK_DP), device=dev, dtype=torch.float32)
         with _timed("dkt_lowrank_gram_f32"):
             st = lib.dkt_lowrank_gram_f32(_p(z), _p(y), y_bstride, _p(mean_), _p(a), _p(p), b_, c_, n, d, _stream())
         _lib.check(st, "dkt_lowrank_gram_f32")
-        zero = torch.zeros(c_, device=dev, dtype=torch.float32)
-        out = mll(a, p, sv_, zero, noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
+        out = mll(a, p, sv_, _zeros_cached(c_, dev), noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
         logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
         alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
         v = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
         dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
         dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
         dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+        obj = torch.empty((b_,), device=dev, dtype=torch.float32)
         with _timed("dkt_lowrank_finish_f32"):
             st = lib.dkt_lowrank_finish_f32(_p(z), _p(y), y_bstride, _p(sv_), _p(mean_), _p(noise_), _p(cw_), _p(out["alpha"]), _p(out["logp"]), _p(out["dnoise"]),
-                                            _p(out["jitter"]), _p(logp), _p(alpha), _p(v), _p(dsv), _p(dmean), _p(dnoise), b_, c_, n, d, _stream())
+                                            _p(out["jitter"]), _p(pre), _p(jit), _p(obj), _p(logp), _p(alpha), _p(v), _p(dsv), _p(dmean), _p(dnoise), b_, c_, n, d, _stream())
         _lib.check(st, "dkt_lowrank_finish_f32")
-        obj = (logp * cw_.reshape(1, -1)).sum(1)
         ctx.save_for_backward(z, v, out["alpha"], out["w"], dsv, dmean, dnoise, cw_)
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
-        ctx.mark_non_differentiable(logp, alpha, out["info"], out["jitter"])
+        ctx.mark_non_differentiable(logp, alpha, out["info"], jit)
         ctx.set_materialize_grads(False)
-        return obj, logp, alpha, out["info"], out["jitter"]
+        return obj, logp, alpha, out["info"], jit
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
         if gobj is None:
-            return (None,) * 8
+            return (None,) * 9
         z, v, t, wd, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         dz = None
@@ -734,7 +753,7 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
         gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
         gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
         gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
-        return dz, None, gsv, gmean, gnoise, None, None, None
+        return dz, None, gsv, gmean, gnoise, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -967,5 +986,5 @@ def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6
     the scaled 2-way f16 split (same fp32-level accuracy, less staging work).
     D <= 64 < N (lowrank_applies: the Conv4S / Omniglot episodes): the episode runs in feature space and E is None -- no N x N matrix exists."""
     if z.dim() == 3 and lowrank_applies(z.shape[1], z.shape[2], y.shape[-2]):
-        return _EpisodeLossLowRankFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries) + (None,)
+        return _EpisodeLossLowRankFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, bool(unit_rows)) + (None,)
     return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows)

@@ -195,7 +195,7 @@ int dkt_predict_var_f32(const float* Ex, const float* exx, const float* L, const
  *     d obj / d Z = sum_c cw_c sv_c (alpha_c - Z t_c) t_c^T + 2 Z W',   W' = 0.5 sum_c cw_c sv_c (t_c t_c^T - K'_c^-1),
  * and K'_c is the matrix family dkt_mll_f32 factorises (base matrix A, targets p_c, zero mean, the same sv / noise / cls_weight / jitter ladder --
  * the jitter lands on noise_c exactly as psd_safe_cholesky's does on K_c's diagonal).  The training episode is then
- *     dkt_lowrank_gram_f32 -> dkt_mll_f32 (B, C, N' = DKT_LOWRANK_DP, y_bstride = C * DKT_LOWRANK_DP, mean = 0, DKT_MLL_WANT_GRAD) -> dkt_lowrank_finish_f32
+ *     dkt_lowrank_noise_floor_f32 -> dkt_lowrank_gram_f32 -> dkt_mll_f32 (B, C, N' = DKT_LOWRANK_DP, y_bstride = C * DKT_LOWRANK_DP, mean = 0, DKT_MLL_WANT_GRAD) -> dkt_lowrank_finish_f32
  *     backward: dkt_lowrank_bwd_f32
  * and neither E[B,N,N] nor W[B,N,N] exists.  Z:[B,N,D] row-major, D % 4 == 0, D <= DKT_LOWRANK_DP (zero-padded to it), C <= 32, any N
  * (DKT_ERR_TOO_LARGE otherwise: the caller takes dkt_gram_f32 / dkt_mll_f32 / dkt_gram_bwd_f32).  A:[B,DP,DP], P and T:[B,C,DP], Wd:[B,DP,DP] hold the
@@ -208,10 +208,19 @@ int dkt_lowrank_supported(int C, int N, int D); /* 1 when the three calls below 
 /* A[b] = Zp^T Zp (exactly symmetric), P[b,c,:] = Zp^T (Y[b,c,:] - mean[c]);  Y: [*,C,N], episode b reads Y + b * y_bstride */
 int dkt_lowrank_gram_f32(const float* Z, const float* Y, long y_bstride, const float* mean, float* A, float* P,
                          int B, int C, int N, int D, void* stream);
-/* from the D x D call's outputs T = alpha', logp_d = logp', dnoise_d = dnoise', jitter_used:  logp[B,C], alpha[B,C,N], dsv / dmean / dnoise [B,C]
- * (the conventions of dkt_mll_f32) and V[B,C,N] = cls_weight_c sv_c (alpha_c - Z t_c) for the backward.  A failed class (NaN in T / logp_d) comes out NaN. */
+/* Which rung of psd_safe_cholesky's ladder (TOTAL jitter 0, jitter0, 10 jitter0, ...) the N x N matrix K_c needs before it is numerically positive definite at
+ * all: with D < N it has N - D eigenvalues equal to noise_c, so its fp32 factorisation fails -- and the reference retries -- when noise_c + jitter < 2^-22 max_i K_ii
+ * = 2^-22 (sv_c zmax2 + noise_c).  The D x D models never see that rank deficiency, so the rung is chosen here ([C] device arithmetic, no read-back):
+ * pre_jitter[c] (NaN when no rung clears the floor: the class then fails), noise_eff[c] = noise[c] + pre_jitter[c] = the noise the other three calls and the
+ * D x D dkt_mll_f32 (whose own ladder runs on top) are given.  zmax2: device scalar max_i |z_i|^2 over the call's rows, or NULL (= 1: rows that went through F.normalize). */
+int dkt_lowrank_noise_floor_f32(const float* sv, const float* noise, const float* zmax2, float jitter0, int max_tries, float* noise_eff,
+                                float* pre_jitter, int C, void* stream);
+/* from the D x D call's outputs T = alpha', logp_d = logp', dnoise_d = dnoise', jitter_used (noise = noise_eff):  logp[B,C], alpha[B,C,N], dsv / dmean / dnoise [B,C]
+ * (the conventions of dkt_mll_f32), V[B,C,N] = cls_weight_c sv_c (alpha_c - Z t_c) for the backward, and optionally obj[B] = sum_c cls_weight_c logp[b,c] and
+ * jitter_total[B,C] = jitter_used + pre_jitter (pre_jitter / jitter_total / obj may be NULL).  A failed class (NaN in T / logp_d) comes out NaN. */
 int dkt_lowrank_finish_f32(const float* Z, const float* Y, long y_bstride, const float* sv, const float* mean, const float* noise,
                            const float* cls_weight, const float* T, const float* logp_d, const float* dnoise_d, const float* jitter_used,
+                           const float* pre_jitter, float* jitter_total, float* obj,
                            float* logp, float* alpha, float* V, float* dsv, float* dmean, float* dnoise,
                            int B, int C, int N, int D, void* stream);
 /* dZ[b] = ep_scale[b] * (V[b]^T T[b] + 2 Z[b] Wd[b])  (= ep_scale[b] (W + W^T) Z of the N x N formulation);  ep_scale: [B] device or NULL (= 1) */

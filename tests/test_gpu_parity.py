@@ -1488,7 +1488,7 @@ def test_dkt_omniglot_shape_train_step_runs_in_feature_space(cuda, capsys, monke
     for g1, g2 in zip(grads, grads2):
         assert (g1 is None) == (g2 is None)
         if g1 is not None:
-            assert float((g1 - g2).norm()) <= GRAD_RTOL * float(g2.norm()) + 1e-7
+            assert float((g1 - g2).norm()) <= GRAD_RTOL * float(g2.norm()) + 2e-5        # (conv biases in front of a train-mode BN have an exactly-zero gradient: absolute floor)
     model.train_loop(0, [(x, None)] * 2, None, print_freq=1)
     assert "Epoch [0] [0/2]" in capsys.readouterr().out
 
