@@ -680,6 +680,57 @@ def _zeros_cached(c: int, dev) -> torch.Tensor:
     return t
 
 
+def _lowrank_forward(z, y, sv_, mean_, noise_in, cw_, jitter0, max_tries, unit_rows) -> dict:
+    """The forward calls of the feature-space episode on contiguous tensors (no autograd): noise floor -> A, P -> the D x D models -> alpha, logp, gradients.
+    Returns obj, logp, alpha, info, jitter (total), v / t / wd (for the backward), dsv, dmean, dnoise."""
+    b_, n, d = z.shape
+    if y.dim() == 2:
+        c_, y_bstride = y.shape[0], 0
+    elif y.dim() == 3 and y.shape[0] == b_:
+        c_, y_bstride = y.shape[1], y.shape[1] * n
+    else:
+        raise RuntimeError("episode_loss_linear: y must be [C,N] or [B,C,N]")
+    dev = z.device
+    lib = _lib.load()
+    # the rung of the jitter ladder that lifts the noise floor of the (rank-deficient) N x N matrix above fp32 rounding -- 0 for any sane noise; rows that
+    # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T
+    zmax2 = None if unit_rows else z.square().sum(2).amax().reshape(1).contiguous()
+    noise_ = torch.empty_like(noise_in)
+    pre = torch.empty_like(noise_in)
+    _lib.check(lib.dkt_lowrank_noise_floor_f32(_p(sv_), _p(noise_in), _p(zmax2), float(jitter0), int(max_tries), _p(noise_), _p(pre), c_, _stream()),
+               "dkt_lowrank_noise_floor_f32")
+    a = torch.empty((b_, LOWRANK_DP, LOWRANK_DP), device=dev, dtype=torch.float32)
+    p = torch.empty((b_, c_, LOWRANK_DP), device=dev, dtype=torch.float32)
+    with _timed("dkt_lowrank_gram_f32"):
+        st = lib.dkt_lowrank_gram_f32(_p(z), _p(y), y_bstride, _p(mean_), _p(a), _p(p), b_, c_, n, d, _stream())
+    _lib.check(st, "dkt_lowrank_gram_f32")
+    out = mll(a, p, sv_, _zeros_cached(c_, dev), noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
+    logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
+    v = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
+    dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
+    obj = torch.empty((b_,), device=dev, dtype=torch.float32)
+    with _timed("dkt_lowrank_finish_f32"):
+        st = lib.dkt_lowrank_finish_f32(_p(z), _p(y), y_bstride, _p(sv_), _p(mean_), _p(noise_), _p(cw_), _p(out["alpha"]), _p(out["logp"]), _p(out["dnoise"]),
+                                        _p(out["jitter"]), _p(pre), _p(jit), _p(obj), _p(logp), _p(alpha), _p(v), _p(dsv), _p(dmean), _p(dnoise), b_, c_, n, d, _stream())
+    _lib.check(st, "dkt_lowrank_finish_f32")
+    return dict(obj=obj, logp=logp, alpha=alpha, info=out["info"], jitter=jit, v=v, t=out["alpha"], wd=out["w"], dsv=dsv, dmean=dmean, dnoise=dnoise)
+
+
+def _lowrank_backward(z, v, t, wd, gobj) -> torch.Tensor:
+    """dZ[b] = gobj[b] (V^T T + 2 Z W')  (dkt_lowrank_bwd_f32)."""
+    b_, n, d = z.shape
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    with _timed("dkt_lowrank_bwd_f32"):
+        st = lib.dkt_lowrank_bwd_f32(_p(z), _p(v), _p(t), _p(wd), _p(_req(gobj.reshape(-1), "gobj", 1)), _p(dz), b_, v.shape[1], n, d, _stream())
+    _lib.check(st, "dkt_lowrank_bwd_f32")
+    return dz
+
+
 class _EpisodeLossLowRankFn(torch.autograd.Function):
     """Training episode of the linear / cossim / bncossim kernel in feature space (D <= 64 < N):
        forward : A = Z^T Z, P = Z^T (Y - m) (dkt_lowrank_gram_f32) -> the D x D model K'_c = sv_c A + noise_c I through dkt_mll_f32 (jitter ladder and all)
@@ -690,50 +741,13 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows):
         z = _req(z, "z", 3)
-        b_, n, d = z.shape
-        y = _req(y, "y")
-        if y.dim() == 2:
-            c_, y_bstride = y.shape[0], 0
-        elif y.dim() == 3 and y.shape[0] == b_:
-            c_, y_bstride = y.shape[1], y.shape[1] * n
-        else:
-            raise RuntimeError("episode_loss_linear: y must be [C,N] or [B,C,N]")
-        sv_ = _req(sv.reshape(-1), "sv", 1)
-        mean_ = _req(mean.reshape(-1), "mean", 1)
-        noise_in = _req(noise.reshape(-1), "noise", 1)
-        cw_ = _req(cls_weight.reshape(-1), "cls_weight", 1)
-        dev = z.device
-        lib = _lib.load()
-        # the rung of the jitter ladder that lifts the noise floor of the (rank-deficient) N x N matrix above fp32 rounding -- 0 for any sane noise; rows that
-        # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T
-        zmax2 = None if unit_rows else z.square().sum(2).amax().reshape(1).contiguous()
-        noise_ = torch.empty_like(noise_in)
-        pre = torch.empty_like(noise_in)
-        _lib.check(lib.dkt_lowrank_noise_floor_f32(_p(sv_), _p(noise_in), _p(zmax2), float(jitter0), int(max_tries), _p(noise_), _p(pre), c_, _stream()),
-                   "dkt_lowrank_noise_floor_f32")
-        a = torch.empty((b_, LOWRANK_DP, LOWRANK_DP), device=dev, dtype=torch.float32)
-        p = torch.empty((b_, c_, LOWRANK_DP), device=dev, dtype=torch.float32)
-        with _timed("dkt_lowrank_gram_f32"):
-            st = lib.dkt_lowrank_gram_f32(_p(z), _p(y), y_bstride, _p(mean_), _p(a), _p(p), b_, c_, n, d, _stream())
-        _lib.check(st, "dkt_lowrank_gram_f32")
-        out = mll(a, p, sv_, _zeros_cached(c_, dev), noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
-        logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
-        alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
-        v = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
-        dsv = torch.empty((b_, c_), device=dev, dtype=torch.float32)
-        dmean = torch.empty((b_, c_), device=dev, dtype=torch.float32)
-        dnoise = torch.empty((b_, c_), device=dev, dtype=torch.float32)
-        jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
-        obj = torch.empty((b_,), device=dev, dtype=torch.float32)
-        with _timed("dkt_lowrank_finish_f32"):
-            st = lib.dkt_lowrank_finish_f32(_p(z), _p(y), y_bstride, _p(sv_), _p(mean_), _p(noise_), _p(cw_), _p(out["alpha"]), _p(out["logp"]), _p(out["dnoise"]),
-                                            _p(out["jitter"]), _p(pre), _p(jit), _p(obj), _p(logp), _p(alpha), _p(v), _p(dsv), _p(dmean), _p(dnoise), b_, c_, n, d, _stream())
-        _lib.check(st, "dkt_lowrank_finish_f32")
-        ctx.save_for_backward(z, v, out["alpha"], out["w"], dsv, dmean, dnoise, cw_)
+        o = _lowrank_forward(z, _req(y, "y"), _req(sv.reshape(-1), "sv", 1), _req(mean.reshape(-1), "mean", 1), _req(noise.reshape(-1), "noise", 1),
+                             _req(cls_weight.reshape(-1), "cls_weight", 1), jitter0, max_tries, unit_rows)
+        ctx.save_for_backward(z, o["v"], o["t"], o["wd"], o["dsv"], o["dmean"], o["dnoise"], _req(cls_weight.reshape(-1), "cls_weight", 1))
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
-        ctx.mark_non_differentiable(logp, alpha, out["info"], jit)
+        ctx.mark_non_differentiable(o["logp"], o["alpha"], o["info"], o["jitter"])
         ctx.set_materialize_grads(False)
-        return obj, logp, alpha, out["info"], jit
+        return o["obj"], o["logp"], o["alpha"], o["info"], o["jitter"]
 
     @staticmethod
     def backward(ctx, gobj, *_unused):
@@ -741,14 +755,7 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
             return (None,) * 9
         z, v, t, wd, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
-        dz = None
-        if ctx.needs_input_grad[0]:
-            b_, n, d = z.shape
-            dz = torch.empty_like(z)
-            lib = _lib.load()
-            with _timed("dkt_lowrank_bwd_f32"):
-                st = lib.dkt_lowrank_bwd_f32(_p(z), _p(v), _p(t), _p(wd), _p(_req(gobj.reshape(-1), "gobj", 1)), _p(dz), b_, v.shape[1], n, d, _stream())
-            _lib.check(st, "dkt_lowrank_bwd_f32")
+        dz = _lowrank_backward(z, v, t, wd, gobj) if ctx.needs_input_grad[0] else None
         gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
         gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
         gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
@@ -908,7 +915,8 @@ class _EpisodeLossBnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries):
         b_, n, d = x.shape
-        ctx.big = n > FUSED_EP_MAX_N
+        ctx.lowrank = lowrank_applies(n, d, y.shape[-2])
+        ctx.big = n > FUSED_EP_MAX_N or ctx.lowrank
         if ctx.big:
             if use_bn:
                 st = bn_stats(x, gamma, beta, eps)
@@ -918,6 +926,17 @@ class _EpisodeLossBnFn(torch.autograd.Function):
                 s = torch.zeros(d, device=x.device, dtype=torch.float32)
                 bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
             zn, rnorm = affine_normalize(x, a, s)
+            if ctx.lowrank:
+                # D <= 64 < N (Conv4S / Omniglot): the episode in feature space on the normalised features -- no E, no W (csrc/dkt_lowrank.hip)
+                cw_ = _req(cls_weight.reshape(-1), "cls_weight", 1)
+                o = _lowrank_forward(zn, _req(y, "y"), _req(sv.reshape(-1), "sv", 1), _req(mean.reshape(-1), "mean", 1), _req(noise.reshape(-1), "noise", 1),
+                                     cw_, jitter0, max_tries, True)
+                ctx.use_bn = bool(use_bn)
+                ctx.save_for_backward(x, zn, o["wd"], a, s, bmean, rstd, rnorm, o["dsv"], o["dmean"], o["dnoise"], cw_, o["v"], o["t"])
+                ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
+                ctx.mark_non_differentiable(o["logp"], o["alpha"], o["info"], o["jitter"], bmean, bvar, a, s, rnorm)
+                ctx.set_materialize_grads(False)
+                return o["obj"], o["logp"], o["alpha"], o["info"], o["jitter"], None, bmean, bvar, a, s, rnorm
             e = gram(zn, None, KERNEL_LINEAR_UNIT)
             out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
             obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
@@ -952,10 +971,10 @@ class _EpisodeLossBnFn(torch.autograd.Function):
     def backward(ctx, gobj, *_unused):
         if gobj is None:
             return (None,) * 12
-        x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors
+        x, e, w, a, s, bmean, rstd, rnorm, dsv, dmean, dnoise, cw = ctx.saved_tensors[:12]
         gobj = gobj.contiguous()
-        if ctx.big:                                           # (the second saved tensor is Zn here)
-            dzn = gram_bwd(w, e, gobj, unit_rows=True, w_symmetric=True)
+        if ctx.big:                                           # (the second saved tensor is Zn here; feature-space path: the third is W', then V and T)
+            dzn = _lowrank_backward(e, ctx.saved_tensors[12], ctx.saved_tensors[13], w, gobj) if ctx.lowrank else gram_bwd(w, e, gobj, unit_rows=True, w_symmetric=True)
             dx, dg, db = normalize_bn_bwd(dzn, e, x, a, rnorm, bmean if ctx.use_bn else None, rstd if ctx.use_bn else None)
         elif ctx.use_bn:
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
@@ -973,7 +992,7 @@ class _EpisodeLossBnFn(torch.autograd.Function):
 
 def episode_loss_bn(x, gamma, beta, y, sv, mean, noise, cls_weight, eps: float = 1e-5, jitter0: float = 1e-6, max_tries: int = 3,
                     use_bn: bool = True, full: bool = False):
-    """x:[B,N,D] trunk output BEFORE bn_out.  Returns (obj[B], logp, alpha, info, jitter, E, batch_mean[B,D],
+    """x:[B,N,D] trunk output BEFORE bn_out.  Returns (obj[B], logp, alpha, info, jitter, E (None when the episode ran in feature space: lowrank_applies), batch_mean[B,D],
     batch_var_unbiased[B,D]) -- the last two feed the caller's running-statistics update -- plus, with full=True, the folded
     affine map a, s and the row scales rnorm (zn = (a x + s) rnorm: what a caller needs to re-create the normalised features)."""
     out = _EpisodeLossBnFn.apply(x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries)

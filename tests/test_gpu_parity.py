@@ -1916,7 +1916,8 @@ def test_fused_gram_eval_mode_and_plain_cossim(cuda, b, n, d):
         assert np.abs(e1[i].cpu().numpy() - z1 @ z1.T).max() < 2e-5
 
 
-@pytest.mark.parametrize("b,c,per,d", [(2, 5, 5, 64), (2, 5, 21, 1600), (3, 5, 17, 512), (2, 3, 6, 40), (1, 2, 64, 128), (2, 5, 30, 64), (2, 20, 21, 128), (1, 3, 67, 36)])
+@pytest.mark.parametrize("b,c,per,d", [(2, 5, 5, 64), (2, 5, 21, 1600), (3, 5, 17, 512), (2, 3, 6, 40), (1, 2, 64, 128), (2, 5, 30, 64), (2, 20, 21, 128), (1, 3, 67, 36),
+                                       (2, 5, 21, 64), (1, 20, 21, 64)])       # the last four with D <= 64 < N: the feature-space path behind dkt_affine_normalize_f32 (round 5)
 def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, per, d):
     """bn_out(train) + F.normalize + Gram + MLL and the whole backward (dX, dgamma, dbeta, hyper-parameters) in the fused
     kernels vs float64 torch autograd of the reference formulation.  N <= 128: the episode-resident kernels (the normalised features never leave the chip);
@@ -1938,6 +1939,7 @@ def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, p
     cw = torch.full((c,), -1.0 / (c * n), device=cuda)
     obj, logp, alpha, info, jit, e, bmean, bvar = ops.episode_loss_bn(xt, gt, bt, y, torch.nn.functional.softplus(rst), mt, noise, cw)
     assert int(info.abs().max().item()) == 0
+    assert (e is None) == ops.lowrank_applies(n, d, c)             # D <= 64 < N: the episode ran in feature space, no N x N matrix exists
     w_ep = torch.linspace(0.5, 1.5, b, device=cuda)                # non-uniform upstream gradient per episode
     (obj * w_ep).sum().backward()
     # float64 reference
