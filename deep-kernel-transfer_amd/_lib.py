@@ -2,6 +2,12 @@
 
 There is NO CPU fallback: every entry point of `ops` goes through this library, and `load()`
 raises if the shared object is missing or a symbol of the header is absent.
+
+Three in-tree shared objects, all hipcc --offload-arch=gfx950:
+  libdkt_hip.so    the PRODUCT: the default kernel of every call, no measurement switch, no variant instantiation;
+  libdkt_twins.so  the same sources with -DDKT_TWINS: every pipeline variant, legacy pipeline and validation twin the defaults were chosen from, selected
+                   by the environment switches of DESIGN.md's appendix.  Same ABI.  Loaded by the tests / A-B tools only (DKT_TWINS=1 + a variant switch);
+  libdkt_diag.so   measurement-only kernels (stream ceilings, co-residency spinners, the round-1 register-sweep kernel).
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_smal
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
 DIAG_SOURCES = ["dkt_diag.hip", "dkt_mll_reg_twin.hip"]
 DIAG_LIB_PATH = os.path.join(_HERE, "libdkt_diag.so")
+TWINS_LIB_PATH = os.path.join(_HERE, "libdkt_twins.so")
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join(INCLUDE, "dkt_abi.h")]
 OBJ_DIR = os.path.join(_HERE, "build")
 
@@ -64,7 +71,7 @@ SIGNATURES = {
 }
 
 _lock = threading.Lock()
-_lib = None
+_libs = {}          # path -> bound CDLL
 
 
 def _lib_path() -> str:
@@ -72,32 +79,23 @@ def _lib_path() -> str:
     return os.environ.get("DKT_AMD_LIB") or LIB_PATH
 
 
-def _flags() -> list:
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
-            "-I", INCLUDE, "-I", CSRC] + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split()
+def _flags(twins: bool = False) -> list:
+    return (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+             "-I", INCLUDE, "-I", CSRC] + (["-DDKT_TWINS"] if twins else []) + os.environ.get("DKT_EXTRA_HIPCC_FLAGS", "").split())
 
 
-# Register-spill budget per kernel (regex on the mangled name -> max VGPR spills); everything else must not spill at all.
-# The headline instantiation of the MFMA marginal-likelihood kernel sits at its 168-VGPR cap (3 waves per SIMD) and keeps ~30
-# values of the round prologue in scratch across the factorisation -- stored / reloaded once per matrix, none inside the sweeps or
-# the MFMA phases.  The check fails the build when a change makes the compiler spill inside the hot loops.
+# Register-spill budget per kernel of the PRODUCT library (regex on the mangled name -> max VGPR spills); everything else must not spill at all.  The check
+# fails the build when a change makes the compiler spill inside a hot loop.  (The twins library carries the non-default instantiations -- NT = 8 MFMA twins
+# with up to 188 spilled VGPRs among them -- and is not checked.)
 SPILL_BUDGET = {
     # mll_h2e_kernel (wave per episode, the bench kernel since round 3): no entry = 0 spills allowed, at 254 of 256 VGPRs
-    r"mll_h2_kernelILi7ELb1ELb1": 24,              # wave per matrix <NT = 7, GRAD, 5 waves per episode> at its 168-VGPR cap (batches < 1024 episodes): 20
-    r"mll_h2_kernelILi[67]E": 16,                  # its forward-only / other-class-count instantiations: 12 / 11 / 2
-    r"mll_mfma_kernelILi7ELb1ELb0ELb1": 16,        # <NT = 7, GRAD, !CHOL, 5 waves per episode>: the bench kernel
-    r"mll_mfma_kernelILi[78]E": 260,               # other NT >= 7 instantiations (Cholesky output, odd class counts): not on a hot path
-    r"mll_mfma_kernelILi[56]E": 120,
-    r"mll_mfma_kernelILi[1-4]ELb.ELb1": 60,        # CHOL instantiations of the small shapes (regression head)
-    r"mll_reg_kernel|chol_inv_block_kernel": 80,   # round-1 register sweep (validation twin / blocked path's diagonal blocks)
-    # Gram forward: the default variants for N <= 112 (<7, 2, 2, 32, 2, 3> f16 split, <7, 1, 1, 32, 3, 4> bf16 split) do not spill;
-    # the non-default pipeline variants kept for A/B runs (DKT_GRAM_UNIT_VAR / DKT_GRAM_SPLIT_VAR) and the NT = 8 shapes
-    # (112 < N <= 128, 36 accumulator tiles) do
-    r"gram_sym_ep_split_kernelILi7ELi1E": 70,
-    r"gram_sym_ep_split_kernelILi8E": 140,
-    # tile-array factorisation at 3 workgroups per CU (168 VGPRs): ~28 values parked in scratch around the diagonal-tile sweep, none in the K loop
-    r"tiled_factor_kernelILi\dELb1ELi3E": 40,
-    r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 32,
+    r"mll_h2_kernelILi7ELb1ELb1": 20,              # wave per matrix <NT = 7, GRAD, 5 waves per episode> at its 168-VGPR cap (batches < 1024 episodes): 16
+    r"mll_h2_kernelILi[67]E": 12,                  # its forward-only / other-class-count instantiations: 8
+    r"gram_sym_ep_split_kernelILi8ELi2ELi2": 24,   # Gram forward for 112 < N <= 128 (36 accumulator tiles), unit rows: 24
+    r"gram_sym_ep_split_kernelILi[78]ELi1ELi1": 8,  # the bf16-split default at NT = 7 / 8
+    # tile-array factorisation / inverse at 3 workgroups per CU (168 VGPRs), MC = 7 (N >= 384): values parked in scratch around the diagonal-tile sweep, none in the K loop
+    r"tiled_factor_kernelILi\dELb1ELi3E": 28,
+    r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 24,
 }
 
 
@@ -134,19 +132,19 @@ def check_resources(usage: dict) -> list:
     return bad
 
 
-def _digest(src: str) -> str:
+def _digest(src: str, twins: bool = False) -> str:
     """Content hash of a source, every header and the flags: the object cache key (mtimes do not survive a checkout)."""
     import hashlib
     h = hashlib.sha256()
     for f in [src] + HEADERS:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(_flags()).encode())
+    h.update(" ".join(_flags(twins)).encode())
     return h.hexdigest()[:20]
 
 
-def _stamp(sources, replace=None) -> str:
-    return ";".join(_digest((replace or {}).get(s, os.path.join(CSRC, s))) for s in sources)
+def _stamp(sources, replace=None, twins: bool = False) -> str:
+    return ";".join(_digest((replace or {}).get(s, os.path.join(CSRC, s)), twins) for s in sources)
 
 
 def needs_build() -> bool:
@@ -158,7 +156,7 @@ def needs_build() -> bool:
         return fh.read() != _stamp(SOURCES)
 
 
-def _compile_link(sources, target, replace=None, verbose=False) -> str:
+def _compile_link(sources, target, replace=None, verbose=False, twins: bool = False, check: bool = True) -> str:
     """One hipcc -c per source (in parallel, objects cached by content hash under build/), then one link."""
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -166,9 +164,9 @@ def _compile_link(sources, target, replace=None, verbose=False) -> str:
 
     def one(name):
         src = (replace or {}).get(name, os.path.join(CSRC, name))
-        obj = os.path.join(OBJ_DIR, "%s.%s.o" % (os.path.basename(src), _digest(src)))
+        obj = os.path.join(OBJ_DIR, "%s.%s.o" % (os.path.basename(src), _digest(src, twins)))
         if not os.path.exists(obj) or not os.path.exists(obj + ".res.json"):
-            cmd = [hipcc] + _flags() + ["-c", src, "-o", obj + ".tmp"]
+            cmd = [hipcc] + _flags(twins) + ["-c", src, "-o", obj + ".tmp"]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)
@@ -187,7 +185,7 @@ def _compile_link(sources, target, replace=None, verbose=False) -> str:
             usage.update(json.load(fh))
     with open(os.path.join(OBJ_DIR, os.path.basename(target) + ".resource_usage.json"), "w") as fh:
         json.dump(usage, fh, indent=1, sort_keys=True)
-    bad = check_resources(usage)
+    bad = check_resources(usage) if (check and not twins) else []       # the spill budget is the product library's
     if bad:
         raise RuntimeError("register spills beyond the budget (deep-kernel-transfer_amd/_lib.py SPILL_BUDGET):\n" +
                            "\n".join("  %s: %d VGPR spills (budget %d)" % b for b in bad))
@@ -197,7 +195,7 @@ def _compile_link(sources, target, replace=None, verbose=False) -> str:
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(target + ".tmp", target)
     with open(target + ".stamp", "w") as fh:
-        fh.write(_stamp(sources, replace))
+        fh.write(_stamp(sources, replace, twins))
     return target
 
 
@@ -213,13 +211,23 @@ def build(force: bool = False, verbose: bool = False, out: str = None, replace: 
     return _compile_link(SOURCES, out or LIB_PATH, replace, verbose)
 
 
+def build_twins(verbose: bool = False) -> str:
+    """The same sources with -DDKT_TWINS (every variant / legacy pipeline / validation twin + the environment switches that select them): libdkt_twins.so,
+    loaded by the tests and the A/B tools only."""
+    if os.path.exists(TWINS_LIB_PATH) and os.path.exists(TWINS_LIB_PATH + ".stamp"):
+        with open(TWINS_LIB_PATH + ".stamp") as fh:
+            if fh.read() == _stamp(SOURCES, None, True):
+                return TWINS_LIB_PATH
+    return _compile_link(SOURCES, TWINS_LIB_PATH, None, verbose, twins=True)
+
+
 def build_diag(verbose: bool = False) -> str:
     """The measurement-only kernels (tools/, tests): libdkt_diag.so, never loaded by the product path."""
     if os.path.exists(DIAG_LIB_PATH) and os.path.exists(DIAG_LIB_PATH + ".stamp"):
         with open(DIAG_LIB_PATH + ".stamp") as fh:
             if fh.read() == _stamp(DIAG_SOURCES):
                 return DIAG_LIB_PATH
-    return _compile_link(DIAG_SOURCES, DIAG_LIB_PATH, None, verbose)
+    return _compile_link(DIAG_SOURCES, DIAG_LIB_PATH, None, verbose, check=False)
 
 
 def abi_version_of_header() -> int:
@@ -229,23 +237,23 @@ def abi_version_of_header() -> int:
         return int(re.search(r"#define\s+DKT_ABI_VERSION\s+(\d+)", fh.read()).group(1))
 
 
-def load() -> ctypes.CDLL:
-    """dlopen the HIP library and bind every declared symbol; raises (never falls back) on failure."""
-    global _lib
+def load(path: str = None) -> ctypes.CDLL:
+    """dlopen the HIP library (the product unless `path` / DKT_AMD_LIB says otherwise) and bind every declared symbol; raises (never falls back) on failure."""
+    path = path or _lib_path()
     with _lock:
-        if _lib is not None:
-            return _lib
-        path = _lib_path()
+        lib = _libs.get(path)
+        if lib is not None:
+            return lib
         if not os.path.exists(path):
             raise RuntimeError(
-                "libdkt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "-- the DKT hot path has no CPU fallback." % path)
         lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(lib, name)
             except AttributeError as e:
-                raise RuntimeError("libdkt_hip.so lacks symbol %s declared in include/dkt_abi.h" % name) from e
+                raise RuntimeError("%s lacks symbol %s declared in include/dkt_abi.h" % (os.path.basename(path), name)) from e
             fn.restype = res
             fn.argtypes = args
         want = abi_version_of_header()
@@ -253,8 +261,13 @@ def load() -> ctypes.CDLL:
         if got != want:
             raise RuntimeError("%s implements DKT_ABI_VERSION %d, include/dkt_abi.h declares %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
                                % (path, got, want))
-        _lib = lib
+        _libs[path] = lib
         return lib
+
+
+def load_twins() -> ctypes.CDLL:
+    """The variant / twin build of the same ABI (tests, A/B tools); built on first use where the sources are present."""
+    return load(build_twins())
 
 
 def load_diag() -> ctypes.CDLL:

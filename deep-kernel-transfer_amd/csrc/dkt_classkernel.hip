@@ -287,7 +287,7 @@ extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int k
     if (C > 32) return DKT_ERR_TOO_LARGE;                                // 32 x 512 floats of LDS partials (64 KB)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * nsplit), block(CKB_T);
-    if (g_ck_v4 < 0) { const char* v = getenv("DKT_CLASS_BWD_V4"); g_ck_v4 = (v && v[0] == '0') ? 0 : 1; }      // (0: the dword kernel, a measurement twin)
+    if (g_ck_v4 < 0) { const char* v = dkt_variant_env("DKT_CLASS_BWD_V4"); g_ck_v4 = (v && v[0] == '0') ? 0 : 1; }      // (0: the dword kernel, a measurement twin)
     // (N <= 128: a row of 4-column groups leaves more than half of a wave's lanes idle -- 0.58 vs 0.28 ms at N = 105, C = 5, 2048 episodes: the dword kernel stays)
     if (N > 128 && N <= 512 && g_ck_v4 != 0) {
         switch (kind) {

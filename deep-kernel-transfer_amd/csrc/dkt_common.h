@@ -8,6 +8,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DKT_WAVE 64
 
+// Measurement / validation switches.  The PRODUCT library (libdkt_hip.so) has none of them: every variant kernel and every switch
+// that selects one is compiled out, the defaults are the product.  The twins library (libdkt_twins.so: the same sources with -DDKT_TWINS, loaded by the
+// tests and the A/B tools only) reads them from the environment.
+#include <cstdlib>
+static inline const char* dkt_variant_env(const char* name) {
+#ifdef DKT_TWINS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, DKT_WAVE);

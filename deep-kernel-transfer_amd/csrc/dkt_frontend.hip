@@ -689,7 +689,7 @@ static int g_dist_ep_minb = -1, g_dist_ep_on = -1;           // DKT_GRAM_EP_MINB
 void dkt_frontend_reload_env() { g_dist_ep_minb = -1; g_dist_ep_on = -1; }
 bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
     if (g_dist_ep_minb < 0) { const char* v = getenv("DKT_GRAM_EP_MINB"); g_dist_ep_minb = v ? atoi(v) : 64; }
-    if (g_dist_ep_on < 0) { const char* v = getenv("DKT_GRAM_DIST_EP"); g_dist_ep_on = (v && v[0] == '0') ? 0 : 1; }
+    if (g_dist_ep_on < 0) { const char* v = dkt_variant_env("DKT_GRAM_DIST_EP"); g_dist_ep_on = (v && v[0] == '0') ? 0 : 1; }
     const int minb = g_dist_ep_minb;
     const bool on = g_dist_ep_on != 0;
     if (!on || N <= 32 || N > 128 || (D & 3) || ((uintptr_t)Z & 15) || B < minb || !lengthscale) return false;

@@ -366,7 +366,7 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
     const bool sym = (Bm == nullptr);
     if (sym && M != N) return DKT_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const char* sm = getenv("DKT_GRAM_SMALL");
+    const char* sm = dkt_variant_env("DKT_GRAM_SMALL");
     const bool small_ok = !(sm && sm[0] == '0');
     if (sym && small_ok && dkt_gram_small_launch(A, E, B, N, D, kind, lengthscale, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
@@ -395,7 +395,7 @@ extern "C" int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B
                                 const float* ep_scale, unsigned flags, void* stream) {
     if (!W || !Z || !dZ || B <= 0 || N <= 0 || D <= 0 || (flags & ~(DKT_GRAM_UNIT_ROWS | DKT_GRAM_W_SYMMETRIC))) return DKT_ERR_BAD_ARG;
     {
-        const char* sm = getenv("DKT_GRAM_SMALL");
+        const char* sm = dkt_variant_env("DKT_GRAM_SMALL");
         if (!(sm && sm[0] == '0') && dkt_gram_small_bwd_launch(W, Z, dZ, B, N, D, ep_scale, (hipStream_t)stream))
             return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     }

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void gram_sym_bigep_f16x2_kernel(const floa
 
 static int g_bwd_rows8 = -1;
 static bool gram_bwd_rows8_enabled() {
-    if (g_bwd_rows8 < 0) { const char* v = getenv("DKT_GRAM_BWD_ROWS8"); g_bwd_rows8 = (v && v[0] == '0') ? 0 : 1; }
+    if (g_bwd_rows8 < 0) { const char* v = dkt_variant_env("DKT_GRAM_BWD_ROWS8"); g_bwd_rows8 = (v && v[0] == '0') ? 0 : 1; }
     return g_bwd_rows8 != 0;
 }
 
@@ -500,7 +500,7 @@ void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D,
 
 static int g_big_ep = -1;
 static bool gram_big_ep_enabled() {
-    if (g_big_ep < 0) { const char* v = getenv("DKT_GRAM_BIG_EP"); g_big_ep = (v && v[0] == '0') ? 0 : 1; }
+    if (g_big_ep < 0) { const char* v = dkt_variant_env("DKT_GRAM_BIG_EP"); g_big_ep = (v && v[0] == '0') ? 0 : 1; }
     return g_big_ep != 0;
 }
 void dkt_gram_big_reload_env();                          // dkt_reload_env(); defined below the switches

@@ -745,12 +745,16 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
 // dkt_reload_env() (below, exported for the test-suite and the A/B tools, which flip switches inside one process) re-reads them.
 struct GramEnv {
     int ep, minb, split, ep_bk, ep_bd, unit_var, split_var, bwd_unit_var, bwd_split_var, bwd_unit_mind, bwd_split_mind;
-    static int get(const char* name, int dflt) {
+    static int get(const char* name, int dflt) {                 // variant switch: twins library only
+        const char* v = dkt_variant_env(name);
+        return v ? atoi(v) : dflt;
+    }
+    static int get_product(const char* name, int dflt) {         // dispatch threshold: product library too
         const char* v = getenv(name);
         return v ? atoi(v) : dflt;
     }
     void load() {
-        ep = get("DKT_GRAM_EP", 1); minb = get("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
+        ep = get("DKT_GRAM_EP", 1); minb = get_product("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
         ep_bk = get("DKT_GRAM_EP_BK", 64); ep_bd = get("DKT_GRAM_EP_BD", 32);
         // Round 4 (tools/sweep_ep_variants.py + the in-step A/B of tools/r4_run12.sh, profiles/r04/v14_ep_variant_sweep.log): the forward with non-temporal Z loads
         // (22232: -1 % at D = 1600, -5 % at D = 512, -4 % at D = 64 against 2223) and, below D = 1024, the backward with ONE LDS image and prefetch depth 1
@@ -771,24 +775,32 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit
         // <LDS buffers><prefetch depth> of the bf16 split; 2xxx = scaled-f16 split (unit-norm rows only):
         // 2223 = 2 stage buffers, prefetch depth 2, 3 workgroups per CU
         const int v = unit ? gram_env().unit_var : gram_env().split_var;
-        if (v == 21) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 611) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 612) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 22) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 12) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 211) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 212) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 2611) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 26113) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 26114) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 4>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 26122) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 2223) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 2213) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-        else if (v == 2115) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2, 5>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+#ifdef DKT_TWINS             // the pipeline variants the defaults were chosen from (A/B runs, bitwise-twin tests)
+        if (v == 21) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 611) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 612) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 22) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 12) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 211) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 212) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 32, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 2611) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 26113) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 26114) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 64, 2, 4>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 26122) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 2, 64, 2, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 2223) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 2213) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 1, 32, 2, 3>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+        if (v == 2115) { hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1, 32, 2, 5>), dim3(B), dim3(256), 0, st, Z, E, N, D); return; }
+#endif
+        // the product: unit rows -> scaled 2-way f16 split, 2 stage buffers, prefetch depth 2, 3 workgroups per CU, non-temporal Z loads (22232);
+        // any rows -> exact 3-way bf16 split, 1 buffer, depth 1 (11)
+        if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
-    } else if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        return;
+    }
+#ifdef DKT_TWINS             // DKT_GRAM_SPLIT=0: the exact-fp32 MFMA kernels (validation twins)
+    if (bk == 32) hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 32>), dim3(B), dim3(256), 0, st, Z, E, N, D);
     else hipLaunchKernelGGL((gram_sym_ep_kernel<NT, 64>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+#endif
 }
 
 template <int NT>
@@ -797,21 +809,29 @@ void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, 
         // <LDS buffers><prefetch depth> of the bf16 split; 2xx = scaled-f16 split (unit-norm rows of Z only)
         int v = unit ? gram_env().bwd_unit_var : gram_env().bwd_split_var;
         if (unit && v == 0) v = D < 1024 ? 211 : 1222;
+#ifdef DKT_TWINS
         if (v == 222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
-        if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 2222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 3222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 3>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 221) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 212) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if constexpr (NT <= 7) {
+            if (v == 12) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        }
+#endif
+        // the product: unit rows -> f16 split, one LDS image below D = 1024 (211), two + non-temporal dZ stores from there (1222); any rows -> bf16 split (11)
+        if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if (v == 211) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         if constexpr (NT <= 7) {                              // one stage buffer must also hold the N x N staging copy of W
             if (v == 11) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
-            if (v == 12) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         }
         hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 2, 2>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+        return;
     }
-    else if (bd == 32) hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
-    else hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);
+#ifdef DKT_TWINS
+    if (bd != 32) { hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 64>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+#endif
+    hipLaunchKernelGGL((gram_bwd_ep_kernel<NT, 32>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc);      // short feature rows: exact-fp32 MFMA, 32-wide slabs
 }
 
 }  // namespace

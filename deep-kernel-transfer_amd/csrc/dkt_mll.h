@@ -48,7 +48,7 @@ void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int l
 size_t dkt_mll_big_workspace_bytes(int B, int C, int N);
 int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Tile-array path for N > 127 (dkt_mll_tiled.hip; the default there unless the Cholesky factors are requested).
-bool dkt_mll_tiled_supports(int N, unsigned flags);
+bool dkt_mll_tiled_supports(int N, unsigned flags, int C = 1);
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes

@@ -238,7 +238,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
     a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     if (g_mll_env_read == 0) {
-        const char* pg = getenv("DKT_MLL_P2_GUARD");      // validation aid: a negative guard forces the grow-on-demand path of dkt_mll_h2.hip
+        const char* pg = dkt_variant_env("DKT_MLL_P2_GUARD");      // validation aid: a negative guard forces the grow-on-demand path of dkt_mll_h2.hip
         g_p2_guard = pg ? atoi(pg) : 1;
         const char* fm = getenv("DKT_MLL_F32MFMA");       // process-wide DKT_MLL_FORCE_F32MFMA: exact-fp32 tile products for every N <= 127 call
         g_force_f32mfma = (fm && fm[0] == '1') ? 1 : 0;
@@ -257,7 +257,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
         // DKT_MLL_FORCE_GENERIC (the validation twin) and N > 447: the generic kernel, one workgroup per matrix
         if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
         if (!(flags & DKT_MLL_FORCE_GENERIC)) {
-            if (N + 1 > 128 && dkt_mll_tiled_supports(N, flags)) {
+            if (N + 1 > 128 && dkt_mll_tiled_supports(N, flags, C)) {
                 if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes(B, C, N)) return DKT_ERR_WORKSPACE;
                 return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
             }
@@ -266,7 +266,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     }
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
-    if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags) && workspace &&
+    if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags, C) && workspace &&
         workspace_bytes >= dkt_mll_tiled_workspace_bytes(B, C, N))
         return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_E_PER_CLASS)) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void big_chol_out_kernel(MllArgs a, const floa
 // block size: <= 108 rows (the register sweep needs nb + 1 <= 112), a multiple of 4 so that block origins stay 16-byte aligned
 // Block size of the blocked factorisation.  DKT_BIG_NB (measurement aid) overrides the default.
 inline int big_nb(int N) {
-    static const int forced = [] { const char* v = getenv("DKT_BIG_NB"); return v ? atoi(v) : 0; }();
+    static const int forced = [] { const char* v = dkt_variant_env("DKT_BIG_NB"); return v ? atoi(v) : 0; }();
     if (forced >= 16 && forced <= 108) return forced & ~3;
     // blocks of 64 rows = the GEMM tile: no padded MFMA work, and with the merged left-looking launches the extra block columns
     // cost little (N = 420: 7 blocks of 64 beat 4 blocks of 105 by 5 %; N = 320: 5 exact blocks)

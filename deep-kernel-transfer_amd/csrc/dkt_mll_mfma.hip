@@ -665,27 +665,37 @@ void launch_mfma(const MllArgs& a, hipStream_t st) {
     constexpr int EPW = mfma_epw<NT>();
     const int epw = EPW;
     const dim3 grid((a.B + epw - 1) / epw), block(64 * wpg * epw);
-    if (g && c && wpg == 5) hipLaunchKernelGGL((mll_mfma_kernel<NT, true, true, true>), grid, block, 0, st, a, wpg);
-    else if (g && c) hipLaunchKernelGGL((mll_mfma_kernel<NT, true, true, false>), grid, block, 0, st, a, wpg);
-    else if (g && wpg == 5) hipLaunchKernelGGL((mll_mfma_kernel<NT, true, false, true>), grid, block, 0, st, a, wpg);
+    if (g && c && wpg == 5) { hipLaunchKernelGGL((mll_mfma_kernel<NT, true, true, true>), grid, block, 0, st, a, wpg); return; }
+    if (g && c) { hipLaunchKernelGGL((mll_mfma_kernel<NT, true, true, false>), grid, block, 0, st, a, wpg); return; }
+    if (c) { hipLaunchKernelGGL((mll_mfma_kernel<NT, false, true, false>), grid, block, 0, st, a, wpg); return; }
+#ifdef DKT_TWINS         // without the Cholesky output this kernel is the exact-fp32 twin of dkt_mll_h2.hip (DKT_MLL_FORCE_F32MFMA)
+    if (g && wpg == 5) hipLaunchKernelGGL((mll_mfma_kernel<NT, true, false, true>), grid, block, 0, st, a, wpg);
     else if (g) hipLaunchKernelGGL((mll_mfma_kernel<NT, true, false, false>), grid, block, 0, st, a, wpg);
-    else if (c) hipLaunchKernelGGL((mll_mfma_kernel<NT, false, true, false>), grid, block, 0, st, a, wpg);
     else hipLaunchKernelGGL((mll_mfma_kernel<NT, false, false, false>), grid, block, 0, st, a, wpg);
+#endif
 }
 
 }  // namespace
 
+// The product library serves DKT_MLL_WANT_CHOL here for N + 1 <= 32 (the regression head's conditioning sets, DKT_regression.py:84-93: 5 .. 19 rows; larger
+// requests take the generic kernel) and nothing else; the twins library (-DDKT_TWINS) has every size with and without the Cholesky output -- the exact-fp32
+// twin of the f16-split kernels.  Returns false when the call is not served.
 bool dkt_mll_mfma_launch(const MllArgs& a, hipStream_t st) {
     const int nt = (a.N + 1 + 15) / 16;
+#ifndef DKT_TWINS
+    if (!(a.flags & DKT_MLL_WANT_CHOL) || nt > 2) return false;
+#endif
     switch (nt) {
         case 1: launch_mfma<1>(a, st); return true;
         case 2: launch_mfma<2>(a, st); return true;
+#ifdef DKT_TWINS
         case 3: launch_mfma<3>(a, st); return true;
         case 4: launch_mfma<4>(a, st); return true;
         case 5: launch_mfma<5>(a, st); return true;
         case 6: launch_mfma<6>(a, st); return true;
         case 7: launch_mfma<7>(a, st); return true;
         case 8: launch_mfma<8>(a, st); return true;
+#endif
         default: return false;
     }
 }

@@ -86,9 +86,14 @@ void dkt_chol_inv_block_launch(const float* A, int lda, long sA, float* L, int l
         case 2: hipLaunchKernelGGL((chol_inv_block_kernel<2>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
         case 3: hipLaunchKernelGGL((chol_inv_block_kernel<3>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
         case 4: hipLaunchKernelGGL((chol_inv_block_kernel<4>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
+        // blocks of the blocked path are nb = 64 rows (the last one of a matrix fewer): NT <= 5; larger blocks only with the measurement switch DKT_BIG_NB
+#ifdef DKT_TWINS
         case 5: hipLaunchKernelGGL((chol_inv_block_kernel<5>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
         case 6: hipLaunchKernelGGL((chol_inv_block_kernel<6>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
         case 7: hipLaunchKernelGGL((chol_inv_block_kernel<7>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
         default: hipLaunchKernelGGL((chol_inv_block_kernel<8>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
+#else
+        default: hipLaunchKernelGGL((chol_inv_block_kernel<5>), dim3(nmat), dim3(256), 0, st, A, lda, sA, L, ldl, sL, U, ldu, sU, nb, pivot_base, info); break;
+#endif
     }
 }

@@ -1351,7 +1351,7 @@ inline bool invres_fits(const WRanges& r, const int NT) {
 int g_tiled_wnw = -1;
 inline int tiled_wnw() {                   // DKT_MLL_TILED_WNW: waves per workgroup of the W kernel (4: two workgroups per CU; 8: one, wider column ranges; 84: 8 for the first range, 4 for the rest; 0 / unset: by NT)
     if (g_tiled_wnw < 0) {
-        const char* v = getenv("DKT_MLL_TILED_WNW");
+        const char* v = dkt_variant_env("DKT_MLL_TILED_WNW");
         const int w = v ? atoi(v) : 0;
         g_tiled_wnw = (w == 8 || w == 4 || w == 84) ? w : 0;
     }
@@ -1360,7 +1360,7 @@ inline int tiled_wnw() {                   // DKT_MLL_TILED_WNW: waves per workg
 int g_tiled_wdma = -1;
 inline bool tiled_wdma() {
     if (g_tiled_wdma < 0) {
-        const char* v = getenv("DKT_MLL_TILED_WDMA");
+        const char* v = dkt_variant_env("DKT_MLL_TILED_WDMA");
         g_tiled_wdma = (v && v[0] == '0') ? 0 : 1;
     }
     return g_tiled_wdma != 0;
@@ -1369,7 +1369,7 @@ inline bool tiled_wdma() {
 int g_tiled_wgs = -1;
 inline int tiled_wgs() {
     if (g_tiled_wgs < 0) {
-        const char* v = getenv("DKT_MLL_TILED_WGS");
+        const char* v = dkt_variant_env("DKT_MLL_TILED_WGS");
         g_tiled_wgs = (v && v[0] == '2') ? 2 : 3;
     }
     return g_tiled_wgs;
@@ -1378,7 +1378,7 @@ inline int tiled_wgs() {
 int g_tiled_invres = -1;
 inline bool tiled_invres() {
     if (g_tiled_invres < 0) {
-        const char* v = getenv("DKT_MLL_TILED_INVRES");                      // default OFF: measured at parity with the block-column kernel (7.3 vs 6.5 ms at
+        const char* v = dkt_variant_env("DKT_MLL_TILED_INVRES");                      // default OFF: measured at parity with the block-column kernel (7.3 vs 6.5 ms at
         g_tiled_invres = (v && v[0] == '1') ? 1 : 0;                           // N = 420, 4.0 vs 4.1 at N = 320: 65 short steps per matrix)
     }
     return g_tiled_invres != 0;
@@ -1387,7 +1387,7 @@ inline bool tiled_invres() {
 int g_tiled_wres = -1;
 inline bool tiled_wres() {
     if (g_tiled_wres < 0) {
-        const char* v = getenv("DKT_MLL_TILED_WRES");
+        const char* v = dkt_variant_env("DKT_MLL_TILED_WRES");
         g_tiled_wres = (v && v[0] == '0') ? 0 : 1;
     }
     return g_tiled_wres != 0;
@@ -1396,7 +1396,7 @@ inline bool tiled_wres() {
 int g_tiled_f16 = -1;
 inline bool tiled_f16() {
     if (g_tiled_f16 < 0) {
-        const char* v = getenv("DKT_MLL_TILED_F16");
+        const char* v = dkt_variant_env("DKT_MLL_TILED_F16");
         g_tiled_f16 = (v && v[0] == '0') ? 0 : 1;
     }
     return g_tiled_f16 != 0;
@@ -1439,7 +1439,9 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     //  block row on, dkt_mll_tiled_factor_row.inc: 6.46 vs 7.05 ms; with MC columns throughout 7.03.  Two K steps' operands at 3 workgroups, where they fit
     //  (MC - 1 <= 5): 4.2 vs 4.0 ms, not used)
     if (msplit && tiled_wgs() >= 3) hipLaunchKernelGGL((tiled_factor_kernel<MC, true, 3>), fgrid, blk, 0, st, t);
+#ifdef DKT_TWINS
     else if (msplit) hipLaunchKernelGGL((tiled_factor_kernel<MC, true, 2>), fgrid, blk, 0, st, t);
+#endif
     else hipLaunchKernelGGL((tiled_factor_kernel<MC, false, 2>), fgrid, blk, 0, st, t);
 #ifdef DKT_TILED_CLOCKS
     return;
@@ -1454,17 +1456,20 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+#ifdef DKT_TWINS
             (void)hipFuncSetAttribute((const void*)tiled_wres_kernel<WRES_MAXC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
             (void)hipFuncSetAttribute((const void*)tiled_invres_kernel<WRES_MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 1024 + 1024);
+#endif
             attr_set = true;
         }
+#ifdef DKT_TWINS         // the resident invert (measured at parity) and the two-workgroups-per-CU build
         if (tiled_invres() && invres_fits(rg, t.NT) && !t.per_class) {
             for (int gq = 0; gq < rg.ng; ++gq) hipLaunchKernelGGL((tiled_invres_kernel<WRES_MAXC>), dim3(nmat), dim3(256), (size_t)2 * 32 * 1024, st, t, rg, gq);
-        } else if (tiled_wgs() >= 3) {
-            hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true, 3>), dim3(nmat), blk, 0, st, t);
-        } else {
+        } else if (tiled_wgs() < 3) {
             hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true>), dim3(nmat), blk, 0, st, t);
-        }
+        } else
+#endif
+        hipLaunchKernelGGL((tiled_invert_kernel<MC, true, true, 3>), dim3(nmat), blk, 0, st, t);
         const int units = t.per_class ? nmat : bcnt;
         // 8 waves when that makes W ONE column range where 4 waves need two (17 <= NT <= 21, N = 256 .. 335): 231 instead of 311 tile reads per matrix at NT = 21,
         // W 2.6 -> 1.9 ms per 1024 N = 320 episodes.  Where 8 waves still need two ranges the single workgroup per CU loses (NT = 27: W 4.0 -> 5.9 ms: each step's
@@ -1497,10 +1502,13 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
             hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8)), dim3(256), lds, st, t, rb);
             return;
         }
-        if (tiled_wdma()) hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
-        else hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
+#ifdef DKT_TWINS
+        if (!tiled_wdma()) { hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, false>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg); return; }
+#endif
+        hipLaunchKernelGGL((tiled_wres_kernel<WRES_MAXC, true>), dim3(8 * ((units + 7) / 8) * rg.ng), dim3(256), lds, st, t, rg);
         return;
     }
+#ifdef DKT_TWINS             // rounds 2 - 3: fp32 tile arrays, block-column W (DKT_MLL_TILED_WRES=0 / DKT_MLL_TILED_F16=0; also what served C > 64 until round 5)
     if (t.per_class) return;                                                 // (unreachable outside the traffic-only measurement build)
     hipLaunchKernelGGL((tiled_invert_kernel<MC, true, false>), dim3(nmat), blk, 0, st, t);
     // Block-column W (rounds 2-3).  Block columns of 8 tile columns with 8 waves (WB = 8: 880 instead of 1232 tile reads per class matrix at
@@ -1508,13 +1516,19 @@ void tiled_chunk(const TiledArgs& t, int bcnt, bool grad, hipStream_t st) {
     const dim3 wgrid(8 * ((bcnt + 7) / 8) * ((t.NT + TB - 1) / TB));
     if (tiled_f16() && t.a.C <= 64) hipLaunchKernelGGL((tiled_w_kernel<MC, true, 4>), wgrid, blk, 0, st, t);
     else hipLaunchKernelGGL((tiled_w_kernel<MC, false, 4>), wgrid, blk, 0, st, t);
+#endif
 }
 
 }  // namespace
 
 void dkt_mll_tiled_reload_env() { g_tiled_f16 = -1; g_tiled_chunk = -1; g_tiled_wres = -1; g_tiled_invres = -1; g_tiled_wgs = -1; g_tiled_wdma = -1; g_tiled_wnw = -1; }      // dkt_reload_env()
 
-bool dkt_mll_tiled_supports(int N, unsigned flags) {
+bool dkt_mll_tiled_supports(int N, unsigned flags, int C) {
+#ifndef DKT_TWINS
+    // the product pipeline (f16-split tile arrays, W with resident accumulators) folds the class weights into split scales for up to 64 classes; a call with
+    // gradients for more shared-matrix classes takes the blocked path
+    if ((flags & DKT_MLL_WANT_GRAD) && !(flags & DKT_MLL_E_PER_CLASS) && C > 64) return false;
+#endif
     return N + 1 > 128 && tiled_nt(N) <= 4 * 7 && !(flags & DKT_MLL_WANT_CHOL);      // N <= 447 (N + 1 <= 448 = 28 tiles): 4 x 7 register tiles per wave without spills
 }
 

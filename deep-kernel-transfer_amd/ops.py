@@ -106,20 +106,36 @@ class _timed:
 # ------------------------------------------------------------------------------------------------
 # raw (non-differentiable) entry points
 # ------------------------------------------------------------------------------------------------
-_ENV_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_EP_MINB", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR",
-                 "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR", "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_F16",
-                 "DKT_GRAM_DIST_EP", "DKT_MLL_F32MFMA", "DKT_MLL_P2_GUARD", "DKT_MLL_TILED_CHUNK", "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA", "DKT_CLASS_BWD_V4", "DKT_MLL_TILED_WNW")
-_env_seen = None
+# Switches the PRODUCT library reads (dispatch thresholds / the process-wide exact-fp32 request of include/dkt_abi.h); everything else is a variant switch that only
+# the twins library (libdkt_twins.so, -DDKT_TWINS) knows: with DKT_TWINS=1 in the environment AND one of them set, the calls of this module go to that library
+# (tests, A/B tools).  Without DKT_TWINS=1 the variant switches have no effect at all.
+_PRODUCT_SWITCHES = ("DKT_GRAM_EP_MINB", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_CHUNK", "DKT_MLL_F32MFMA")
+_VARIANT_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR", "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR",
+                     "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_TILED_F16", "DKT_GRAM_DIST_EP", "DKT_MLL_P2_GUARD",
+                     "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA", "DKT_CLASS_BWD_V4",
+                     "DKT_MLL_TILED_WNW", "DKT_GRAM_SMALL", "DKT_BIG_NB")
+_ENV_SWITCHES = _PRODUCT_SWITCHES + _VARIANT_SWITCHES
+_env_seen = {}
 
 
 def _sync_env(lib) -> None:
-    """The library reads its measurement switches once; when a test or an A/B tool changed one inside this process, tell it."""
-    global _env_seen
+    """The library reads its switches once; when a test or an A/B tool changed one inside this process, tell it."""
     cur = tuple(os.environ.get(k) for k in _ENV_SWITCHES)
-    if cur != _env_seen:
-        if _env_seen is not None or any(v is not None for v in cur):
+    seen = _env_seen.get(id(lib))
+    if cur != seen:
+        if seen is not None or any(v is not None for v in cur):
             lib.dkt_reload_env()
-        _env_seen = cur
+        _env_seen[id(lib)] = cur
+
+
+def _lib_now(want_twin: bool = False):
+    """The library this call goes to: the product, or -- DKT_TWINS=1 and a variant switch set (or `want_twin`: a call that names a validation twin the
+    product library serves with its generic kernel, e.g. force_f32mfma) -- the twins build of the same ABI."""
+    if os.environ.get("DKT_TWINS") == "1" and (want_twin or os.environ.get("DKT_MLL_F32MFMA") == "1" or any(os.environ.get(k) is not None for k in _VARIANT_SWITCHES)):
+        lib = _lib.load_twins()
+    else:
+        lib = _lib_now()
+    return lib
 
 
 def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_LINEAR,
@@ -137,8 +153,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
     if kind not in (KERNEL_LINEAR, KERNEL_LINEAR_UNIT):
         lengthscale = _req(lengthscale.reshape(-1), "lengthscale", 1)
     e = torch.empty((b_, m, n), device=a.device, dtype=torch.float32)
-    lib = _lib.load()
-    _sync_env(lib)
+    lib = _lib_now()
     with _timed("dkt_gram_f32"):
         st = lib.dkt_gram_f32(_p(a), _p(bm), _p(e), b_, m, n, d, kind, _p(lengthscale), _stream())
     _lib.check(st, "dkt_gram_f32")
@@ -205,8 +220,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
                                        _p(jit), _p(info), _stream())
         _lib.check(st, "dkt_diag_mll_reg_f32")
         return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
-    lib = _lib.load()
-    _sync_env(lib)
+    lib = _lib_now(want_twin=force_f32mfma)
     ws_bytes = int(lib.dkt_mll_workspace_bytes(b_, c_, n))
     ws = torch.empty((max(ws_bytes, 4) + 3) // 4, device=dev, dtype=torch.float32) if ws_bytes else None
     with _timed("dkt_mll_f32"):
@@ -233,8 +247,7 @@ def gram_bwd(w: torch.Tensor, z: torch.Tensor, ep_scale: Optional[torch.Tensor] 
         if ep_scale.numel() != b_:
             raise RuntimeError("gram_bwd: ep_scale must have B elements")
     dz = torch.empty_like(z)
-    lib = _lib.load()
-    _sync_env(lib)
+    lib = _lib_now()
     with _timed("dkt_gram_bwd_f32"):
         st = lib.dkt_gram_bwd_f32(_p(w), _p(z), _p(dz), b_, n, d, _p(ep_scale),
                                   (GRAM_UNIT_ROWS if unit_rows else 0) | (GRAM_W_SYMMETRIC if w_symmetric else 0), _stream())
@@ -249,7 +262,7 @@ def rbf_bwd(w: torch.Tensor, e: torch.Tensor, lengthscale: torch.Tensor):
     b_, n, _ = e.shape
     wp = torch.empty_like(e)
     dl = torch.empty((b_,), device=e.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_rbf_bwd_f32"):
         st = lib.dkt_rbf_bwd_f32(_p(w), _p(e), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream())
     _lib.check(st, "dkt_rbf_bwd_f32")
@@ -263,7 +276,7 @@ def sqdist_bwd(w: torch.Tensor, u: torch.Tensor, lengthscale: torch.Tensor):
     b_, n, _ = u.shape
     wp = torch.empty_like(u)
     dl = torch.empty((b_,), device=u.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     _lib.check(lib.dkt_sqdist_bwd_f32(_p(w), _p(u), _p(lengthscale), _p(wp), _p(dl), b_, n, _stream()), "dkt_sqdist_bwd_f32")
     return wp, dl
 
@@ -303,7 +316,7 @@ def predict(ex: torch.Tensor, alpha: torch.Tensor, sv: torch.Tensor, mean: torch
     mean = _req(mean.reshape(-1), "mean", 1)
     mu = torch.empty((b_, c_, m), device=ex.device, dtype=torch.float32)
     labels = torch.empty((b_, m), device=ex.device, dtype=torch.int32) if want_labels else None
-    lib = _lib.load()
+    lib = _lib_now()
     fn, name = (lib.dkt_predict_per_class_f32, "dkt_predict_per_class_f32") if per_class else (lib.dkt_predict_f32, "dkt_predict_f32")
     _lib.check(fn(_p(ex), _p(alpha), _p(sv), _p(mean), _p(mu), _p(labels), b_, c_, m, n, _stream()), name)
     return mu, labels
@@ -318,7 +331,7 @@ def predict_var(ex: torch.Tensor, exx: torch.Tensor, chol: torch.Tensor, sv: tor
     sv = _req(sv.reshape(-1), "sv", 1)
     noise = _req(noise.reshape(-1), "noise", 1)
     var = torch.empty((b_, c_, m), device=ex.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     _lib.check(lib.dkt_predict_var_f32(_p(ex), _p(exx), _p(chol), _p(sv), _p(noise), _p(var), b_, c_, m, n, _stream()),
                "dkt_predict_var_f32")
     return var
@@ -345,7 +358,7 @@ def smk(x1: torch.Tensor, x2: Optional[torch.Tensor], weights: torch.Tensor, mea
         raise RuntimeError("smk: means / scales must be [Q,D] with D = %d" % d)
     e = torch.empty((b_, m, n), device=x1.device, dtype=torch.float32)
     eq = torch.empty((b_, q, m, n), device=x1.device, dtype=torch.float32) if want_terms else None
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_smk_f32"):
         st = lib.dkt_smk_f32(_p(x1), _p(x2), _p(weights), _p(means), _p(scales), _p(e), _p(eq), b_, m, n, d, q, _stream())
     _lib.check(st, "dkt_smk_f32")
@@ -366,7 +379,7 @@ def smk_bwd(ge: torch.Tensor, eq: torch.Tensor, x: torch.Tensor, weights: torch.
     dx = torch.empty_like(x)
     dmeans = torch.empty((b_, q, d), device=x.device, dtype=torch.float32)
     dscales = torch.empty((b_, q, d), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_smk_bwd_f32"):
         st = lib.dkt_smk_bwd_f32(_p(ge), _p(eq), _p(x), _p(weights), _p(means), _p(scales), _p(dx), _p(dmeans), _p(dscales),
                                  b_, n, d, q, _stream())
@@ -464,7 +477,7 @@ def class_kernel(base: torch.Tensor, cmap: int, power: int, param: torch.Tensor)
     b_, c = base.shape[0], param.numel()
     nn = base[0].numel()
     e = torch.empty((b_, c) + tuple(base.shape[1:]), device=base.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_class_kernel_f32"):
         st = lib.dkt_class_kernel_f32(_p(base), int(cmap), _p(param), int(power), _p(e), b_, c, nn, _stream())
     _lib.check(st, "dkt_class_kernel_f32")
@@ -481,8 +494,7 @@ def class_kernel_bwd(w: torch.Tensor, base: torch.Tensor, cmap: int, power: int,
     if tuple(base.shape) != (b_, n, n) or param.numel() != c:
         raise RuntimeError("class_kernel_bwd: base must be [B,N,N] and param [C]")
     wp = torch.empty_like(base)
-    lib = _lib.load()
-    _sync_env(lib)
+    lib = _lib_now()
     nsplit = int(lib.dkt_class_kernel_bwd_nsplit(b_, n))
     dparam = torch.empty((b_, nsplit, c), device=w.device, dtype=torch.float32)
     with _timed("dkt_class_kernel_bwd_f32"):
@@ -691,7 +703,7 @@ def _lowrank_forward(z, y, sv_, mean_, noise_in, cw_, jitter0, max_tries, unit_r
     else:
         raise RuntimeError("episode_loss_linear: y must be [C,N] or [B,C,N]")
     dev = z.device
-    lib = _lib.load()
+    lib = _lib_now()
     # the rung of the jitter ladder that lifts the noise floor of the (rank-deficient) N x N matrix above fp32 rounding -- 0 for any sane noise; rows that
     # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T
     zmax2 = None if unit_rows else z.square().sum(2).amax().reshape(1).contiguous()
@@ -724,7 +736,7 @@ def _lowrank_backward(z, v, t, wd, gobj) -> torch.Tensor:
     """dZ[b] = gobj[b] (V^T T + 2 Z W')  (dkt_lowrank_bwd_f32)."""
     b_, n, d = z.shape
     dz = torch.empty_like(z)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_lowrank_bwd_f32"):
         st = lib.dkt_lowrank_bwd_f32(_p(z), _p(v), _p(t), _p(wd), _p(_req(gobj.reshape(-1), "gobj", 1)), _p(dz), b_, v.shape[1], n, d, _stream())
     _lib.check(st, "dkt_lowrank_bwd_f32")
@@ -776,7 +788,7 @@ def bn_stats(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torc
     gamma = None if gamma is None else _req(gamma.reshape(-1), "gamma", 1)
     beta = None if beta is None else _req(beta.reshape(-1), "beta", 1)
     out = {k: torch.empty((b_, d), device=x.device, dtype=torch.float32) for k in ("mean", "rstd", "a", "s", "var_unbiased")}
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_bn_stats_f32"):
         st = lib.dkt_bn_stats_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(out["mean"]), _p(out["rstd"]), _p(out["a"]),
                                   _p(out["s"]), _p(out["var_unbiased"]), b_, n, d, _stream())
@@ -805,7 +817,7 @@ def gram_bn(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
     stride = _ab_stride(a, s, b_, d)
     e = torch.empty((b_, n, n), device=x.device, dtype=torch.float32)
     rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_gram_bn_f32"):
         st = lib.dkt_gram_bn_f32(_p(x), _p(a), _p(s), stride, _p(e), _p(rnorm), b_, n, d, _stream())
     _lib.check(st, "dkt_gram_bn_f32")
@@ -824,7 +836,7 @@ def gram_bn_train(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
     out = {k: torch.empty((b_, d), device=x.device, dtype=torch.float32) for k in ("mean", "rstd", "a", "s", "var_unbiased")}
     e = torch.empty((b_, n, n), device=x.device, dtype=torch.float32)
     rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_gram_bn_train_f32"):
         st = lib.dkt_gram_bn_train_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(out["mean"]), _p(out["rstd"]), _p(out["a"]),
                                        _p(out["s"]), _p(out["var_unbiased"]), _p(e), _p(rnorm), b_, n, d, _stream())
@@ -852,7 +864,7 @@ def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
     dx = torch.empty_like(x)
     dg = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
     db = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_gram_bn_bwd_f32"):
         st = lib.dkt_gram_bn_bwd_f32(_p(w), _p(e), _p(x), _p(a), _p(s), stride, _p(mean), _p(rstd), _p(rnorm), _p(ep_scale),
                                      _p(dx), _p(dg), _p(db), b_, n, d, _stream())
@@ -870,7 +882,7 @@ def affine_normalize(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
     stride = _ab_stride(a, s, b_, d)
     zn = torch.empty_like(x)
     rnorm = torch.empty((b_, n), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_affine_normalize_f32"):
         st = lib.dkt_affine_normalize_f32(_p(x), _p(a), _p(s), stride, _p(zn), _p(rnorm), b_, n, d, _stream())
     _lib.check(st, "dkt_affine_normalize_f32")
@@ -895,7 +907,7 @@ def normalize_bn_bwd(dzn, zn, x, a, rnorm, mean=None, rstd=None):
     dg = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
     db = torch.empty((b_, d), device=x.device, dtype=torch.float32) if train else None
     ws = torch.empty((b_, n), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
+    lib = _lib_now()
     with _timed("dkt_normalize_bn_bwd_f32"):
         st = lib.dkt_normalize_bn_bwd_f32(_p(dzn), _p(zn), _p(x), _p(a), stride, _p(mean), _p(rstd), _p(rnorm), _p(dx), _p(dg), _p(db), _p(ws), b_, n, d, _stream())
     _lib.check(st, "dkt_normalize_bn_bwd_f32")

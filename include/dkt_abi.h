@@ -56,15 +56,23 @@ extern "C" {
 
 /* mll flags */
 #define DKT_MLL_WANT_GRAD 1u /* also produce W (d obj / d E) and the per-class hyper grads */
-#define DKT_MLL_WANT_CHOL 2u /* also write the Cholesky factors L[B,C,N,N]                  */
+#define DKT_MLL_WANT_CHOL 2u /* also write the Cholesky factors L[B,C,N,N] (what dkt_predict_var_f32 / confidence_region need: the regression head conditions on
+                                5 .. 19 rows, DKT_regression.py:84-93).  Served by the exact-fp32 MFMA kernel for N <= 31, the generic kernel for 32 <= N <= 127, the
+                                blocked path above */
 #define DKT_MLL_FORCE_GENERIC 4u /* validation aid: take the generic LDS/global path for any N  */
 #define DKT_MLL_FORCE_REG 8u     /* RETIRED in ABI 3 (dkt_mll_f32 answers DKT_ERR_BAD_ARG): the round-1 register-sweep kernel is a validation twin in the
                                     measurement library now (libdkt_diag.so: dkt_diag_mll_reg_f32), not part of the product */
 #define DKT_MLL_FORCE_BLOCKED 16u /* validation aid: the blocked batched-GEMM path instead of the tile-array kernels (N > 127) */
-#define DKT_MLL_FORCE_F32MFMA 32u /* validation aid: the exact-fp32 MFMA wave-per-matrix kernel instead of the f16-split one (N <= 127) */
+#define DKT_MLL_FORCE_F32MFMA 32u /* exact-fp32 arithmetic instead of the f16-split kernels (N <= 127; no range contract, see below).  The product library serves it
+                                     with its generic exact-fp32 kernel; the exact-fp32 MFMA twin of the split kernels lives in the twins library */
 #define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */
 
 int dkt_abi_version(void);
+
+/* Two builds of this ABI exist.  libdkt_hip.so, the PRODUCT: one kernel per (call, shape class), no measurement switch -- the only environment variables it reads
+ * are the dispatch thresholds DKT_GRAM_EP_MINB, DKT_MLL_H2E_MINB, DKT_MLL_TILED_CHUNK and the process-wide exact-fp32 request DKT_MLL_F32MFMA=1.
+ * libdkt_twins.so (the same sources compiled with -DDKT_TWINS): in addition every pipeline variant, legacy pipeline and validation twin the defaults were
+ * measured against, selected by the environment switches of DESIGN.md's appendix; loaded by the test-suite and the A/B tools only. */
 
 /* The library reads its measurement / validation switches (environment variables) once, at the first call that needs
  * them; a host that changed one inside a running process (tests, A/B tools) calls this to have them re-read.  No effect on results of the

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The tests are the consumers of the validation twins: with DKT_TWINS=1 a test that sets one of the variant switches (ops._VARIANT_SWITCHES) is served by
+# libdkt_twins.so (the same sources with -DDKT_TWINS); every other call -- and every call of a user process -- goes to the product library, which has no switches.
+os.environ.setdefault("DKT_TWINS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

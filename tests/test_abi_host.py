@@ -46,6 +46,28 @@ def test_argument_errors_do_not_launch(lib):
     assert lib.dkt_mll_workspace_bytes(1, 20, 420) >= 2 * 20 * (27 * 28 // 2) * 1024
 
 
+def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches():
+    """libdkt_twins.so = the same sources with -DDKT_TWINS: every symbol of the header, the same ABI version.  The product library must not read a variant
+    switch: its binary contains none of their names (they are compiled out), only the four documented product switches."""
+    twins = dkt_amd._lib.load_twins()
+    assert twins.dkt_abi_version() == dkt_amd._lib.abi_version_of_header()
+    for name in dkt_amd._lib.SIGNATURES:
+        assert hasattr(twins, name), name
+    prod = open(dkt_amd._lib.LIB_PATH, "rb").read()
+    twin = open(dkt_amd._lib.TWINS_LIB_PATH, "rb").read()
+    for name in dkt_amd.ops._VARIANT_SWITCHES:
+        assert name.encode() + b"\0" not in prod, name
+    for name in ("DKT_GRAM_UNIT_VAR", "DKT_MLL_TILED_WRES", "DKT_GRAM_SPLIT"):
+        assert name.encode() + b"\0" in twin, name
+    for name in dkt_amd.ops._PRODUCT_SWITCHES:
+        assert name.encode() + b"\0" in prod, name
+    upath = os.path.join(os.path.dirname(dkt_amd._lib.LIB_PATH), "build", "libdkt_hip.so.resource_usage.json")       # written by the build in this checkout
+    if os.path.exists(upath):
+        usage = __import__("json").load(open(upath))
+        assert len(usage) <= 230 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
+        assert dkt_amd._lib.check_resources(usage) == []
+
+
 def test_per_class_path_sizes():
     """Which (N, C) the one-launch per-class path serves (ops.mll_per_class_supported mirrors dkt_mll_f32 with DKT_MLL_E_PER_CLASS and dkt_class_kernel_bwd_f32)."""
     ok = dkt_amd.ops.mll_per_class_supported
