@@ -134,7 +134,8 @@ def _lib_now(want_twin: bool = False):
     if os.environ.get("DKT_TWINS") == "1" and (want_twin or os.environ.get("DKT_MLL_F32MFMA") == "1" or any(os.environ.get(k) is not None for k in _VARIANT_SWITCHES)):
         lib = _lib.load_twins()
     else:
-        lib = _lib_now()
+        lib = _lib.load()
+    _sync_env(lib)
     return lib
 
 

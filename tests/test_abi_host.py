@@ -68,6 +68,24 @@ def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches()
         assert dkt_amd._lib.check_resources(usage) == []
 
 
+def test_library_selection_product_unless_twins_are_asked_for(monkeypatch):
+    """ops._lib_now(): the product library for every call, the twins library only with DKT_TWINS=1 AND (a variant switch set | the call names a twin)."""
+    ops, L = dkt_amd.ops, dkt_amd._lib
+    for k in ops._VARIANT_SWITCHES + ("DKT_MLL_F32MFMA",):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DKT_TWINS", "1")
+    assert ops._lib_now()._name == L.LIB_PATH
+    assert ops._lib_now(want_twin=True)._name == L.TWINS_LIB_PATH
+    monkeypatch.setenv("DKT_GRAM_UNIT_VAR", "2223")
+    assert ops._lib_now()._name == L.TWINS_LIB_PATH
+    monkeypatch.setenv("DKT_TWINS", "0")
+    assert ops._lib_now()._name == L.LIB_PATH and ops._lib_now(want_twin=True)._name == L.LIB_PATH      # no opt-in: the variant switches have no effect
+    monkeypatch.delenv("DKT_GRAM_UNIT_VAR")
+    monkeypatch.setenv("DKT_TWINS", "1")
+    monkeypatch.setenv("DKT_MLL_H2E_MINB", "1")                  # a product switch: stays on the product library
+    assert ops._lib_now()._name == L.LIB_PATH
+
+
 def test_per_class_path_sizes():
     """Which (N, C) the one-launch per-class path serves (ops.mll_per_class_supported mirrors dkt_mll_f32 with DKT_MLL_E_PER_CLASS and dkt_class_kernel_bwd_f32)."""
     ok = dkt_amd.ops.mll_per_class_supported
