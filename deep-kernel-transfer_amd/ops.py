@@ -130,8 +130,10 @@ def _sync_env(lib) -> None:
 
 def _lib_now(want_twin: bool = False):
     """The library this call goes to: the product, or -- DKT_TWINS=1 and a variant switch set (or `want_twin`: a call that names a validation twin the
-    product library serves with its generic kernel, e.g. force_f32mfma) -- the twins build of the same ABI."""
-    if os.environ.get("DKT_TWINS") == "1" and (want_twin or os.environ.get("DKT_MLL_F32MFMA") == "1" or any(os.environ.get(k) is not None for k in _VARIANT_SWITCHES)):
+    product library serves with its generic kernel, e.g. force_f32mfma) -- the twins build of the same ABI.  DKT_TWINS=force: the twins build for every call."""
+    if os.environ.get("DKT_TWINS") == "force":                # (tests of the twins library's own instantiations)
+        lib = _lib.load_twins()
+    elif os.environ.get("DKT_TWINS") == "1" and (want_twin or os.environ.get("DKT_MLL_F32MFMA") == "1" or any(os.environ.get(k) is not None for k in _VARIANT_SWITCHES)):
         lib = _lib.load_twins()
     else:
         lib = _lib.load()

@@ -399,6 +399,7 @@ def test_mll_mfma_kernel_against_register_twin(cuda, c, per, d, corr, monkeypatc
     """The default wave-per-matrix MFMA kernel and the register-sweep twin are different algorithms (upper blocked
     factorisation on the matrix pipe vs a right-looking sweep on the VALU): every output must agree to rounding, with and
     without the gradient / Cholesky outputs (different template instantiations), C > 5 running the classes in rounds."""
+    monkeypatch.setenv("DKT_TWINS", "force")             # every instantiation of the MFMA kernel lives in the twins library (the product keeps the Cholesky-output ones for N <= 31)
     z, hyp, n = _episode_case(c, per, d, 5 + n_hash(c, per, d), corr, b=3)
     y = dev_t(O.one_vs_rest_targets(c, per), cuda)
     cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
