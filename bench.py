@@ -457,7 +457,15 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
         dt = (time.perf_counter() - t0) / steps
         kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
         ops.kernel_timing(False)
-        res[name] = {"value": round(nb / dt, 1), "unit": "episodes/s", "episodes_per_step": nb, "ms_per_step": round(1e3 * dt, 4),
+        # algorithmic bytes per episode of the calls of these paths (include/dkt_abi.h contracts: every operand once) -> HBM roofline per kernel
+        nn, nd = 4 * n * n, 4 * n * d
+        alg_b = {"dkt_gram_bn_train_f32": nd + nn + 4 * n + 20 * d, "dkt_gram_bn_bwd_f32": 2 * nn + 2 * nd + 4 * n + 24 * d, "dkt_bn_stats_f32": nd + 20 * d,
+                 "dkt_affine_normalize_f32": 2 * nd + 4 * n + 8 * d, "dkt_normalize_bn_bwd_f32": 4 * nd + 4 * n + 24 * d, "dkt_gram_f32": nd + nn,
+                 "dkt_gram_bwd_f32": nn + 2 * nd, "dkt_class_kernel_f32": nn + c * nn, "dkt_class_kernel_bwd_f32": c * nn + 2 * nn,
+                 "dkt_lowrank_gram_f32": nd + 4 * 64 * (64 + c), "dkt_lowrank_finish_f32": nd + 4 * c * (64 + 2 * n), "dkt_lowrank_bwd_f32": 2 * nd + 4 * 64 * 64 + 4 * c * (n + 64)}
+        roofs = {k: {"bound": "hbm", "achieved": round(alg_b[k] * nb / v / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_b[k] * nb / v / 1e6 / HBM_PEAK_GBS, 4)} for k, v in kt.items() if k in alg_b and v > 0}
+        res[name] = {"value": round(nb / dt, 1), "unit": "episodes/s", "episodes_per_step": nb, "ms_per_step": round(1e3 * dt, 4), "roofline": roofs,
                      "valid": bool(int(info.abs().max().item()) == 0 and (x_rbf if fn is rbf else x).grad is not None
                                    and bool(torch.isfinite((x_rbf if fn is rbf else x).grad).all().item())),
                      "kernels_ms": kt}
@@ -607,8 +615,16 @@ def _kernel_report(cfg, m, unit_rows, traffic):
                          note="algorithmic fp32-equivalent flops / dense f16 MFMA peak (the pipe the K loops and the K^-1 product run on); the kernels are bound by "
                               "their tile streams, see traffic / fabric_gbs")
             other = dict(mat, note="algorithmic fp32-equivalent flops / fp32 MFMA peak (the pipe rounds 1-3 used for the factorisation / inverse; kept for comparison)")
+            # executed f16 MFMA flops of the three K loops: tile products per class matrix (factor sum_{i<=j} i, invert sum_{i<j} (j - i), W sum_{i<=j} (NT - j)) x 3 plane
+            # products x 8192 flop, against the dense f16 peak -- next to the fabric bytes per second against the HBM peak: the kernels are bound by the latter
+            nt = (n + 1 + 15) // 16
+            prods = sum(i for j in range(nt) for i in range(j + 1)) + sum(j - i for j in range(nt) for i in range(j)) + sum(nt - j for j in range(nt) for i in range(j + 1))
+            ex = prods * 3 * 8192.0 * c * b / k["ms"] / 1e9
+            first["executed_tflops"] = round(ex, 1)
+            first["executed_frac"] = round(ex / MFMA_F16_PEAK_TFLOPS, 4)
             if tr:
                 first["fabric_gbs"] = round(tr / k["ms"] / 1e6, 1)
+                first["fabric_frac"] = round(tr / k["ms"] / 1e6 / HBM_PEAK_GBS, 4)
         r = dict(kernel=name, **first, traffic=tr, traffic_unit="bytes/launch (PMC: FETCH_SIZE + WRITE_SIZE at L2<->fabric)",
                  traffic_source=src, algorithmic_bytes_per_launch=alg[name]["bytes"] * b,
                  algorithmic_flops_per_launch=alg[name]["flops"] * b, avg_launch_ms=k["ms"], episodes_per_launch=b)
@@ -674,8 +690,11 @@ def _dominant(kernels, roofs):
         return None
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     r = roofs.get(dom, {})
-    return {"kernel": dom, "ms": kernels[dom]["ms"], "bound": r.get("bound"), "frac": r.get("frac"),
-            "hbm_frac": round(kernels[dom]["gbs"] / HBM_PEAK_GBS, 4)}
+    out = {"kernel": dom, "ms": kernels[dom]["ms"], "bound": r.get("bound"), "frac": r.get("frac"), "hbm_frac": round(kernels[dom]["gbs"] / HBM_PEAK_GBS, 4)}
+    for key in ("executed_frac", "fabric_frac"):
+        if key in r:
+            out[key] = r[key]
+    return out
 
 
 def _write_detail(detail):
@@ -906,7 +925,9 @@ def _line_of(out):
     for key in ("other_paths_cfg2", "other_paths_cfg4"):
         if key in out:
             line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
-                                "kernels_ms": o["kernels_ms"], **({"roofline": o["roofline"]} if "roofline" in o else {})}
+                                "kernels_ms": o["kernels_ms"],
+                                # per kernel: algorithmic bytes / HIP-event time / 8 TB/s (the full roofline objects are in the detail file)
+                                **({"hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}} if "roofline" in o else {})}
                          for name, o in out[key].items()}
     if "test_time_forward" in out:
         line["test_time_forward"] = {k: out["test_time_forward"][k] for k in ("value", "ms_per_step", "episodes_per_step")}
