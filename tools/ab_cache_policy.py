@@ -1,5 +1,6 @@
 """A/B of the cache policy of the two Gram kernels at the headline shape (8192 x 105 x 1600, unit rows): default vs non-temporal
 Z loads / dZ stores, next to the arithmetic-free copy kernels of the same access pattern.  Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import ctypes
 import os
 import sys

@@ -1,5 +1,6 @@
 """A/B of the split variants of the episode-resident Gram kernels on unit-norm rows (cfg2, B = 8192): 3-way bf16 split
 vs 2-way scaled-f16 split; error against float64 and HIP-event time per launch.  Measurement tooling; prints only."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

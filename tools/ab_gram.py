@@ -1,5 +1,6 @@
 """A/B of the episode-resident Gram kernels (exact-fp32 MFMA vs 3-way bf16 split): error against float64 and
 HIP-event time per launch.  Measurement tooling; prints, never asserts."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

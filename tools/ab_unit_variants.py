@@ -1,5 +1,6 @@
 """A/B of the pipeline variants of the unit-row (f16-split) episode-resident Gram kernel at the headline shape (DKT_GRAM_UNIT_VAR,
 DESIGN.md appendix): alternating runs, 30 launches each.  Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dkt_amd

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import dkt_amd

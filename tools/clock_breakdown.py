@@ -1,5 +1,6 @@
 """Phase breakdown of the split Gram forward kernel from the DKT_EXP_CLOCKS measurement build (wave 0 of every workgroup
 accumulates clock64() deltas per phase and dumps them over E[b][0][0:8])."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

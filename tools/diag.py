@@ -1,5 +1,6 @@
 """GPU diagnostics: per-kernel numeric errors vs the oracle + per-kernel timings. Prints, never asserts.
 (test/measurement tooling; may import the oracle)"""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 import time

@@ -1,5 +1,6 @@
 """Large-N Gram backward: the default kernel (128-row blocks) against the 64-row kernel of round 2 at the cfg4 shapes.
 Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

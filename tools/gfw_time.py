@@ -1,4 +1,5 @@
 """Large-N symmetric Gram (unit rows): the episode-resident kernel against the 64 x 64-tile kernel of round 2 at the cfg4 shapes.  Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

@@ -1,4 +1,5 @@
 """Accuracy of dkt_mll_f32 (register kernel vs generic twin) against the float64 oracle at cfg2. Prints, never asserts."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

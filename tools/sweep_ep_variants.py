@@ -1,5 +1,6 @@
 """Sweep of the episode-resident Gram / Gram-backward variants (DKT_GRAM_UNIT_VAR / DKT_GRAM_BWD_UNIT_VAR) at the small-D shapes (cfg1: D = 64, cfg3: D = 512): the
 defaults were tuned at the headline shape (D = 1600).  Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os
 import sys
 

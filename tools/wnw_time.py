@@ -1,4 +1,5 @@
 """W kernel with 8 waves per workgroup: variants of the staged group size (a -DDKT_WRES_NST8=k build) against the default library.  Measurement tooling."""
+import os as _os; _os.environ.setdefault("DKT_TWINS", "1")   # the variant switches this tool flips live in libdkt_twins.so (ops._lib_now)
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
