@@ -12,7 +12,7 @@ Device kernel -> ABI function is an EXPLICIT table (KERNEL_TABLE): a kernel of t
 more than 1 MB per dispatch aborts the run (round 3 matched by substrings and silently summed cfg0's `gram_small_bwd_kernel` into
 dkt_gram_f32).  Kernels of other libraries (torch element-wise glue) are ignored.
 
-usage: python tools/make_traffic_json.py profiles/r04 [profiles/pmc_traffic.json]"""
+usage: python tools/make_traffic_json.py profiles/r04,profiles/r05 [profiles/pmc_traffic.json]     (several directories: a later one overrides a config of an earlier one)"""
 import glob
 import json
 import os
@@ -40,8 +40,11 @@ KERNEL_TABLE = {
     "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",
     "class_kernel_fwd": "dkt_class_kernel_f32", "class_kernel_bwd": "dkt_class_kernel_bwd_f32",
     "predict_kernel": "dkt_predict_f32", "predict_var_kernel": "dkt_predict_var_f32",
+    # the feature-space episode (round 5)
+    "lowrank_gram_kernel": "dkt_lowrank_gram_f32", "lowrank_finish_kernel": "dkt_lowrank_finish_f32", "lowrank_bwd_kernel": "dkt_lowrank_bwd_f32",
+    "lowrank_noise_floor_kernel": "dkt_lowrank_noise_floor_f32",
 }
-OURS = re.compile(r"gram|mll_|tiled_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats")
+OURS = re.compile(r"gram|mll_|tiled_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank")
 
 
 def short_name(kernel: str) -> str:
@@ -69,7 +72,7 @@ def abi_of(kernel: str):
 def main():
     res = {"unit": "bytes per launch (ABI call)",
            "correction": "FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read under-count, 16-byte-per-lane loads) + WRITE_SIZE KB x 1024", "configs": {}}
-    for path in sorted(glob.glob(os.path.join(src_dir, "*_summary.txt"))):
+    for path in [p_ for d_ in src_dir.split(",") for p_ in sorted(glob.glob(os.path.join(d_, "*_summary.txt")))]:
         cfg = os.path.basename(path)[:-len("_summary.txt")]
         episodes = None
         per_kernel = {}                                    # kernel -> {counter: (dispatches, mean)}
