@@ -265,9 +265,17 @@ def load(path: str = None) -> ctypes.CDLL:
         return lib
 
 
+_twins_checked = False
+
+
 def load_twins() -> ctypes.CDLL:
-    """The variant / twin build of the same ABI (tests, A/B tools); built on first use where the sources are present."""
-    return load(build_twins())
+    """The variant / twin build of the same ABI (tests, A/B tools); built on first use where the sources are present (the staleness check -- a content hash of
+    every source -- runs once per process, not per call)."""
+    global _twins_checked
+    if not _twins_checked:
+        build_twins()
+        _twins_checked = True
+    return load(TWINS_LIB_PATH)
 
 
 def load_diag() -> ctypes.CDLL:
