@@ -59,8 +59,9 @@ __global__ __launch_bounds__(64) void lowrank_gram_kernel(const float* __restric
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) accp[ct][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K steps of 4 rows, LR_U at a time: the loads of the next chunk are issued before the products of the current one (a wave keeps
-    // LR_U 1-KB row groups of Z in flight; without it the kernel ran one load per wave at a time: 0.098 -> ms per 8192 cfg1 episodes)
+    // K steps of 4 rows, LR_U at a time: the loads of the next chunk are issued before the products of the current one (a wave keeps LR_U 1-KB row groups
+    // of Z in flight).  At cfg1 (27 K steps) this measures the same as one load in flight at seven waves per SIMD -- 0.097 ms per 8192 episodes either way:
+    // the kernel sits at ~40 % of the fp32 MFMA rate, not on memory latency -- and is kept for long episodes (N = 420: 105 K steps at three waves per SIMD).
     const int nks = (N + 3) >> 2;
     f32x4 va[LR_U];
     float ra[LR_U][NCT];
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(64) void lowrank_gram_kernel(const float* __restric
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 // unconditional load (an out-of-range offset returns 0) and no select on the value: written as `ok ? y - m : 0` hipcc branches around
-                // the load and waits vmcnt(0) inside the branch, which serialises every Z load of the chunk behind it (measured: 0.13 vs ms).  Rows
-                // beyond N multiply zero rows of Z, classes beyond C have mc = 0 and are never stored.
+                // the load and waits vmcnt(0) inside the branch, which serialises every Z load of the chunk behind it (measured: 0.134 vs 0.097 ms per
+                // 8192 cfg1 episodes).  Rows beyond N multiply zero rows of Z, classes beyond C have mc = 0 and are never stored.
                 const int n = 16 * ct + m;
                 const int off = (n < C && row < N) ? (n * N + row) * 4 : OOB;
                 r[u][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, off, 0, 0)) - mc[ct];
