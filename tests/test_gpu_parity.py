@@ -2222,9 +2222,13 @@ def test_test_time_fused_front_end_matches_unfused(cuda, monkeypatch, kernel):
     assert len(used) == 2
 
 
-def test_dkt_20way_train_and_test_use_the_blocked_large_n_path(cuda, capsys):
-    """cfg4 shape through the drop-in class: 20-way 5-shot, 16 queries -> N = 420 in train_loop (tile-array MLL path, the streaming front end of
-    dkt_frontend_big.hip), 100 support / 300 query at test time; the loss of one episode against the float64 restatement."""
+@pytest.mark.parametrize("path", ["feature_space", "nxn"])
+def test_dkt_20way_train_and_test_use_the_blocked_large_n_path(cuda, capsys, path, monkeypatch):
+    """The 20-way shape through the drop-in class: 20-way 5-shot, 16 queries -> N = 420 in train_loop, 100 support / 300 query at test time; the loss of one episode
+    against the float64 restatement.  Conv4S features (D = 64: the Omniglot trunk) take the feature-space episode since round 5 (`feature_space`: dkt_lowrank_*
+    behind the streaming front end of dkt_frontend_big.hip); `nxn` (DKT_LOWRANK=0) keeps the N x N kernels of the cfg4 shape on the same data: tile-array MLL path."""
+    if path == "nxn":
+        monkeypatch.setenv("DKT_LOWRANK", "0")
     torch.manual_seed(0)
     m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=20, n_support=5).to(cuda)
     m.train()
@@ -2235,6 +2239,7 @@ def test_dkt_20way_train_and_test_use_the_blocked_large_n_path(cuda, capsys):
     z = m._embed(x.view(420, 3, 28, 28).to(cuda))
     y = m._targets(20, 21, cuda)
     loss, aux = m._episode_loss(z, y)
+    assert (aux["e"] is None) == (path == "feature_space")
     hyp = O.GPHypers(m.model.outputscale.detach().cpu().numpy().astype(np.float64),
                      m.model.mean.detach().cpu().numpy().astype(np.float64), np.full(20, 0.1))
     ref = O.train_episode(z.detach().cpu().numpy().astype(np.float64), 20, hyp)
