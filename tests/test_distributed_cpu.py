@@ -257,3 +257,25 @@ def test_grad_bucket_zero_clears_gradients_that_are_not_views():
     assert p32.grad.data_ptr() == bkt._flat.data_ptr()          # still a view
     (p32.sum() + p64.sum()).backward()
     assert float(p32.grad[0]) == 1.0 and float(p64.grad[0]) == 1.0
+
+
+def test_bench_under_the_drivers_launcher_prints_one_json_line():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`:
+    rank 0's JSON record must be the only line on the launcher's stdout (every rank points its fd 1 at stderr; only rank 0 writes the record)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-collective"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.strip().splitlines()
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[-1])
+    assert out["selftest"] is True and out["n_gpus"] == 2 and out["valid"] is True and out["collective"]["ranks"] == 2
