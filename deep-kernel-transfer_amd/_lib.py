@@ -42,6 +42,7 @@ SIGNATURES = {
     "dkt_reload_env": (None, []),
     "dkt_gram_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "dkt_mll_workspace_bytes": (ctypes.c_size_t, [_c_i, _c_i, _c_i]),
+    "dkt_mll_workspace_bytes_for": (ctypes.c_size_t, [_c_i, _c_i, _c_i, ctypes.c_uint]),
     "dkt_mll_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_i,
                            ctypes.c_uint, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                            _c_p, ctypes.c_size_t, _c_p]),

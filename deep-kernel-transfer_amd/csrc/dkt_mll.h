@@ -50,6 +50,7 @@ int dkt_mll_big_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipSt
 // Tile-array path for N > 127 (dkt_mll_tiled.hip; the default there unless the Cholesky factors are requested).
 bool dkt_mll_tiled_supports(int N, unsigned flags, int C = 1);
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
+size_t dkt_mll_tiled_workspace_bytes_form(int B, int C, int N, bool per_class);
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes
 // -- with the full jitter-retry ladder -- only the episodes the blocked path reported as failed.  No host synchronisation.

@@ -222,6 +222,20 @@ extern "C" size_t dkt_mll_workspace_bytes(int B, int C, int N) {
     return mx > til ? mx : til;
 }
 
+// What THIS call's flags need (the flag-less query reserves the larger of the shared-matrix and per-class tile layouts and the blocked path's
+// 4 N^2 floats per matrix for every call; a default shared-matrix call of a few episodes needs a tenth of that).
+extern "C" size_t dkt_mll_workspace_bytes_for(int B, int C, int N, unsigned flags) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    const bool pc = (flags & DKT_MLL_E_PER_CLASS) != 0;
+    const size_t gen = mll_fits_lds(N) ? 0 : (size_t)(pc ? (B < 128 ? B : 128) * C : B) * mll_mat_floats(N) * sizeof(float);
+    if (flags & DKT_MLL_FORCE_GENERIC) return gen;
+    if (N + 1 <= 128) return (flags & DKT_MLL_WANT_CHOL) && (N + 1 + 15) / 16 > 2 ? gen : 0;      // (Cholesky output beyond N = 31: the generic kernel, LDS-resident up to N ~ 190)
+    if (!(flags & DKT_MLL_FORCE_BLOCKED) && dkt_mll_tiled_supports(N, flags, C)) return dkt_mll_tiled_workspace_bytes_form(B, C, N, pc);
+    if (pc) return gen;                                                                               // N > 447 with per-class matrices: the generic kernel
+    const size_t big = dkt_mll_big_workspace_bytes(B, C, N);
+    return big > gen ? big : gen;
+}
+
 extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const float* sv, const float* mean,
                            const float* noise, int B, int C, int N, float jitter0, int max_tries,
                            unsigned flags, const float* cls_weight, float* logp, float* alpha, float* L,
@@ -258,7 +272,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
         if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_BLOCKED)) return DKT_ERR_BAD_ARG;
         if (!(flags & DKT_MLL_FORCE_GENERIC)) {
             if (N + 1 > 128 && dkt_mll_tiled_supports(N, flags, C)) {
-                if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes(B, C, N)) return DKT_ERR_WORKSPACE;
+                if (!workspace || workspace_bytes < dkt_mll_tiled_workspace_bytes_form(B, C, N, true)) return DKT_ERR_WORKSPACE;
                 return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
             }
             if (N + 1 <= 128) return dkt_mll_h2_launch(a, st) ? (hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH) : DKT_ERR_BAD_ARG;
@@ -267,7 +281,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags, C) && workspace &&
-        workspace_bytes >= dkt_mll_tiled_workspace_bytes(B, C, N))
+        workspace_bytes >= dkt_mll_tiled_workspace_bytes_form(B, C, N, false))
         return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_E_PER_CLASS)) && N + 1 > 128 && workspace && workspace_bytes >= dkt_mll_big_workspace_bytes(B, C, N))
         return dkt_mll_big_launch(a, workspace, workspace_bytes, st);

@@ -1549,13 +1549,18 @@ size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N) {
     const size_t shared = tiled_ws_floats(bc, C, N), pc = C <= 65535 ? tiled_pc_ws_floats(tiled_pc_chunk(B, C, TILED_CHUNK_MAX), C, N) : 0;
     return (shared > pc ? shared : pc) * sizeof(float);
 }
+// the form one call needs (dkt_mll_workspace_bytes_for): shared base matrix or one per class
+size_t dkt_mll_tiled_workspace_bytes_form(int B, int C, int N, bool per_class) {
+    if (per_class) return C <= 65535 ? tiled_pc_ws_floats(tiled_pc_chunk(B, C, TILED_CHUNK_MAX), C, N) * sizeof(float) : 0;
+    return tiled_ws_floats(B < TILED_CHUNK_MAX ? B : TILED_CHUNK_MAX, C, N) * sizeof(float);
+}
 
 // Returns 0 on success, a negative DKT status otherwise.
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st) {
     const int N = a.N, C = a.C;
-    if (!workspace || ws_bytes < dkt_mll_tiled_workspace_bytes(a.B, C, N)) return DKT_ERR_WORKSPACE;
-    const int NT = tiled_nt(N);
     const bool pc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    if (!workspace || ws_bytes < dkt_mll_tiled_workspace_bytes_form(a.B, C, N, pc)) return DKT_ERR_WORKSPACE;
+    const int NT = tiled_nt(N);
     if (pc && C > 65535) return DKT_ERR_TOO_LARGE;
     const int Bc = pc ? tiled_pc_chunk(a.B, C, tiled_chunk_episodes()) : (a.B < tiled_chunk_episodes() ? a.B : tiled_chunk_episodes());
     const size_t ntt = (size_t)NT * (NT + 1) / 2, nmat_max = (size_t)Bc * C;

@@ -224,7 +224,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
         _lib.check(st, "dkt_diag_mll_reg_f32")
         return dict(logp=logp, alpha=alpha, jitter=jit, info=info, chol=chol, w=w, dsv=dsv, dmean=dmean, dnoise=dnoise)
     lib = _lib_now(want_twin=force_f32mfma)
-    ws_bytes = int(lib.dkt_mll_workspace_bytes(b_, c_, n))
+    ws_bytes = int(lib.dkt_mll_workspace_bytes_for(b_, c_, n, flags))           # what THIS call needs (the flag-less query covers every flag combination)
     ws = torch.empty((max(ws_bytes, 4) + 3) // 4, device=dev, dtype=torch.float32) if ws_bytes else None
     with _timed("dkt_mll_f32"):
         st = lib.dkt_mll_f32(_p(e), _p(y), y_bstride, _p(sv), _p(mean), _p(noise), b_, c_, n,

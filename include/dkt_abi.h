@@ -101,6 +101,9 @@ int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, int M, int N,
  * factorisation is LDS/register resident).
  */
 size_t dkt_mll_workspace_bytes(int B, int C, int N);
+/* The same for ONE call: the bytes dkt_mll_f32 needs with exactly these flags (never more than dkt_mll_workspace_bytes(B, C, N), which covers every
+ * flag combination; a default shared-matrix call of a few 420-row episodes needs a tenth of it).  (ABI 4) */
+size_t dkt_mll_workspace_bytes_for(int B, int C, int N, unsigned flags);
 
 /*
  * dkt_mll_f32 -- exact-GP marginal log likelihood of C one-vs-rest models per episode that

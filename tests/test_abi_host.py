@@ -44,6 +44,13 @@ def test_argument_errors_do_not_launch(lib):
     # per-class base matrices need as many tiles again for E: a small batch reserves up to twice the shared-matrix workspace, a full chunk of 1024 episodes the same
     assert lib.dkt_mll_workspace_bytes(2048, 20, 420) == lib.dkt_mll_workspace_bytes(1024, 20, 420)
     assert lib.dkt_mll_workspace_bytes(1, 20, 420) >= 2 * 20 * (27 * 28 // 2) * 1024
+    # the per-call query: never more than the flag-less one; a default shared-matrix call takes the tile arrays only (no per-class layout, no blocked-path matrices)
+    for (b, c, n) in ((1, 20, 420), (64, 20, 420), (1024, 20, 320), (3, 5, 150), (2, 5, 500)):
+        for flags in (0, 1, 2, 4, 16, 64, 65, 1 | 16):
+            assert lib.dkt_mll_workspace_bytes_for(b, c, n, flags) <= lib.dkt_mll_workspace_bytes(b, c, n), (b, c, n, flags)
+    assert lib.dkt_mll_workspace_bytes_for(1, 20, 420, 1) < lib.dkt_mll_workspace_bytes(1, 20, 420) // 4
+    assert lib.dkt_mll_workspace_bytes_for(1, 20, 420, 1 | 64) >= 2 * 20 * (27 * 28 // 2) * 1024
+    assert lib.dkt_mll_workspace_bytes_for(8, 5, 105, 1) == 0 and lib.dkt_mll_workspace_bytes_for(8, 5, 105, 2) == 0
 
 
 def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches():
