@@ -827,6 +827,8 @@ def run(args):
         torch.cuda.empty_cache()
         out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 3)
         torch.cuda.empty_cache()
+        out["other_paths_cfg1"] = _aux_paths(dev, "cfg1", 8192, 2048, 5)          # the Omniglot shape from trunk features: the feature-space episode behind the streaming front end
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_test_time and args.config != "cfg0":
             # the forward-only test-time episode (`correct`, DKT.py:199-272) reported separately:
@@ -922,7 +924,7 @@ def _line_of(out):
     if "other_configs" in out:
         line["other_configs"] = {cfg: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
                                        "dominant": _dominant(o["kernels"], o["roofline_by_kernel"])} for cfg, o in out["other_configs"].items()}
-    for key in ("other_paths_cfg2", "other_paths_cfg4"):
+    for key in ("other_paths_cfg2", "other_paths_cfg4", "other_paths_cfg1"):
         if key in out:
             line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
                                 "kernels_ms": o["kernels_ms"],

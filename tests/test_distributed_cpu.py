@@ -226,7 +226,7 @@ def test_bench_line_stays_under_8k_with_every_section_filled():
                roofline_by_kernel={k: roof for k in kern}, kernels=kern, collective=dict(op="o" * 60, bytes=4, allreduce_ms=0.0, backend="none" * 10, ranks=1,
                NCCL_ALGO="unset", NCCL_PROTO="unset", pack_copies_last_step=0), other_configs={c: other for c in ("cfg0", "cfg1", "cfg3", "cfg4", "cfg4_n320")},
                other_paths_cfg2={"from_trunk_features": path, "rbf_per_class_lengthscales": path}, other_paths_cfg4={"from_trunk_features": path,
-               "rbf_per_class_lengthscales": path}, test_time_forward=dict(value=1.0, unit="episodes/s", episodes_per_step=4096, ms_per_step=1.0, workload="w" * 100),
+               "rbf_per_class_lengthscales": path}, other_paths_cfg1={"from_trunk_features": path, "rbf_per_class_lengthscales": path}, test_time_forward=dict(value=1.0, unit="episodes/s", episodes_per_step=4096, ms_per_step=1.0, workload="w" * 100),
                mll_rel_err=9.6e-7, mll_rel_err_episodes=32, speedup_vs_cpu=100.0, speedup_vs_cpu_1thread=13000.0, gpytorch_reference="g" * 90, detail="gpurun_out/bench_detail.json",
                cpu_baseline=dict(value=15000.0, unit="episodes/s", cores=128, kind="port", sample="s" * 600, one_thread=152.0, all_cores=15000.0, cores_effective=128,
                parallel_efficiency=0.8, slowest_process_eps=100.0, cpu_model="AMD EPYC 9575F 64-Core Processor", host_cpus=256, affinity_cpus=256, physical_cores=128,
