@@ -569,7 +569,7 @@ def _kernel_report(cfg, m, unit_rows, traffic):
     from dkt_amd import ops
     st, b = m["st"], m["b"]
     n, d, c = st["n"], st["d"], st["c"]
-    lowrank = st["kernel"] == "bncossim" and ops.lowrank_applies(n, d, c)
+    lowrank = st["kernel"] == "bncossim" and ops.lowrank_applies(n, d, c, b)
     alg = _algorithmic(cfg, n, d, c, unit_rows, lowrank)
     if lowrank:
         n = ops.LOWRANK_DP                    # the size the marginal-likelihood kernel runs at (for its executed-flop count below)

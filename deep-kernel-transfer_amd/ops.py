@@ -673,14 +673,30 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 # Linear kernels in FEATURE space: D <= 64 < N (Conv4S / Omniglot; include/dkt_abi.h "dkt_lowrank_*", csrc/dkt_lowrank.hip)
 # ------------------------------------------------------------------------------------------------------
+FUSED_EP_MAX_N = 128          # the episode-resident fused kernels of dkt_frontend.hip (Zn never written); above it: dkt_frontend_big.hip
 LOWRANK_DP = 64               # DKT_LOWRANK_DP
 LOWRANK_MIN_N = 80            # below it the D x D problem (5 x 5 tiles) is no smaller than the N x N one
+LOWRANK_MIN_B = 3072          # episodes of N <= 128 rows: batches from which the feature-space step wins (below, both steps are bound by their launches, and it has 5 to the N x N step's 3:
+                              # tools/lowrank_small_batch_probe.py -- 0.35 vs 0.31 ms up to 1024 episodes of 105 rows; 0.69 vs 1.03 ms at 8192)
 
 
-def lowrank_applies(n: int, d: int, c: int) -> bool:
-    """Shapes the feature-space path serves AND wins on: K_c = sv_c Z Z^T + noise_c I with D <= 64, D % 4 == 0, C <= 32 and an episode of at least
-    80 rows (the Omniglot / Conv4S episodes: D = 64, N = 105 or 420).  DKT_LOWRANK=0 keeps every call on the N x N kernels (the twin the tests compare)."""
-    return (os.environ.get("DKT_LOWRANK", "1") != "0" and d <= LOWRANK_DP and d % 4 == 0 and c <= 32 and n >= LOWRANK_MIN_N)
+def lowrank_supported(n: int, d: int, c: int) -> bool:
+    """Shapes the feature-space calls (dkt_lowrank_*) serve and are meant for: K_c = sv_c Z Z^T + noise_c I with D <= 64, D % 4 == 0, C <= 32 and an episode of at
+    least 80 rows (the Omniglot / Conv4S episodes: D = 64, N = 105 or 420)."""
+    return d <= LOWRANK_DP and d % 4 == 0 and c <= 32 and n >= LOWRANK_MIN_N
+
+
+def lowrank_applies(n: int, d: int, c: int, b: int = LOWRANK_MIN_B, front_end: bool = False) -> bool:
+    """Does this call take the feature-space episode?  DKT_LOWRANK: 1 (default) = where it wins -- every batch of episodes with more than 128 rows (one 420-row episode:
+    0.35 instead of 1.2 ms, 1024 of them: 0.49 instead of 16.9 ms), and for N <= 128 from LOWRANK_MIN_B episodes per call (never behind the fused bn_out front end, whose
+    episode-resident kernels for N <= 128 are as fast at 8192 episodes and faster below); 0 = never (the N x N kernels: the twin the tests compare); force = wherever the
+    shape is supported (tests)."""
+    mode = os.environ.get("DKT_LOWRANK", "1")
+    if mode == "0" or not lowrank_supported(n, d, c):
+        return False
+    if mode == "force" or n > FUSED_EP_MAX_N:
+        return True
+    return (not front_end) and b >= LOWRANK_MIN_B
 
 
 _lowrank_zeros = {}
@@ -917,7 +933,6 @@ def normalize_bn_bwd(dzn, zn, x, a, rnorm, mean=None, rstd=None):
     return dx, dg, db
 
 
-FUSED_EP_MAX_N = 128          # the episode-resident fused kernels of dkt_frontend.hip (Zn never written); above it: dkt_frontend_big.hip
 
 
 class _EpisodeLossBnFn(torch.autograd.Function):
@@ -930,7 +945,7 @@ class _EpisodeLossBnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, use_bn, y, sv, mean, noise, cls_weight, jitter0, max_tries):
         b_, n, d = x.shape
-        ctx.lowrank = lowrank_applies(n, d, y.shape[-2])
+        ctx.lowrank = lowrank_applies(n, d, y.shape[-2], b_, front_end=True)
         ctx.big = n > FUSED_EP_MAX_N or ctx.lowrank
         if ctx.big:
             if use_bn:
@@ -1018,7 +1033,8 @@ def episode_loss_linear(z, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6
     """z:[B,N,D] (already bn_out'ed + normalised).  Returns (obj[B], logp, alpha, info, jitter, E).
     unit_rows=True: z went through F.normalize (cossim / bncossim), |z| <= 1 element-wise -- the Gram kernels may then use
     the scaled 2-way f16 split (same fp32-level accuracy, less staging work).
-    D <= 64 < N (lowrank_applies: the Conv4S / Omniglot episodes): the episode runs in feature space and E is None -- no N x N matrix exists."""
-    if z.dim() == 3 and lowrank_applies(z.shape[1], z.shape[2], y.shape[-2]):
+    D <= 64 < N where it wins (lowrank_applies: the Conv4S / Omniglot episodes -- every 420-row batch, 105-row batches from 3072 episodes): the episode runs in
+    feature space and E is None -- no N x N matrix exists."""
+    if z.dim() == 3 and lowrank_applies(z.shape[1], z.shape[2], y.shape[-2], z.shape[0]):
         return _EpisodeLossLowRankFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, bool(unit_rows)) + (None,)
     return _EpisodeLossLinearFn.apply(z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows)

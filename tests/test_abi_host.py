@@ -102,6 +102,20 @@ def test_per_class_path_sizes():
     assert dkt_amd.ops.FUSED_EP_MAX_N == 128
 
 
+def test_feature_space_dispatch_rule(monkeypatch):
+    """ops.lowrank_applies: D <= 64, D % 4 == 0, C <= 32, N >= 80; by default every batch of episodes with more than 128 rows and batches >= LOWRANK_MIN_B of shorter
+    ones (never behind the fused front end at N <= 128); DKT_LOWRANK=0 never, =force wherever supported."""
+    ap, ops = dkt_amd.ops.lowrank_applies, dkt_amd.ops
+    monkeypatch.delenv("DKT_LOWRANK", raising=False)
+    assert ap(105, 64, 5, 8192) and ap(105, 64, 5, ops.LOWRANK_MIN_B) and not ap(105, 64, 5, ops.LOWRANK_MIN_B - 1) and not ap(105, 64, 5, 1)
+    assert ap(420, 64, 20, 1) and ap(129, 32, 5, 1) and ap(420, 64, 20, 1, front_end=True) and not ap(105, 64, 5, 8192, front_end=True)
+    assert not ap(105, 1600, 5, 8192) and not ap(105, 62, 5, 8192) and not ap(79, 64, 5, 8192) and not ap(420, 64, 33, 8192) and not ap(25, 64, 5, 8192)
+    monkeypatch.setenv("DKT_LOWRANK", "0")
+    assert not ap(420, 64, 20, 8192) and not ap(105, 64, 5, 8192)
+    monkeypatch.setenv("DKT_LOWRANK", "force")
+    assert ap(105, 64, 5, 1) and ap(105, 64, 5, 1, front_end=True) and not ap(105, 1600, 5, 1)
+
+
 def test_product_path_fails_loudly_on_cpu_tensors():
     with pytest.raises(RuntimeError, match="HIP-only"):
         dkt_amd.ops.gram(torch.zeros(1, 4, 8))

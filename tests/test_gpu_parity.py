@@ -1337,8 +1337,7 @@ def test_full_size_properties_cfg2(cuda, unit, cfg, monkeypatch):
     cfg1 = (105, 64, 5) Conv4S features, cfg3 = (85, 512, 5) 5-way 1-shot ResNet10 features."""
     # b = 1024 >= DKT_MLL_H2E_MINB: the DEFAULT dispatch takes the wave-per-episode kernels the bench times (mll_h2e_kernel<7> / <6>), not
     # the wave-per-matrix kernel of smaller batches (VERDICT round 3, weak #9)
-    if cfg == "cfg1_nxn":
-        monkeypatch.setenv("DKT_LOWRANK", "0")
+    monkeypatch.setenv("DKT_LOWRANK", "0" if cfg == "cfg1_nxn" else "force")      # (1024 episodes of 105 rows: below the batch from which the default takes feature space)
     b, n, d, c = {"cfg2": (1024, 105, 1600, 5), "cfg1": (1024, 105, 64, 5), "cfg1_nxn": (1024, 105, 64, 5), "cfg3": (1024, 85, 512, 5)}[cfg]
     gen = torch.Generator(device="cpu").manual_seed(1234)
     zr = torch.randn(b, n, d, generator=gen)
@@ -1407,7 +1406,8 @@ def test_episode_in_feature_space_vs_oracle_and_nxn_twin(cuda, b, c, per, d, cor
         (out[0] * dev_t(gup, cuda)).sum().backward()
         return out, z.grad, sv.grad, mean.grad, noise.grad
 
-    assert ops.lowrank_applies(n, d, c)
+    monkeypatch.setenv("DKT_LOWRANK", "force")             # small batches: the default dispatch takes feature space from 3072 episodes of <= 128 rows, always above 128 rows
+    assert ops.lowrank_applies(n, d, c, b) and ops.lowrank_supported(n, d, c)
     (obj, logp, alpha, info, jit, e), dz, gsv, gmean, gnoise = run()
     assert e is None and int(info.abs().max().item()) == 0 and float(jit.abs().max()) == 0.0
     monkeypatch.setenv("DKT_LOWRANK", "0")
@@ -1431,16 +1431,20 @@ def test_episode_in_feature_space_vs_oracle_and_nxn_twin(cuda, b, c, per, d, cor
     # the N x N twin: same tolerances to each other as each has to the oracle
     assert rel_l2(logp.cpu().numpy(), logp_t.cpu().numpy()) < 2e-5 and rel_l2(alpha.cpu().numpy(), alpha_t.cpu().numpy()) < 5e-4
     assert rel_l2(dz.cpu().numpy(), dz_t.cpu().numpy()) < GRAD_RTOL and rel_l2(gsv.cpu().numpy(), gsv_t.cpu().numpy()) < GRAD_RTOL
-    monkeypatch.delenv("DKT_LOWRANK")
+    monkeypatch.setenv("DKT_LOWRANK", "force")
     # bitwise repeatable (fixed reduction orders, no atomics)
     (_, logp2, alpha2, *_), dz2, *_ = run()
     assert torch.equal(logp, logp2) and torch.equal(alpha, alpha2) and torch.equal(dz, dz2)
+    # the default dispatch: feature space for every batch of episodes with more than 128 rows, for shorter ones from LOWRANK_MIN_B episodes per call
+    monkeypatch.delenv("DKT_LOWRANK")
+    assert ops.lowrank_applies(n, d, c, b) == (n > 128) and ops.lowrank_applies(n, d, c, ops.LOWRANK_MIN_B) and ops.lowrank_applies(n, d, c, 8192, front_end=True) == (n > 128)
 
 
-def test_episode_in_feature_space_jitter_and_failure(cuda):
+def test_episode_in_feature_space_jitter_and_failure(cuda, monkeypatch):
     """The jitter ladder of the feature-space path is the D x D call's: psd_safe_cholesky's total jitter 1e-6 * 10^i lands on noise_c, as it does on
     the diagonal of K_c in the reference.  noise = 0 makes K_c = sv Z Z^T singular (rank D < N): attempt 0 fails, 1e-6 succeeds -- per class, per
     episode; a NaN feature poisons only its own episode (info != 0 / NaN outputs), per-episode targets are honoured."""
+    monkeypatch.setenv("DKT_LOWRANK", "force")
     b, c, per, d = 3, 5, 21, 64
     n = c * per
     z64 = O.synthetic_features(b, n, d, 41, 0)
@@ -1472,6 +1476,7 @@ def test_dkt_omniglot_shape_train_step_runs_in_feature_space(cuda, capsys, monke
     """The drop-in class at the Omniglot shape (Conv4S trunk: D = 64, backbone.py:287-310; 5-way 5-shot + 16 queries: N = 105; cossim = the un-fused
     front end): the train step takes the feature-space path (aux['e'] is None) and its loss / parameter gradients match the N x N twin; the in-loop
     evaluation at a print point (which conditions on the stale train features, DKT.py:170-192) builds its own Gram."""
+    monkeypatch.setenv("DKT_LOWRANK", "force")             # (one 105-row episode: the default dispatch keeps it on the N x N kernels -- both steps are launch-bound there)
     torch.manual_seed(3)
     model = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5, kernel_type="cossim").to(cuda)
     model.train()
@@ -1484,7 +1489,7 @@ def test_dkt_omniglot_shape_train_step_runs_in_feature_space(cuda, capsys, monke
     monkeypatch.setenv("DKT_LOWRANK", "0")
     loss2, aux2 = model._episode_loss(model._embed(x.view(105, 3, 28, 28).to(cuda)), y_t)
     grads2 = torch.autograd.grad(loss2, params, allow_unused=True)
-    monkeypatch.delenv("DKT_LOWRANK")
+    monkeypatch.setenv("DKT_LOWRANK", "force")
     assert aux2["e"] is not None and abs(loss.item() - loss2.item()) < 1e-5 * abs(loss2.item())
     for g1, g2 in zip(grads, grads2):
         assert (g1 is None) == (g2 is None)
@@ -1940,7 +1945,7 @@ def test_episode_loss_from_trunk_features_matches_float64_autograd(cuda, b, c, p
     cw = torch.full((c,), -1.0 / (c * n), device=cuda)
     obj, logp, alpha, info, jit, e, bmean, bvar = ops.episode_loss_bn(xt, gt, bt, y, torch.nn.functional.softplus(rst), mt, noise, cw)
     assert int(info.abs().max().item()) == 0
-    assert (e is None) == ops.lowrank_applies(n, d, c)             # D <= 64 < N: the episode ran in feature space, no N x N matrix exists
+    assert (e is None) == ops.lowrank_applies(n, d, c, b, front_end=True)      # D <= 64 and more than 128 rows: the episode ran in feature space, no N x N matrix exists
     w_ep = torch.linspace(0.5, 1.5, b, device=cuda)                # non-uniform upstream gradient per episode
     (obj * w_ep).sum().backward()
     # float64 reference
