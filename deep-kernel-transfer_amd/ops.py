@@ -704,6 +704,8 @@ _lowrank_zeros = {}
 
 def _zeros_cached(c: int, dev) -> torch.Tensor:
     """[C] zeros (the mean of the D x D models), one tensor per (device, C): never written."""
+    if torch.cuda.is_current_stream_capturing():          # (a tensor born inside a graph capture lives in the graph's private pool: not cached)
+        return torch.zeros(c, device=dev, dtype=torch.float32)
     key = (dev, int(c))
     t = _lowrank_zeros.get(key)
     if t is None:

@@ -2178,6 +2178,25 @@ def test_dkt_train_loop_and_test_loop_run(cuda, capsys):
     assert countb == 75 and np.isfinite(avg) and avg != 0.0
 
 
+@pytest.mark.parametrize("way", [5, 20])
+def test_dkt_train_loop_captured_in_a_hip_graph_matches_eager(cuda, capsys, monkeypatch, way):
+    """DKT_TRAIN_GRAPH=1: the whole training step (backbone, GP kernels, capturable Adam) as one hipGraph launch -- same losses as the eager loop after four steps,
+    at the 5-way shape (N = 105: fused front end + N x N kernels) and at the 20-way shape (N = 420, Conv4S features: streaming front end + feature-space episode)."""
+    losses = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("DKT_TRAIN_GRAPH", graph)
+        torch.manual_seed(0)
+        m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=way, n_support=5).to(cuda)
+        m.train()
+        g = torch.Generator().manual_seed(1)
+        loader = [(torch.rand(way, 21, 3, 28, 28, generator=g), None) for _ in range(4)]
+        m.train_loop(0, loader, None, print_freq=2)
+        losses[graph] = float(m._last["loss"])
+        assert np.isfinite(losses[graph])
+    capsys.readouterr()
+    assert abs(losses["1"] - losses["0"]) < 1e-4 * abs(losses["0"])
+
+
 def test_dkt_failed_step_is_skipped_on_the_device_and_raised_at_the_next_print(cuda, capsys):
     """An episode whose factorisation fails (here: NaN pixels -> NaN Gram -> info != 0 after every jitter retry) must not reach the
     weights: the fused Adam step takes the failure flag as `found_inf` and leaves parameters and moments untouched; the error
