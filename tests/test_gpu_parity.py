@@ -2197,6 +2197,18 @@ def test_dkt_train_loop_captured_in_a_hip_graph_matches_eager(cuda, capsys, monk
     assert abs(losses["1"] - losses["0"]) < 1e-4 * abs(losses["0"])
 
 
+def test_correct_laplace_branch(cuda):
+    """`correct(x, laplace=True)` (reference DKT.py:207-222: sklearn's Laplace-approximation GP classifier on the embedded support set, "not the method used in the
+    paper"): the surface and the return convention (top1_correct, count, 0.0)."""
+    torch.manual_seed(0)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=5, n_support=5).to(cuda)
+    m.eval()
+    m.n_query = 16
+    x = torch.rand(5, 21, 3, 28, 28, generator=torch.Generator().manual_seed(2))
+    top1, count, avg_loss = m.correct(x, laplace=True)
+    assert count == 80 and 0.0 <= top1 <= 80.0 and avg_loss == 0.0 and isinstance(top1, float)
+
+
 def test_dkt_failed_step_is_skipped_on_the_device_and_raised_at_the_next_print(cuda, capsys):
     """An episode whose factorisation fails (here: NaN pixels -> NaN Gram -> info != 0 after every jitter retry) must not reach the
     weights: the fused Adam step takes the failure flag as `found_inf` and leaves parameters and moments untouched; the error
