@@ -94,11 +94,13 @@ struct BnTrainOut {                // train-mode statistics written by the STATS
 // affine map is y = x - x_0 (row 0 of the episode: the shift GPyTorch's mean-centring provides, taken while the slice is staged), the
 // epilogue reads |y_i|^2 off the diagonal and emits d2_ij / l^2 = (|y_i|^2 + |y_j|^2 - 2 y_i . y_j) / l^2 (EPI = 1) or exp(-d2 / 2 l^2)
 // (EPI = 2), exact zero / unit diagonal, bitwise symmetric.  A / S are unused.
+// redo_only (round 5): the fix-up pass behind gram_bn_train_f16_kernel (below) -- workgroups whose episode that kernel did not flag (rnorm[b, 0] is not
+// NaN) exit at once; a flagged episode is computed here in full, in the 3-way bf16 split that needs no bound on the operands.
 template <int NT, bool STATS, int EPI = 0>
 __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_sym_ep_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                                               const float* __restrict__ S, long ab_bstride,
                                                                               float* __restrict__ E, float* __restrict__ rnorm,
-                                                                              int N, int D, BnTrainOut bo) {
+                                                                              int N, int D, BnTrainOut bo, int redo_only) {
     constexpr int NP = 16 * NT;
     constexpr int BK = 32;
     constexpr int SPLD = BK + 16;
@@ -114,6 +116,10 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
     __shared__ __attribute__((aligned(16))) float fold_as[STATS ? 4 * 2 * BK : 4];         // [wave][a x 32, s x 32]: wave-private
 
     const int b = blockIdx.x;
+    if (redo_only) {                                     // fix-up pass behind the f16 instance: only the episodes it flagged
+        const float f = rnorm[(size_t)b * N];
+        if (f == f) return;
+    }
     float* Eb = E + (size_t)b * N * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
     const brsrc_t xr = mk_rsrc(X + (size_t)b * N * D, N * D * 4);
@@ -129,6 +135,9 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
         voff[i] = rowok[i] ? (row * D + 4 * c4) * 4 : OOB;
     }
     float4 rg[NLD], av, sv, x0;
+    f32x4 acc[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gsc = 1.0f, bsc = 0.0f;                        // STATS: gamma / beta of feature k0 + lane % 32
     int kcur = 0;                                        // first feature of the slice held in rg (STATS: where its statistics go)
     auto gload = [&](int k0) {
@@ -240,10 +249,11 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
             *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
         }
     };
+    auto tiles = [&](auto rows) {
+        using R = decltype(rows);
+        if constexpr (R::RA >= 0) sym_tiles_mfma_bf16x3<NT, R::RA, R::RB, SPLD, PLANE>(acc, zp, r16, q);
+    };
 
-    f32x4 acc[NT + 1];
-#pragma unroll
-    for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (D + BK - 1) / BK;
     gload(0);
     if constexpr (STATS) {
@@ -255,15 +265,10 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload((kt + 1) * BK);
-        if (wave == 0) {
-            if constexpr (RowsOf<NT, 0>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 0>::RA, RowsOf<NT, 0>::RB, SPLD, PLANE>(acc, zp, r16, q);
-        } else if (wave == 1) {
-            if constexpr (RowsOf<NT, 1>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 1>::RA, RowsOf<NT, 1>::RB, SPLD, PLANE>(acc, zp, r16, q);
-        } else if (wave == 2) {
-            if constexpr (RowsOf<NT, 2>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 2>::RA, RowsOf<NT, 2>::RB, SPLD, PLANE>(acc, zp, r16, q);
-        } else {
-            if constexpr (RowsOf<NT, 3>::RA >= 0) sym_tiles_mfma_bf16x3<NT, RowsOf<NT, 3>::RA, RowsOf<NT, 3>::RB, SPLD, PLANE>(acc, zp, r16, q);
-        }
+        if (wave == 0) tiles(RowsOf<NT, 0>{});
+        else if (wave == 1) tiles(RowsOf<NT, 1>{});
+        else if (wave == 2) tiles(RowsOf<NT, 2>{});
+        else tiles(RowsOf<NT, 3>{});
         if constexpr (STATS) {
             if (kt + 1 < nk) stats_partial();            // the table was last read before the previous barrier
         }
@@ -316,6 +321,297 @@ __global__ __launch_bounds__(256, NT <= 6 ? 4 : (NT == 7 ? 3 : 2)) void gram_bn_
                 t[reg] = (EPI == 2) ? expf(-0.5f * d2 * inv_l2) : d2 * inv_l2;
             }
         }
+    };
+    auto finish = [&](auto w) {
+        constexpr int W = decltype(w)::value;
+        constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
+        if constexpr (RA >= 0) {
+#pragma unroll
+            for (int tj = 0; tj <= RA; ++tj) emit(acc[tj], RA, tj);
+            sym_store_row<RA>(acc, Eb, N, r16, q);
+        }
+        if constexpr (RB >= 0) {
+#pragma unroll
+            for (int tj = 0; tj <= RB; ++tj) emit(acc[RA + 1 + tj], RB, tj);
+            sym_store_row<RB>(acc + RA + 1, Eb, N, r16, q);
+        }
+    };
+    if (wave == 0) finish(std::integral_constant<int, 0>{});
+    else if (wave == 1) finish(std::integral_constant<int, 1>{});
+    else if (wave == 2) finish(std::integral_constant<int, 2>{});
+    else finish(std::integral_constant<int, 3>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Train-mode fused forward on the f16 pipe (round 5; dkt_gram_bn_train_f32 at N > 32).
+// Arithmetic: the scaled 2-way f16 split of the level-1 unit-row kernel instead of the 3-way bf16 split -- three MFMA products instead of six, two LDS
+// planes instead of three, ~3 instead of 5.5 VALU instructions per staged element.  Rounds 2-4 kept bf16 here because y = a x + s is not bounded by 1.  But
+// train-mode BatchNorm bounds every element a priori, |y_ik| <= |beta_k| + |gamma_k| sqrt(N - 1) (the largest z-score N samples can hold), so the power-of-two
+// scale S that keeps the high piece inside f16 is known before the first slice (a max over gamma / beta in the prologue): no overflow is possible.  What the
+// bound cannot give is the other side: the MFMA flushes f16 subnormals, i.e. a low piece below 2^-14 in scaled units, an absolute error of <= sqrt(D) 2^-14
+// per ROW -- nothing against a row of typical norm (S |y_i| ~ 2^16 at D = 1600), not so for a row whose norm is orders of magnitude below the element bound.
+// That is checked a posteriori on the diagonal of the scaled G' (S^2 |y_i|^2 >= D 2^14  <=>  flush error <= 2^-21 of the row norm; and finite): an episode
+// that fails it gets NaN in rnorm[b, 0], writes no E, and is redone by gram_bn_sym_ep_kernel<NT, true> (bf16 x 3) in the fix-up launch right behind, where
+// every other workgroup exits at once -- the pattern of the tile-array marginal likelihood; no host round trip.  Measured error against float64: 2.4e-7
+// (bf16 x 3: 1.8e-7..2.4e-7; tools/fe_fwd_ab.py).
+// Schedule: that of gram_sym_ep_split_kernel<NT, 2, 2, 32, 2> -- two LDS images, two register stages of raw slices in flight, ONE barrier per
+// 32-feature slice (the round-3 kernel: one image, two barriers).  A stage (slice kt multiplied from image kt & 1):
+//     fold the statistics of slice kt + 1 (published before the last barrier) -> a, s;  apply + split + store it into image (kt + 1) & 1
+//     issue the loads of slice kt + 3 into the registers that just became free
+//     the MFMA products of slice kt
+//     partial column sums of slice kt + 2 (its loads were issued a whole stage ago) -> table kt & 1
+//     barrier
+// Every cross-wave dependence (image, partial-sum table, row-0 shift) is one barrier apart, written -> read or read -> overwritten.  The loop is
+// branch-free (slices past D load as zeros through the descriptor, get a = s = 0 and multiply as zeros; an odd slice count is rounded up; absent gamma /
+// beta are empty descriptors; the statistics leave through buffer stores with out-of-range offsets for idle lanes) so that the compiler's vmcnt
+// bookkeeping is exact and the far loads really stay in flight across a stage.
+// Measured (profiles/r05/v5_fe_fwd_ab.log, same box): 2048 cfg2 episodes 0.550 -> 0.369 ms, 8192: 1.858 -> 1.345 ms (0.41 -> 0.57 of 8 TB/s); the same
+// split in the round-3 schedule: 0.469 / 1.603 ms.
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 5 ? 4 : (NT <= 7 ? 3 : 2)) void gram_bn_train_f16_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                                 const float* __restrict__ Bt, float* __restrict__ E,
+                                                                                 float* __restrict__ rnorm, int N, int D, BnTrainOut bo) {
+    constexpr int NP = 16 * NT;
+    constexpr int BK = 32;
+    constexpr int SPLD = BK + 16;
+    constexpr int V4_PER_ROW = BK / 4;
+    constexpr int NV4 = NP * V4_PER_ROW;
+    constexpr int NLD = (NV4 + 255) / 256;
+    constexpr int NPL = NLD * 256 / V4_PER_ROW;
+    constexpr int PLANE = NPL * SPLD;
+    __shared__ __attribute__((aligned(16))) _Float16 zp[2][2 * PLANE];
+    __shared__ float rho[NP];
+    __shared__ __attribute__((aligned(16))) float red[2][4 * V4_PER_ROW * 8];      // [table][wave][c4][s1 x 4, s2 x 4]
+    __shared__ __attribute__((aligned(16))) float redx0[2][BK];                    // row 0 of the slice: the shift of the sums
+    __shared__ __attribute__((aligned(16))) float fold_as[4 * 2 * BK];             // [wave][a x 32, s x 32]: wave-private
+    __shared__ float bmax_w[4];
+    __shared__ int bad;
+
+    const int b = blockIdx.x;
+    float* Eb = E + (size_t)b * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const brsrc_t xr = mk_rsrc(X + (size_t)b * N * D, N * D * 4);
+    // absent gamma / beta: an empty descriptor -- every load returns 0 (gamma = 0 + 1, beta = 0) with no branch around it
+    const brsrc_t gr = mk_rsrc(G, bo.has_gamma ? D * 4 : 0);
+    const brsrc_t br = mk_rsrc(Bt, bo.has_beta ? D * 4 : 0);
+    const float gdef = bo.has_gamma ? 0.0f : 1.0f;
+    // the statistics leave through buffer stores: lanes with nothing to store (waves 1-3, the upper half of wave 0, features past D) get an
+    // out-of-range offset, a NULL var_unbiased an empty descriptor -- no exec-masked region, no branch inside the loop
+    const size_t so = (size_t)b * D;
+    const brsrc_t o_mean = mk_rsrc(bo.mean + so, D * 4), o_rstd = mk_rsrc(bo.rstd + so, D * 4), o_a = mk_rsrc(bo.a + so, D * 4),
+                  o_s = mk_rsrc(bo.s + so, D * 4), o_var = mk_rsrc(bo.var_unbiased ? bo.var_unbiased + so : bo.mean, bo.var_unbiased ? D * 4 : 0);
+    const bool st_lane = wave == 0 && lane < BK;
+    const float unb = (N > 1) ? (float)N / (float)(N - 1) : 1.0f;      // biased -> unbiased variance: what torch feeds the running estimate
+    const int c4 = tid % V4_PER_ROW;
+    int voff[NLD];
+    bool rowok[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int row = (tid + 256 * i) / V4_PER_ROW;
+        rowok[i] = row < N;
+        voff[i] = rowok[i] ? (row * D + 4 * c4) * 4 : OOB;
+    }
+    struct Slice {
+        float4 rg[NLD], x0;
+        float gsc, bsc;                                  // gamma / beta of feature k0 + lane % 32
+    };
+    auto gload = [&](Slice& r, int k0) {
+        const bool in = k0 + 4 * c4 < D;                 // ragged last slice and the slices past D: zeros
+        const int f = lane & (BK - 1);
+        const int fo = (k0 + f < D) ? 4 * f : OOB;
+        r.gsc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, fo, k0 * 4, 0));
+        r.bsc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, fo, k0 * 4, 0));
+        r.x0 = bload4(xr, in ? 16 * c4 : OOB, k0 * 4);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) r.rg[i] = bload4(xr, in ? voff[i] : OOB, k0 * 4);
+    };
+    // partial sums about row 0 (shifted data), reduced over the 8 lanes of the wave that hold the same features: as stats_partial above
+    auto partial = [&](const Slice& r, const int tab) {
+        const f32x2 xa = {r.x0.x, r.x0.y}, xb = {r.x0.z, r.x0.w};
+        f32x2 s1a = {0.f, 0.f}, s1b = s1a, s2a = s1a, s2b = s1a;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            f32x2 ea = (f32x2){r.rg[i].x, r.rg[i].y} - xa, eb = (f32x2){r.rg[i].z, r.rg[i].w} - xb;
+            if (i == NLD - 1) {                          // only the last 32-row group can hold padded rows (N > 32 (NLD - 1) for every NT >= 3): multiplied out exactly
+                const f32x2 mk = {rowok[i] ? 1.0f : 0.0f, rowok[i] ? 1.0f : 0.0f};
+                ea *= mk;
+                eb *= mk;
+            }
+            s1a += ea;
+            s1b += eb;
+            s2a += ea * ea;
+            s2b += eb * eb;
+        }
+        float v[8] = {s1a.x, s1a.y, s1b.x, s1b.y, s2a.x, s2a.y, s2b.x, s2b.y};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[t]), 0x128, 0xf, 0xf, false));   // lane ^ 8
+        float u[4], w2[2];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+            const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * p2]), __float_as_uint(v[2 * p2 + 1]), false, false);
+            u[p2] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * p2]), __float_as_uint(u[2 * p2 + 1]), false, false);
+            w2[p2] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+        }
+        if ((lane & 8) == 0) {
+            const int rr = lane >> 4, idx = ((rr & 1) << 1) | (rr >> 1);
+            red[tab][(wave * V4_PER_ROW + c4) * 8 + idx] = w2[0];
+            red[tab][(wave * V4_PER_ROW + c4) * 8 + 4 + idx] = w2[1];
+        }
+        if (tid < V4_PER_ROW) *reinterpret_cast<float4*>(&redx0[tab][4 * c4]) = r.x0;
+    };
+    // lane f % 32 of every wave folds feature f of the slice (the four waves do the same work); a / s reach the staging threads through a wave-private table
+    float4 av, sv;
+    float fscale = 1.0f;                                 // the power-of-two scale of the f16 split
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));
+    auto fold = [&](const Slice& r, const int tab, const int k0) {
+        const int f = lane & (BK - 1), fc = f >> 2, ft = f & 3;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s1 += red[tab][(w * V4_PER_ROW + fc) * 8 + ft];
+            s2 += red[tab][(w * V4_PER_ROW + fc) * 8 + 4 + ft];
+        }
+        const float inv_n = 1.0f / (float)N;
+        const float m1 = s1 * inv_n;
+        const float var = fmaxf(__builtin_fmaf(-m1, m1, s2 * inv_n), 0.f);      // biased variance (normalisation)
+        const float mu = redx0[tab][f] + m1;
+        const float ve = var + bo.eps;
+        float rs = __builtin_amdgcn_rsqf(ve);
+        rs = rs * __builtin_fmaf(-0.5f * ve * rs, rs, 1.5f);                     // one Newton step: v_rsq_f32 is ~1 ulp
+        const bool fin = k0 + f < D;
+        const float aa = fin ? (r.gsc + gdef) * rs : 0.f;                        // features past D: exact zeros whatever eps is
+        const float ss = fin ? __builtin_fmaf(-mu, aa, r.bsc) : 0.f;
+        float* tab_as = &fold_as[wave * 2 * BK];
+        tab_as[f] = aa * fscale;                         // the staging threads get the map with the f16 scale folded in (a power of two: exact)
+        tab_as[BK + f] = ss * fscale;
+        const int o = (st_lane && fin) ? 4 * f : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), o_mean, o, k0 * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rs), o_rstd, o, k0 * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(aa), o_a, o, k0 * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ss), o_s, o, k0 * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(var * unb), o_var, o, k0 * 4, 0);
+        av = *reinterpret_cast<const float4*>(&tab_as[4 * c4]);
+        sv = *reinterpret_cast<const float4*>(&tab_as[BK + 4 * c4]);
+    };
+    auto lstore = [&](const Slice& r, const int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int row = (tid + 256 * i) / V4_PER_ROW;
+            float y[4] = {__builtin_fmaf(av.x, r.rg[i].x, sv.x), __builtin_fmaf(av.y, r.rg[i].y, sv.y), __builtin_fmaf(av.z, r.rg[i].z, sv.z),
+                          __builtin_fmaf(av.w, r.rg[i].w, sv.w)};              // S y
+            f16x4 h, m;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (i == NLD - 1) y[t] = rowok[i] ? y[t] : 0.f;                // padded rows must stay 0 (their y would be s)
+                h[t] = (_Float16)y[t];
+                m[t] = (_Float16)__builtin_fmaf(y[t], one, -(float)h[t]);     // one v_fma_mix per element (`one` is opaque to the compiler: a plain y - h costs cvt + sub + cvt)
+            }
+            _Float16* dst = &zp[buf][row * SPLD + 4 * c4];
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + PLANE) = m;
+        }
+    };
+    f32x4 acc[NT + 1];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto tiles = [&](auto rows, const _Float16* zs) {
+        using R = decltype(rows);
+        if constexpr (R::RA >= 0) {
+            // the four wave branches stay opaque to each other: hipcc otherwise hoists the fragment reads they share above the branch and sinks the
+            // `c += t` below the join -- every tile's fresh accumulator and eight fragments live at once (+68 VGPRs at NT = 7, spills at 3 workgroups per CU)
+            asm volatile("" ::: "memory");
+            sym_tiles_mfma_f16x2<NT, R::RA, R::RB, SPLD, PLANE>(acc, zs, r16, q);
+            constexpr int NACC = R::RA + 1 + (R::RB >= 0 ? R::RB + 1 : 0);
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) asm volatile("" : "+v"(acc[i]));
+        }
+    };
+    auto compute = [&](const int buf) {
+        if (wave == 0) tiles(RowsOf<NT, 0>{}, zp[buf]);
+        else if (wave == 1) tiles(RowsOf<NT, 1>{}, zp[buf]);
+        else if (wave == 2) tiles(RowsOf<NT, 2>{}, zp[buf]);
+        else tiles(RowsOf<NT, 3>{}, zp[buf]);
+    };
+
+    Slice r0, r1;
+    const int nk = (D + BK - 1) / BK;
+    gload(r0, 0);
+    gload(r1, BK);
+    {
+        // the a-priori element bound of train-mode BatchNorm: max_k |beta_k| + |gamma_k| sqrt(N - 1)
+        const float sq = sqrtf((float)(N > 1 ? N - 1 : 1));
+        float bm = 0.f;
+        for (int k = tid; k < D; k += 256) {
+            const float g = bo.has_gamma ? G[k] : 1.0f, be = bo.has_beta ? Bt[k] : 0.0f;
+            bm = fmaxf(bm, __builtin_fmaf(fabsf(g), sq, fabsf(be)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, DKT_WAVE));
+        if (lane == 0) bmax_w[wave] = bm;
+        if (tid == 0) bad = 0;
+    }
+    partial(r0, 0);
+    __syncthreads();
+    {
+        const float bm = fmaxf(fmaxf(fmaxf(bmax_w[0], bmax_w[1]), fmaxf(bmax_w[2], bmax_w[3])), 1e-30f) * 1.01f;
+        const int eb = (int)((__float_as_uint(bm) >> 23) & 0xffu) - 127;
+        const int e = max(-60, min(60, 14 - eb));
+        fscale = __uint_as_float((unsigned)(e + 127) << 23);
+    }
+    fold(r0, 0, 0);
+    lstore(r0, 0);
+    gload(r0, 2 * BK);
+    partial(r1, 1);
+    __syncthreads();
+    // stage kt: image kt & 1 holds slice kt; `near` holds slice kt + 1 raw, its partial sums in table (kt + 1) & 1; `far` is in flight with slice kt + 2
+    auto stage = [&](Slice& near, Slice& far, const int kt, const int par) {      // par = (kt + 1) & 1, a literal at both call sites
+        fold(near, par, (kt + 1) * BK);
+        lstore(near, par);
+        gload(near, (kt + 3) * BK);
+        compute(par ^ 1);
+        partial(far, par ^ 1);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        stage(r1, r0, kt, 1);
+        stage(r0, r1, kt + 1, 0);
+    }
+
+    // ---- row norms from the diagonal of the scaled G' = S^2 Y Y^T, the a-posteriori check, then E_ij = G'_ij rho_i rho_j ----
+    const float thr = (float)D * 16384.f;
+    auto put_diag = [&](const f32x4& t, int row_blk) {
+        if ((r16 >> 2) == q) {
+            const int rr = r16 & 3;
+            const float v = rr == 0 ? t[0] : rr == 1 ? t[1] : rr == 2 ? t[2] : t[3];
+            if (16 * row_blk + r16 < N && !(v >= thr && v <= 3.0e38f)) bad = 1;
+            rho[16 * row_blk + r16] = 1.0f / fmaxf(sqrtf(fmaxf(v, 0.f)), 1e-12f * fscale);      // rho_i / S
+        }
+    };
+    auto diag_of = [&](auto w) {
+        constexpr int W = decltype(w)::value;
+        constexpr int RA = RowsOf<NT, W>::RA, RB = RowsOf<NT, W>::RB;
+        if constexpr (RA >= 0) put_diag(acc[RA], RA);
+        if constexpr (RB >= 0) put_diag(acc[RA + 1 + RB], RB);
+    };
+    if (wave == 0) diag_of(std::integral_constant<int, 0>{});
+    else if (wave == 1) diag_of(std::integral_constant<int, 1>{});
+    else if (wave == 2) diag_of(std::integral_constant<int, 2>{});
+    else diag_of(std::integral_constant<int, 3>{});
+    __syncthreads();
+    const bool flagged = bad != 0;
+    if (tid < N) rnorm[(size_t)b * N + tid] = (flagged && tid == 0) ? __uint_as_float(0x7fc00000u) : rho[tid] * fscale;
+    if (flagged) return;                                 // E of this episode comes from the fix-up launch
+    auto emit = [&](f32x4& t, const int rowblk, const int tj) {
+        const float rj = rho[16 * tj + r16];
+        const f32x4 ri = *reinterpret_cast<const f32x4*>(&rho[16 * rowblk + 4 * q]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) t[reg] *= ri[reg] * rj;
     };
     auto finish = [&](auto w) {
         constexpr int W = decltype(w)::value;
@@ -419,9 +715,13 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
         const float* Wb = W + (size_t)b * nn;
         const float* Eb = Eg + (size_t)b * nn;
         float* el = wl + NP * NP;
-        for (int i = tid; i < nn; i += NTH) {
-            wl[i] = Wb[i];
-            el[i] = Eb[i];
+        DKT_LDS_STAGE_OLD_LOOP(for (int i = tid; i < nn; i += NTH) { wl[i] = Wb[i]; el[i] = Eb[i]; })
+        {
+            LdsStage<NTH, NT> wst, est;                 // all of W and E in flight at once (dkt_split.h)
+            wst.load(Wb, nn, tid);
+            est.load(Eb, nn, tid);
+            wst.store(wl, nn, tid);
+            est.store(el, nn, tid);
         }
         if (tid < NP) rl[tid] = (tid < N) ? rnorm[(size_t)b * N + tid] : 0.f;      // padded rows: rho = 0 -> dY = 0
         __syncthreads();
@@ -648,22 +948,43 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
 #undef FCLK
 }
 
+static int g_stage_synced = 0;                          // twins library: DKT_LDS_STAGE_OLD reaches the device at the first launch and after dkt_reload_env()
+void lds_stage_env_sync_once() {
+    if (!g_stage_synced) { lds_stage_env_sync(); g_stage_synced = 1; }
+}
+
 template <int NT>
 void launch_gram_bn_bwd(const float* W, const float* E, const float* X, const float* a, const float* s, long abs, const float* mean,
                         const float* rstd, const float* rnorm, const float* sc, float* dX, float* dg, float* db, int B, int N, int D,
                         bool train_bn, hipStream_t st) {
+    lds_stage_env_sync_once();
     if (train_bn) hipLaunchKernelGGL((gram_bn_bwd_ep_kernel<NT, true>), dim3(B), dim3(64 * NT), 0, st, W, E, X, a, s, abs, mean, rstd, rnorm, sc, dX, dg, db, N, D);
     else hipLaunchKernelGGL((gram_bn_bwd_ep_kernel<NT, false>), dim3(B), dim3(64 * NT), 0, st, W, E, X, a, s, abs, mean, rstd, rnorm, sc, dX, dg, db, N, D);
+}
+
+// DKT_GRAM_BN_F16 (twins library only; default 1): 0 = the 3-way bf16 split in the train-mode fused forward at every N (the round-3 kernel: A/B, twin test)
+static int g_bn_f16 = -1;
+bool bn_train_f16() {
+    if (g_bn_f16 < 0) { const char* v = dkt_variant_env("DKT_GRAM_BN_F16"); g_bn_f16 = (v && v[0] == '0') ? 0 : 1; }
+    return g_bn_f16 != 0;
 }
 
 template <int NT>
 void launch_gram_bn(const float* X, const float* A, const float* S, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
                     const BnTrainOut* bo) {
     if (bo && bo->epi != 0) {
-        if (bo->epi == 2) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 2>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);       // RBF
-        else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 1>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo);                     // SQDIST
-    } else if (bo) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo);
-    else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{});
+        if (bo->epi == 2) hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 2>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo, 0);       // RBF
+        else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false, 1>), dim3(B), dim3(256), 0, st, X, X, X, 0L, E, nullptr, N, D, *bo, 0);                     // SQDIST
+    } else if (bo) {
+        if constexpr (NT >= 3) {
+            if (bn_train_f16()) {                        // f16 split under the a-priori bound, then the fix-up pass over the episodes it flagged
+                hipLaunchKernelGGL((gram_bn_train_f16_kernel<NT>), dim3(B), dim3(256), 0, st, X, A, S, E, rnorm, N, D, *bo);
+                hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo, 1);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo, 0);
+    } else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{}, 0);
 }
 
 int gram_bn_dispatch(const float* X, const float* a, const float* s, long abs, float* E, float* rnorm, int B, int N, int D, hipStream_t st,
@@ -686,7 +1007,7 @@ int gram_bn_dispatch(const float* X, const float* a, const float* s, long abs, f
 // Episode-resident squared-distance / RBF build of dkt_gram_f32 (symmetric, 32 < N <= 128, D % 4 == 0, 16-byte aligned Z, a batch that
 // fills the GPU); returns false when it does not apply (the generic 64 x 64-tile kernel then runs).
 static int g_dist_ep_minb = -1, g_dist_ep_on = -1;           // DKT_GRAM_EP_MINB / DKT_GRAM_DIST_EP, read at the first call and at dkt_reload_env()
-void dkt_frontend_reload_env() { g_dist_ep_minb = -1; g_dist_ep_on = -1; }
+void dkt_frontend_reload_env() { g_dist_ep_minb = -1; g_dist_ep_on = -1; g_bn_f16 = -1; g_stage_synced = 0; }
 bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
     if (g_dist_ep_minb < 0) { const char* v = getenv("DKT_GRAM_EP_MINB"); g_dist_ep_minb = v ? atoi(v) : 64; }
     if (g_dist_ep_on < 0) { const char* v = dkt_variant_env("DKT_GRAM_DIST_EP"); g_dist_ep_on = (v && v[0] == '0') ? 0 : 1; }

@@ -463,7 +463,12 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
         float* wl = reinterpret_cast<float*>(&zt[0][0]);
         static_assert(sizeof(zt) >= NP * NP * 4, "W does not fit the staging buffer(s)");
         const int nn = N * N;
-        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        DKT_LDS_STAGE_OLD_LOOP(for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];)
+        {
+            LdsStage<NTH, NT> wst;                      // all of W in flight at once (dkt_split.h)
+            wst.load(Wb, nn, tid);
+            wst.store(wl, nn, tid);
+        }
         __syncthreads();
         const int row = wave * 16 + r16;
 #pragma unroll
@@ -628,7 +633,12 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
     {
         float* wl = reinterpret_cast<float*>(lds);
         const int nn = N * N;
-        for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];
+        DKT_LDS_STAGE_OLD_LOOP(for (int i = tid; i < nn; i += NTH) wl[i] = Wb[i];)
+        {
+            LdsStage<NTH, NT> wst;                      // all of W in flight at once (dkt_split.h)
+            wst.load(Wb, nn, tid);
+            wst.store(wl, nn, tid);
+        }
         __syncthreads();
         const int row = wave * 16 + r16;
         float v[KS][8];
@@ -762,6 +772,7 @@ struct GramEnv {
         unit_var = get("DKT_GRAM_UNIT_VAR", 22232); split_var = get("DKT_GRAM_SPLIT_VAR", 11);
         bwd_unit_var = get("DKT_GRAM_BWD_UNIT_VAR", 0); bwd_split_var = get("DKT_GRAM_BWD_SPLIT_VAR", 11);
         bwd_unit_mind = get("DKT_GRAM_BWD_UNIT_MIND", 64); bwd_split_mind = get("DKT_GRAM_BWD_SPLIT_MIND", 1024);
+        lds_stage_env_sync();
     }
 };
 GramEnv& gram_env() {

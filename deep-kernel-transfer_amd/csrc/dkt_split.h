@@ -2,6 +2,7 @@
 // the exact 3-way bf16 split of an fp32 value, the 6-product tile update with two-level accumulation, and the
 // mirrored store of a tile row of a symmetric result.  Header-only (anonymous namespace: one copy per translation unit).
 #pragma once
+#include <hip/hip_runtime.h>
 #include "dkt_common.h"
 #include "dkt_tiles.h"
 
@@ -112,6 +113,51 @@ __device__ __forceinline__ void sym_tiles_mfma_bf16x3(f32x4* acc, const __bf16* 
         for (int tj = 0; tj <= RB; ++tj) tile(acc[RA + 1 + tj], ah, am, al, tj);
     }
 }
+
+
+// ---- an nn-float matrix (W, E of an episode) from global memory into LDS in ONE memory round trip ----
+// Every load is issued before the first LDS store: 16-byte buffer loads at the matrix' dword alignment (an episode starts N * N floats after the
+// previous one), NV = ceil(nn / 4 / NTH) per thread, the last nn % 4 floats by scalar loads.  The plain copy loop `for (i = tid; i < nn; i += NTH)
+// lds[i] = src[i]` compiles to dword loads unrolled eight-fold and DRAINED (vmcnt(0)) per trip plus two remainder loops that drain every one or
+// two loads: 6 - 10 dependent memory round trips per episode at N = 105 (round 5, found in the ISA of the Gram-backward prologues).
+#ifdef DKT_TWINS          // DKT_LDS_STAGE_OLD=1 (twins library): the copy loop this replaced, for same-box A/B runs and the bitwise-twin test
+__device__ int g_lds_stage_old = 0;
+inline void lds_stage_env_sync() {
+    const char* v = getenv("DKT_LDS_STAGE_OLD");
+    const int f = (v && v[0] == '1') ? 1 : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lds_stage_old), &f, sizeof(int));
+}
+#define DKT_LDS_STAGE_OLD_LOOP(stmt) if (g_lds_stage_old) { stmt } else
+#else
+inline void lds_stage_env_sync() {}
+#define DKT_LDS_STAGE_OLD_LOOP(stmt)
+#endif
+template <int NTH, int NV>
+struct LdsStage {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t[NV];
+    float ts;
+    __device__ __forceinline__ void load(const float* __restrict__ src, int nn, int tid) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, nn * 4, 0x00020000);
+        const int nv4 = nn >> 2;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + NTH * i;
+            t[i] = __builtin_amdgcn_raw_buffer_load_b128(r, v < nv4 ? 16 * v : 0x7ffffff0, 0, 0);
+        }
+        const int ti = 4 * nv4 + tid;
+        ts = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, tid < (nn & 3) ? 4 * ti : 0x7ffffff0, 0, 0));
+    }
+    __device__ __forceinline__ void store(float* __restrict__ dst, int nn, int tid) const {      // dst 16-byte aligned
+        const int nv4 = nn >> 2;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + NTH * i;
+            if (v < nv4) *reinterpret_cast<u32x4*>(dst + 4 * v) = t[i];
+        }
+        if (tid < (nn & 3)) dst[4 * nv4 + tid] = ts;
+    }
+};
 
 
 template <int ROW>

@@ -1905,6 +1905,53 @@ def test_one_pass_statistics_and_gram_train_mode(cuda, b, n, d, affine):
     assert torch.equal(e, e3) and torch.equal(st["a"], st3["a"])
 
 
+@pytest.mark.parametrize("n,d", [(105, 1600), (85, 512), (50, 96), (128, 64), (40, 2916)])
+def test_fused_train_forward_f16_split_twins_and_fixup(cuda, monkeypatch, n, d):
+    """dkt_gram_bn_train_f32 at N > 32 (round 5): the scaled 2-way f16 split under train-mode BatchNorm's a-priori element bound in the pipelined kernel
+    (default) against the 3-way bf16 kernel it replaces (DKT_GRAM_BN_F16=0) and float64; and the a-posteriori row check:
+    an episode with a row whose norm is far below the element bound (a sample that sits on the batch mean; one feature with an enormous gamma) is
+    redone by the bf16 kernel in the fix-up launch -- its outputs are then bitwise those of DKT_GRAM_BN_F16=0, its neighbours in the batch untouched."""
+    rng = np.random.default_rng(n * 11 + d)
+    b = 4
+    x = _relu_like(rng, b, n, d)
+    x[1, 3] = (x[1].astype(np.float64).sum(0) - x[1, 3]) / (n - 1)          # episode 1: row 3 on the batch mean -> |y_3| ~ rounding noise (beta = 0 below)
+    gamma = rng.uniform(0.5, 1.5, d).astype(np.float32)
+    xd, gd = dev_t(x, cuda), dev_t(gamma, cuda)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("DKT_GRAM_BN_F16", v)
+        out[v] = ops.gram_bn_train(xd, gd, None, 1e-5)
+    monkeypatch.delenv("DKT_GRAM_BN_F16")
+    e_p, rn_p, st_p = ops.gram_bn_train(xd, gd, None, 1e-5)                  # the product library's default
+    assert torch.equal(e_p, out["1"][0]) and torch.equal(rn_p, out["1"][1]) and torch.equal(st_p["a"], out["1"][2]["a"])
+    e0, rn0, st0 = out["0"]
+    for v in ("1",):
+        e, rn, st = out[v]
+        assert torch.isfinite(e).all() and torch.isfinite(rn).all()
+        for k in ("mean", "rstd", "a", "s", "var_unbiased"):
+            assert rel_l2(st[k].cpu().numpy(), st0[k].cpu().numpy()) < 1e-6, k      # the statistics path is the same arithmetic in all three
+        assert torch.equal(e[1], e0[1]) and torch.equal(rn[1], rn0[1])      # flagged -> the bf16 kernel's result, bit for bit
+        for i in (0, 2, 3):
+            assert not torch.equal(e[i], e0[i])                             # (the check discriminates: an f16 result differs in the last bits)
+            y, _, _ = O.batchnorm1d_train(x[i].astype(np.float64), gamma.astype(np.float64), np.zeros(d))
+            zn = O.l2_normalize(y)
+            err, err0 = np.abs(e[i].cpu().numpy() - zn @ zn.T).max(), np.abs(e0[i].cpu().numpy() - zn @ zn.T).max()
+            assert err < 6e-6 and err < 3.0 * err0 + 2e-6, (v, i, err, err0)
+            assert rel_l2(rn[i].cpu().numpy(), 1.0 / np.linalg.norm(y, axis=1)) < 2e-6
+        assert torch.equal(e, e.transpose(1, 2))
+        monkeypatch.setenv("DKT_GRAM_BN_F16", v)
+        e_a, rn_a, _ = ops.gram_bn_train(xd[2:3].contiguous(), gd, None, 1e-5)          # an episode's result does not depend on its neighbours
+        assert torch.equal(e_a[0], e[2]) and torch.equal(rn_a[0], rn[2])
+        # one feature's gamma dwarfs the rest: the element bound pushes every ordinary row under the flush threshold -> all episodes redone
+        g2 = gamma.copy()
+        g2[0] = 3.0e6
+        e_g, rn_g, _ = ops.gram_bn_train(xd, dev_t(g2, cuda), None, 1e-5)
+        monkeypatch.setenv("DKT_GRAM_BN_F16", "0")
+        e_g0, rn_g0, _ = ops.gram_bn_train(xd, dev_t(g2, cuda), None, 1e-5)
+        assert torch.equal(e_g, e_g0) and torch.equal(rn_g, rn_g0)
+    monkeypatch.delenv("DKT_GRAM_BN_F16")
+
+
 @pytest.mark.parametrize("b,n,d", [(3, 25, 64), (2, 105, 1600), (2, 75, 512)])
 def test_fused_gram_eval_mode_and_plain_cossim(cuda, b, n, d):
     rng = np.random.default_rng(n + d)

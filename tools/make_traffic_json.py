@@ -27,6 +27,7 @@ KERNEL_TABLE = {
     # dkt_gram_f32
     "gram_sym_ep_split_kernel": "dkt_gram_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_sym_tiles_split_kernel": "dkt_gram_f32",
     "gram_sym_bigep_f16x2_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
+    "gram_bn_train_f16_kernel": "dkt_gram_bn_train_f32",
     # dkt_gram_bwd_f32
     "gram_bwd_ep_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
     "gram_bwd_rows_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_big_ep_kernel": "dkt_gram_bwd_f32", "gram_small_bwd_kernel": "dkt_gram_bwd_f32",
