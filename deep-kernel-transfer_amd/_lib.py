@@ -238,6 +238,64 @@ def abi_version_of_header() -> int:
         return int(re.search(r"#define\s+DKT_ABI_VERSION\s+(\d+)", fh.read()).group(1))
 
 
+def device_code_objects(path: str = None) -> list:
+    """The gfx950 code objects (ELF images) inside a built library or object file: the uncompressed clang offload bundles of its .hip_fatbin data."""
+    import struct
+    blob = open(path or LIB_PATH, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], blob.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", blob, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tlen].decode()
+            q += 24 + tlen
+            if "gfx950" in triple and size:
+                out.append(blob[pos + off:pos + off + size])
+        pos = blob.find(magic, pos + len(magic))
+    return out
+
+
+def unprotected_wide_buffer_stores(path: str = None) -> list:
+    """Disassemble the library's device code (llvm-objdump) and list every 12 / 16-byte BUFFER store with a REGISTER in its soffset field whose data
+    registers are written by the next VALU instruction.  hipcc's hazard recogniser skips that form of the store (it inserts the wait state only for a
+    literal soffset); on gfx950 the store then sends whatever the VALU wrote (round 5: dX of a software-pipelined fused backward came out as run-to-run
+    garbage).  The kernels keep the scalar offset in the VGPR offset instead (bstore4, dkt_mfma_tiles.h); this is the audit that they all do."""
+    import re
+    import tempfile
+    objdump = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+    rx_store = re.compile(r"^\s*buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi)\b")
+    rx_dst = re.compile(r"^\s*(v_\w+)\s+(v\[(\d+):(\d+)\]|v(\d+))\b")
+    hits = []
+    for img in device_code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as fh:
+            fh.write(img)
+            fh.flush()
+            res = subprocess.run([objdump, "-d", "--no-show-raw-insn", fh.name], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("llvm-objdump failed: " + res.stderr[:500])
+        kernel, pending = "?", None
+        for line in res.stdout.splitlines():
+            if line.endswith(">:"):
+                kernel, pending = line.split("<")[-1][:-2], None
+                continue
+            text = line.split("//")[0]
+            if not text.strip():
+                continue
+            if pending is not None:
+                m = rx_dst.match(text)
+                if m and not m.group(1).startswith(("v_cmp", "v_mfma", "v_readlane", "v_readfirstlane")):
+                    lo, hi = (int(m.group(3)), int(m.group(4))) if m.group(3) else (int(m.group(5)), int(m.group(5)))
+                    if lo <= pending[1] and hi >= pending[0]:
+                        hits.append((kernel, pending[2].strip(), text.strip()))
+                pending = None
+            m = rx_store.match(text)
+            if m:
+                pending = (int(m.group(1)), int(m.group(2)), text)
+    return hits
+
+
 def load(path: str = None) -> ctypes.CDLL:
     """dlopen the HIP library (the product unless `path` / DKT_AMD_LIB says otherwise) and bind every declared symbol; raises (never falls back) on failure."""
     path = path or _lib_path()

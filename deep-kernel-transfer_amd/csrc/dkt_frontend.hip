@@ -818,16 +818,35 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
     FCLK(0);                                             // prologue (W, E staging, A fragments, first image)
     for (int sl = 0; sl < nslab; ++sl) {
         const int d0 = sl * BD, buf = sl & 1;
-        if (sl + 1 < nslab) gload(d0 + BD);
-        // epilogue operands of this lane's 4 rows x 4 features (d = d0 + 4 r16 + t): issued early, consumed after the MFMAs
+        // epilogue operands of this lane's 4 rows x 4 features (d = d0 + 4 r16 + t).  The lane's staging task IS that patch (jg = tid / 16 = 4 wave + q,
+        // d4 = tid % 16 = r16): the x, a, s that were loaded to stage this slab's image are still in rg / sa / ss -- kept (round 5) instead of loaded a second
+        // time (4 + 2 of the 9 sixteen-byte loads per thread and slab, a third of what the CU pulls through its L1).  Same-box A/B against the second load
+        // (-DDKT_FE_BWD_RELOAD_X, tools/fe_bwd_lib_ab.py, profiles/r05/v6_fe_bwd_lib_ab.log; bitwise equal): N = 105 / D = 1600 0.771 -> 0.724 ms per 2048
+        // episodes, 3.06 -> 2.83 ms per 8192, N = 128: 0.957 -> 0.865 ms; at NT <= 6 the second load stays -- there the shorter live ranges of the reuse
+        // form let a second workgroup onto the CU (162 instead of 174 VGPRs) and that measured 2 - 3 % SLOWER (N = 85 / D = 512: 0.253 -> 0.260 ms).
         const bool din = d0 + 4 * r16 < D;
-        float4 xe[4];
+        float4 xe[4], ea, es;
+#ifdef DKT_FE_BWD_RELOAD_X
+        constexpr bool REUSE = false;
+#else
+        constexpr bool REUSE = NT >= 7;
+#endif
+        if constexpr (REUSE) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int i = 16 * wave + 4 * q + reg;
-            xe[reg] = bload4(xr, (din && i < N) ? (i * D + 4 * r16) * 4 : OOB, d0 * 4);
+            for (int reg = 0; reg < 4; ++reg) xe[reg] = rg[reg];
+            ea = sa;
+            es = ss;
+            if (sl + 1 < nslab) gload(d0 + BD);
+        } else {
+            if (sl + 1 < nslab) gload(d0 + BD);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = 16 * wave + 4 * q + reg;
+                xe[reg] = bload4(xr, (din && i < N) ? (i * D + 4 * r16) * 4 : OOB, d0 * 4);
+            }
+            ea = bload4(ar, din ? 16 * r16 : OOB, d0 * 4);
+            es = bload4(sr, din ? 16 * r16 : OOB, d0 * 4);
         }
-        const float4 ea = bload4(ar, din ? 16 * r16 : OOB, d0 * 4), es = bload4(sr, din ? 16 * r16 : OOB, d0 * 4);
         float4 em = make_float4(0.f, 0.f, 0.f, 0.f), er = em;
         if constexpr (TRAIN_BN) {
             em = bload4(mr, din ? 16 * r16 : OOB, d0 * 4);

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __rest
             for (int q = 0; q < 4; ++q) {
                 const int row = 16 * ib + 4 * g + q;
                 const u32x4 v = {__float_as_uint(acc[ib][0][q]), __float_as_uint(acc[ib][1][q]), __float_as_uint(acc[ib][2][q]), __float_as_uint(acc[ib][3][q])};
-                __builtin_amdgcn_raw_buffer_store_b128(v, dr, (row < N && col_ok) ? (row * D + 4 * c) * 4 : SM_OOB, ch * 256, 0);
+                // (the chunk offset rides in the VGPR offset, soffset is the literal 0: see bstore4 in dkt_mfma_tiles.h)
+                __builtin_amdgcn_raw_buffer_store_b128(v, dr, (row < N && col_ok) ? (row * D + 4 * c) * 4 + ch * 256 : SM_OOB, 0, 0);
             }
         }
     };

@@ -17,9 +17,13 @@ __device__ __forceinline__ f32x4 bload4(brsrc r, int voff, int soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
+// 16-byte stores: the scalar offset is folded into the VGPR offset and the instruction's soffset stays the literal 0.  With a REGISTER in the soffset
+// field hipcc assumes that the store's data registers may be rewritten by the very next VALU instruction (its hazard recogniser skips that form) -- on
+// gfx950 they may not: a loop that stored dX with soffset = 4 d0 wrote garbage that changed from run to run until the offset moved into the VGPR
+// (round 5, the dropped software-pipelined fused backward; profiles/r05/v5_stage_ab.log).
 __device__ __forceinline__ void bstore4(brsrc r, f32x4 x, int voff, int soff) {
     const u32x4 v = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)((unsigned)voff + (unsigned)soff), 0, 0);
 }
 __device__ __forceinline__ void bstore1(brsrc r, float x, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
