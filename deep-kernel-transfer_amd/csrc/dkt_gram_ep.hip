@@ -885,9 +885,10 @@ void dkt_frontend_reload_env();         // dkt_frontend.hip: DKT_GRAM_EP_MINB / 
 void dkt_mll_reload_env();              // dkt_mll.hip: DKT_MLL_F32MFMA, DKT_MLL_P2_GUARD
 void dkt_gram_big_reload_env();         // dkt_gram_big.hip: DKT_GRAM_BIG_EP
 void dkt_classkernel_reload_env();      // dkt_classkernel.hip: DKT_CLASS_BWD_V4
+void dkt_gram_small_reload_env();       // dkt_gram_small.hip: DKT_GRAM_SMALL_WG
 extern "C" void dkt_reload_env(void) {
     gram_env().load(); dkt_mll_h2_reload_env(); dkt_mll_tiled_reload_env(); dkt_frontend_reload_env(); dkt_mll_reload_env(); dkt_gram_big_reload_env();
-    dkt_classkernel_reload_env();
+    dkt_classkernel_reload_env(); dkt_gram_small_reload_env();
 }
 
 // DKT_GRAM_SPLIT (default 1): the split-precision kernels may be used (0: exact-fp32 MFMA kernels everywhere) -- for dkt_gram_big.hip

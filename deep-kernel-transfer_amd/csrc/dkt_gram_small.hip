@@ -35,13 +35,16 @@ __device__ __forceinline__ f32x4 sm_load4(brsrc r, int voff, int soff) {
 
 constexpr int SM_PF = 4;                 // 16-feature steps in flight
 
-template <int KIND, int NB>              // NB = 1: N <= 16, NB = 2: N <= 32
+// WGT (round 5): a WORKGROUP per task instead of a wave per task -- wave w takes the feature blocks w, w + 4, ... (64 features each), so that the four waves
+// of a workgroup pull 1 KB of every row at a time instead of 256 B of the rows of four different tasks; the partial Grams meet in LDS at the end.
+template <int KIND, int NB, bool WGT>    // NB = 1: N <= 16, NB = 2: N <= 32
 __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
                                                          const float* __restrict__ lengthscale) {
     __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
+    __shared__ f32x4 part[WGT ? 3 : 1][NB * (NB + 1) / 2][64];      // WGT: the partial Grams of waves 1..3
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;                  // (no workgroup barrier below: the LDS scratch is per wave)
+    const int b = WGT ? blockIdx.x : blockIdx.x * 4 + wave;
+    if (b >= B) return;                  // (wave per task: no workgroup barrier below, the LDS scratch is per wave; WGT: b is the workgroup's)
     const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
     int voff[NB];
 #pragma unroll
@@ -57,9 +60,10 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
     f32x4 acc[NB * (NB + 1) / 2];
 #pragma unroll
     for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int sfirst = WGT ? wave * SM_PF : 0, sstride = WGT ? 4 * SM_PF : SM_PF;
 #pragma unroll
-    for (int p = 0; p < SM_PF; ++p) load(p, p);
-    for (int s0 = 0; s0 < nstep; s0 += SM_PF) {
+    for (int p = 0; p < SM_PF; ++p) load(p, sfirst + p);
+    for (int s0 = sfirst; s0 < nstep; s0 += sstride) {
 #pragma unroll
         for (int p = 0; p < SM_PF; ++p) {
             f32x4 xb[NB];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
                     for (int t = 0; t < 4; ++t) xb[blk][t] = row_ok ? xb[blk][t] - ref[p][t] : 0.f;
                 }
             }
-            load(p, s0 + p + SM_PF);
+            load(p, s0 + p + sstride);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[0][t], xb[0][t], acc[0], 0, 0, 0);
@@ -83,6 +87,18 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
                 }
             }
         }
+    }
+    if constexpr (WGT) {                 // partial Grams of waves 1..3 -> wave 0 (fixed order: bitwise reproducible)
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NB * (NB + 1) / 2; ++i) part[wave - 1][i][lane] = acc[i];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] += part[w][i][lane];
     }
     // ---- epilogue.  C / D layout: lane (g, c = r), register q  <->  element [4 g + q][c] ----
     float* Eb = E + (size_t)b * N * N;
@@ -128,11 +144,12 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
     }
 }
 
-// dZ[b] = s_b (W[b] + W[b]^T) Z[b], N <= 32
+// dZ[b] = s_b (W[b] + W[b]^T) Z[b], N <= 32.  WGT: a workgroup per task, wave w takes the 64-feature chunks w, w + 4, ... (as in the forward)
+template <bool WGT>
 __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z, float* __restrict__ dZ,
                                                              int B, int N, int D, const float* __restrict__ ep_scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const int b = blockIdx.x * 4 + wave;
+    const int b = WGT ? blockIdx.x : blockIdx.x * 4 + wave;
     if (b >= B) return;
     const float sc = ep_scale ? ep_scale[b] : 1.0f;
     const float* Wb = W + (size_t)b * N * N;
@@ -187,27 +204,44 @@ __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __rest
             }
         }
     };
-    load(z0, 0);
-    for (int ch = 0; ch < nchunk; ch += 2) {
-        load(z1, ch + 1);
+    const int c0 = WGT ? wave : 0, cs = WGT ? 4 : 1;
+    load(z0, c0);
+    for (int ch = c0; ch < nchunk; ch += 2 * cs) {
+        load(z1, ch + cs);
         chunk(z0, ch);
-        load(z0, ch + 2);
-        if (ch + 1 < nchunk) chunk(z1, ch + 1);
+        load(z0, ch + 2 * cs);
+        if (ch + cs < nchunk) chunk(z1, ch + cs);
     }
 }
 
 }  // namespace
 
+// Workgroup per task for long rows (the QMUL head's 19 x 2916), a wave per task below (a 64-feature row leaves three of the four waves idle).  Same-box
+// A/B (tools/small_wg_ab.py, profiles/r05/v7_small_wg_ab.log; per 8192 tasks): backward 19 x 2916 0.941 -> 0.830 ms, 10 x 2916 0.488 -> 0.402, 25 x 1600
+// 0.514 -> 0.492, 19 x 512 0.130 -> 0.133, 25 x 64 0.035 -> 0.068: from 1024 features.  Forward: equal at 8192 tasks of 19 x 2916 (0.441 / 0.438 ms),
+// 0.076 -> 0.053 ms at 1024 tasks, 25 x 1600 0.261 -> 0.271: from 2048 features.  Twins library: DKT_GRAM_SMALL_WG=0 / 1 forces either form.
+static int g_small_wg = -2;
+void dkt_gram_small_reload_env() { g_small_wg = -2; }
+static bool small_wgt(int D, int mind) {
+    if (g_small_wg == -2) { const char* v = dkt_variant_env("DKT_GRAM_SMALL_WG"); g_small_wg = v ? atoi(v) : -1; }
+    if (g_small_wg >= 0) return g_small_wg != 0;
+    return D >= mind;
+}
+
 // Symmetric Gram of small episodes (N <= 32, D % 4 == 0, 16-byte aligned Z); returns false when it does not apply.
 bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
     if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
-    const dim3 grid((B + 3) / 4), block(256);
+    // workgroup per task: the forward from 2048 features (16 < N <= 32, linear / RBF: the QMUL head), see small_wgt()
+    const bool wgt = small_wgt(D, 2048) && N > 16 && kind != DKT_KERNEL_SQDIST;
+    const dim3 grid(wgt ? B : (B + 3) / 4), block(256);
 #define DKT_SM_LAUNCH(K)                                                                                              \
     do {                                                                                                              \
-        if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1>), grid, block, 0, st, Z, E, B, N, D, lengthscale);   \
-        else hipLaunchKernelGGL((gram_small_kernel<K, 2>), grid, block, 0, st, Z, E, B, N, D, lengthscale);           \
+        if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1, false>), grid, block, 0, st, Z, E, B, N, D, lengthscale);   \
+        else hipLaunchKernelGGL((gram_small_kernel<K, 2, false>), grid, block, 0, st, Z, E, B, N, D, lengthscale);           \
     } while (0)
-    if (kind == DKT_KERNEL_LINEAR) DKT_SM_LAUNCH(DKT_KERNEL_LINEAR);
+    if (wgt && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, true>), grid, block, 0, st, Z, E, B, N, D, lengthscale);
+    else if (wgt && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, true>), grid, block, 0, st, Z, E, B, N, D, lengthscale);
+    else if (kind == DKT_KERNEL_LINEAR) DKT_SM_LAUNCH(DKT_KERNEL_LINEAR);
     else if (kind == DKT_KERNEL_RBF) DKT_SM_LAUNCH(DKT_KERNEL_RBF);
     else if (kind == DKT_KERNEL_SQDIST) DKT_SM_LAUNCH(DKT_KERNEL_SQDIST);
     else return false;
@@ -217,6 +251,7 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
 
 bool dkt_gram_small_bwd_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
     if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
-    hipLaunchKernelGGL(gram_small_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
+    if (small_wgt(D, 1024)) hipLaunchKernelGGL(gram_small_bwd_kernel<true>, dim3(B), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
+    else hipLaunchKernelGGL(gram_small_bwd_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
     return true;
 }

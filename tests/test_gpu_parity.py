@@ -1905,6 +1905,37 @@ def test_one_pass_statistics_and_gram_train_mode(cuda, b, n, d, affine):
     assert torch.equal(e, e3) and torch.equal(st["a"], st3["a"])
 
 
+@pytest.mark.parametrize("b,n,d,kind", [(5, 19, 2916, "rbf"), (3, 25, 1600, "linear"), (6, 32, 2052, "linear"), (2, 17, 4096, "rbf"), (7, 10, 2916, "rbf")])
+def test_small_gram_workgroup_per_task_twin(cuda, monkeypatch, b, n, d, kind):
+    """N <= 32 with long rows (round 5): a workgroup per task (DKT_GRAM_SMALL_WG=1; the default from 2048 / 1024 features) against the wave-per-task kernels
+    (=0) and float64 -- the forward sums its four partial Grams in a fixed order (equal to rounding, bitwise reproducible), the backward is bitwise equal."""
+    rng = np.random.default_rng(n * 7 + d)
+    z = (rng.standard_normal((b, n, d)) * 0.05).astype(np.float32)
+    w = (rng.standard_normal((b, n, n)) * 0.1).astype(np.float32)
+    zd, wd = dev_t(z, cuda), dev_t(w, cuda)
+    ls = torch.tensor([1.1], device=cuda)
+    k = ops.KERNEL_RBF if kind == "rbf" else ops.KERNEL_LINEAR
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("DKT_GRAM_SMALL_WG", v)
+        out[v] = (ops.gram(zd, None, k, ls if kind == "rbf" else None), ops.gram_bwd(wd, zd))
+        e2 = ops.gram(zd, None, k, ls if kind == "rbf" else None)
+        assert torch.equal(e2, out[v][0])
+    monkeypatch.delenv("DKT_GRAM_SMALL_WG")
+    assert torch.equal(out["0"][1], out["1"][1])
+    z64 = z.astype(np.float64)
+    for i in range(b):
+        g = z64[i] @ z64[i].T
+        if kind == "rbf":
+            d2 = np.maximum(np.diag(g)[:, None] + np.diag(g)[None, :] - 2 * g, 0.0)
+            g = np.exp(-0.5 * d2 / 1.1 ** 2)
+        for v in ("0", "1"):
+            assert np.abs(out[v][0][i].cpu().numpy() - g).max() < 2e-6 * max(1.0, np.abs(g).max()), (v, i)
+        dz = (w[i].astype(np.float64) + w[i].astype(np.float64).T) @ z64[i]
+        assert rel_l2(out["1"][1][i].cpu().numpy(), dz) < 2e-6
+    assert torch.equal(out["1"][0], out["1"][0].transpose(1, 2))
+
+
 @pytest.mark.parametrize("n,d", [(105, 1600), (85, 512), (50, 96), (128, 64), (40, 2916)])
 def test_fused_train_forward_f16_split_twins_and_fixup(cuda, monkeypatch, n, d):
     """dkt_gram_bn_train_f32 at N > 32 (round 5): the scaled 2-way f16 split under train-mode BatchNorm's a-priori element bound in the pipelined kernel
