@@ -265,6 +265,9 @@ int dkt_gram_bn_f32(const float* X, const float* a, const float* s, long ab_bstr
  *   32-feature slice are taken while all N rows of the slice sit in the workgroup's registers on their way into LDS, folded into
  *   a / s and applied to the same registers.  Outputs as dkt_bn_stats_f32 (mean, rstd, a, s, var_unbiased: each [B,D];
  *   var_unbiased may be NULL) and dkt_gram_bn_f32 (E, rnorm).  gamma / beta: [D] or NULL (1 / 0).  N <= 128, D % 4 == 0.
+ *   Round 5: at N > 32 the products run as a scaled 2-way f16 split whose scale comes from train-mode BatchNorm's a-priori bound
+ *   |y| <= |beta| + |gamma| sqrt(N - 1); an episode with a row whose norm is too far below that bound for the split (checked on the device) is
+ *   recomputed by the 3-way bf16 kernel in a second launch of the same call -- two launches on `stream`, results to fp32 accuracy either way.
  *   Replaces bn_out in train mode + F.normalize + LinearKernel (methods/DKT.py:48, 141-142, 375-378) of a training episode.
  */
 int dkt_gram_bn_train_f32(const float* X, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
