@@ -585,8 +585,9 @@ __global__ __launch_bounds__(64 * NT, NBUF == 1 ? 4 : 2) void gram_bwd_ep_bf16x3
 //     [2^14, 2^15)) before the split -- exact, and undone per output row in the epilogue together with the 2^-15 of Z;
 //   * the staging copy of W shares the LDS with both stage buffers (74 KB, 2 workgroups per CU).
 //   * POL (measurement variants): bit 0 = non-temporal dZ stores, bit 1 = non-temporal Z loads (aux = 2)
+// (waves per SIMD the register allocation must leave room for: two workgroups of NT waves per CU -- 4 at NT >= 7, i.e. <= 128 VGPRs)
 template <int NT, int NBUF, int PF, int POL = 0>
-__global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
+__global__ __launch_bounds__(64 * NT, (2 * NT + 3) / 4) void gram_bwd_ep_f16x2_kernel(const float* __restrict__ W, const float* __restrict__ Z,
                                                                       float* __restrict__ dZ, int N, int D,
                                                                       const float* __restrict__ ep_scale) {
     constexpr int NP = 16 * NT;
@@ -613,14 +614,14 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
 
     const int d4 = tid & 15, jg = tid >> 4;
     const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
-    int voff[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) voff[rr] = (4 * jg + rr < N) ? ((4 * jg + rr) * D + 4 * d4) * 4 : 0x7ffffff0;
+    const __amdgpu_buffer_rsrc_t dzr = __builtin_amdgcn_make_buffer_rsrc(dZb, 0, N * D * 4, 0x00020000);
+    // one offset register for the thread's four rows: a row past N starts behind the descriptor's end by itself (the range check sees voffset only)
+    const int voff0 = (4 * jg * D + 4 * d4) * 4;
     auto gload = [&](float4 (&rg)[4], int d0) {
-        const bool in = d0 + 4 * d4 < D;
+        const int vb = (d0 + 4 * d4 < D) ? voff0 : 0x7ffffff0;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, in ? voff[rr] : 0x7ffffff0, d0 * 4, (POL & 2) ? 2 : 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, vb + rr * D * 4, d0 * 4, (POL & 2) ? 2 : 0);
             rg[rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     };
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
             *reinterpret_cast<f16x4*>(dst + PLANE) = m;
         }
     };
+    const int st_row0 = wave * 16 + 4 * q;               // first of this lane's four output rows
     auto compute_store = [&](int buf, int d0) {
         f32x4 acc[4];
 #pragma unroll
@@ -710,17 +712,35 @@ __global__ __launch_bounds__(64 * NT, 2) void gram_bwd_ep_f16x2_kernel(const flo
             }
         }
         const int d = d0 + 4 * r16;
+#ifndef DKT_GRAM_BWD_BRANCHY_STORES
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = wave * 16 + 4 * q + reg;
             const float u = rowinv[row];
+#ifdef DKT_GRAM_BWD_BRANCHY_STORES        // the round-2..4 form: a global store inside an exec-masked block per row group (A/B builds, tools/gram_bwd_lib_ab.py)
             if (row < N && d < D) {
                 const f32x4 o = {acc[0][reg] * u, acc[1][reg] * u, acc[2][reg] * u, acc[3][reg] * u};
                 f32x4* dst = reinterpret_cast<f32x4*>(dZb + (size_t)row * D + d);
                 if constexpr (POL & 1) __builtin_nontemporal_store(o, dst);
                 else *dst = o;
             }
+#else
+            // Branch-free (round 5): rows / features past the end get an out-of-range offset.  Behind a branch hipcc cannot know how many stores are
+            // outstanding when the NEXT image's registers are waited for and counts none -- `vmcnt(4)` for the last of them, which with the four stores
+            // really in flight also drains the four FAR loads issued at the top of the stage: the second prefetch stage never stayed in flight.
+            // (soffset stays the literal 0: see bstore4 in dkt_mfma_tiles.h.)
+            // One live offset register: rows past N fall behind the descriptor's end by themselves ((row D + d) 4 >= 4 N D), only a feature past D needs the mask.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = {__float_as_uint(acc[0][reg] * u), __float_as_uint(acc[1][reg] * u), __float_as_uint(acc[2][reg] * u), __float_as_uint(acc[3][reg] * u)};
+            const int so = (d < D) ? (st_row0 + reg) * D * 4 + d * 4 : 0x7ffffff0;
+            __builtin_amdgcn_raw_buffer_store_b128(o, dzr, so, 0, (POL & 1) ? 2 : 0);
+#endif
         }
+#ifndef DKT_GRAM_BWD_BRANCHY_STORES
+        __builtin_amdgcn_sched_barrier(0);               // (the exec-masked blocks used to keep the staging code's live ranges out of this phase: 128 VGPRs = 2 workgroups per CU)
+#endif
     };
     auto stage = [&](float4 (&rnear)[4], float4 (&rfar)[4], int sl) {
         const int buf = (NBUF == 2) ? (sl & 1) : 0;
