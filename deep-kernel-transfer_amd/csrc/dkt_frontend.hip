@@ -27,6 +27,11 @@ __device__ __forceinline__ float4 bload4(brsrc_t r, int voff, int soff) {
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 constexpr int OOB = 0x7ffffff0;
+__device__ __forceinline__ void fe_store4(brsrc_t r, int voff, float a0, float a1, float a2, float a3) {     // soffset = literal 0: see bstore4, dkt_mfma_tiles.h
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), __float_as_uint(a3)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Batch statistics: grid (ceil(D/4 / 256), B); a thread owns 4 adjacent features and walks the N rows of its episode
@@ -687,6 +692,9 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
     const brsrc_t mr = mk_rsrc(TRAIN_BN ? mean + (size_t)b * D : Aa, D * 4);
     const brsrc_t rr_ = mk_rsrc(TRAIN_BN ? rstd + (size_t)b * D : Aa, D * 4);
     float* dXb = dX + (size_t)b * N * D;
+    const brsrc_t dxr = mk_rsrc(dXb, N * D * 4);
+    const brsrc_t dgr = mk_rsrc(TRAIN_BN ? dgamma_part + (size_t)b * D : dXb, TRAIN_BN ? D * 4 : 0);
+    const brsrc_t dbr = mk_rsrc(TRAIN_BN ? dbeta_part + (size_t)b * D : dXb, TRAIN_BN ? D * 4 : 0);
 
     // staging task of this thread: rows 4 jg .. 4 jg + 3, features 4 d4 .. 4 d4 + 3 of the slab
     const int d4 = tid & 15, jg = tid >> 4;
@@ -831,14 +839,19 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
 #else
         constexpr bool REUSE = NT >= 7;
 #endif
+        // (this slab's own operands are issued BEFORE the next slab's staging loads: the counter is in order, and a wait for mean / rstd issued behind the
+        // prefetch -- the round-3 order -- was a `vmcnt(0)` that drained the prefetch in front of every epilogue)
+        float4 em = make_float4(0.f, 0.f, 0.f, 0.f), er = em;
+        if constexpr (TRAIN_BN) {
+            em = bload4(mr, din ? 16 * r16 : OOB, d0 * 4);
+            er = bload4(rr_, din ? 16 * r16 : OOB, d0 * 4);
+        }
         if constexpr (REUSE) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) xe[reg] = rg[reg];
             ea = sa;
             es = ss;
-            if (sl + 1 < nslab) gload(d0 + BD);
         } else {
-            if (sl + 1 < nslab) gload(d0 + BD);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int i = 16 * wave + 4 * q + reg;
@@ -847,11 +860,7 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
             ea = bload4(ar, din ? 16 * r16 : OOB, d0 * 4);
             es = bload4(sr, din ? 16 * r16 : OOB, d0 * 4);
         }
-        float4 em = make_float4(0.f, 0.f, 0.f, 0.f), er = em;
-        if constexpr (TRAIN_BN) {
-            em = bload4(mr, din ? 16 * r16 : OOB, d0 * 4);
-            er = bload4(rr_, din ? 16 * r16 : OOB, d0 * 4);
-        }
+        gload(d0 + BD);                                  // unconditional (past D: every offset out of range, zeros): behind a branch the compiler cannot count these six loads
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -919,7 +928,7 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
             dst[4 + idx] = w2[1];
         }
         FCLK(3);                                         // first half of the epilogue
-        if (sl + 1 < nslab) lstore(buf ^ 1);             // the other image buffer: last read before the previous barrier
+        lstore(buf ^ 1);                                 // the other image buffer: last read before the previous barrier (unconditional: behind the last slab it stages zeros)
         FCLK(4);                                         // split + LDS stores of the next image
         __syncthreads();                                 // next image staged; column partials of every wave published
         FCLK(5);                                         // barrier wait
@@ -932,11 +941,11 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
                 m1p[0] += (f32x2){p1[0], p1[1]}; m1p[1] += (f32x2){p1[2], p1[3]};
                 m2p[0] += (f32x2){p2[0], p2[1]}; m2p[1] += (f32x2){p2[2], p2[3]};
             }
-            if (wave == 0 && q == 0 && din) {
-                const size_t o = (size_t)b * D + d0 + 4 * r16;
-                *reinterpret_cast<float4*>(dbeta_part + o) = make_float4(m1p[0].x, m1p[0].y, m1p[1].x, m1p[1].y);
-                *reinterpret_cast<float4*>(dgamma_part + o) = make_float4(m2p[0].x, m2p[0].y, m2p[1].x, m2p[1].y);
-            }
+            // (branch-free stores, round 5: lanes with nothing to store get an out-of-range offset -- behind a branch the compiler counts no store as
+            // outstanding, and its `vmcnt(0)` in front of the next slab's operands drained these stores at the top of every trip; soffset stays 0)
+            const int po = (wave == 0 && q == 0 && din) ? (d0 + 4 * r16) * 4 : OOB;
+            fe_store4(dbr, po, m1p[0].x, m1p[0].y, m1p[1].x, m1p[1].y);
+            fe_store4(dgr, po, m2p[0].x, m2p[0].y, m2p[1].x, m2p[1].y);
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 m1p[p2] *= inv_n;
@@ -953,7 +962,7 @@ __global__ __launch_bounds__(64 * NT, DKT_FE_BWD_WPE) void gram_bn_bwd_ep_kernel
                 if constexpr (TRAIN_BN) vv = vv - m1p[p2] - xh2[reg][p2] * m2p[p2];
                 o2[p2] = a2[p2] * vv;
             }
-            if (i < N && din) *reinterpret_cast<float4*>(dXb + (size_t)i * D + d0 + 4 * r16) = make_float4(o2[0].x, o2[0].y, o2[1].x, o2[1].y);
+            fe_store4(dxr, (i < N && din) ? (i * D + d0 + 4 * r16) * 4 : OOB, o2[0].x, o2[0].y, o2[1].x, o2[1].y);
         }
         FCLK(6);                                         // second half of the epilogue + dX stores
         // no second barrier: cs[buf] and image[buf] are written again two slabs on, i.e. behind the next slab's barrier

@@ -59,14 +59,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_
     // ---- Z staging: thread = 4 rows (4 jg .. 4 jg + 3, + 128 per pass) x 4 features (4 d4 .. 4 d4 + 3) ----
     const int d4 = tid & 7, jg = tid >> 3;
     const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zb), 0, N * D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dzr = __builtin_amdgcn_make_buffer_rsrc(dZb, 0, N * D * 4, 0x00020000);
+    // The per-thread offsets are loop-invariant (round 5): a feature past D in a ragged last slab is NOT masked -- it reads the next row's first features
+    // (unit-row values; behind the last row: 0 through the descriptor) into image columns whose outputs the dZ store drops (a column of dZ depends on
+    // that column of Z only).  With the mask the offsets were recomputed per slab INTO the registers the loads return to, and the `vmcnt` waits hipcc
+    // put in front of those writes (it cannot prove across the back edge that the previous loads have landed) drained the slab's dZ stores every trip:
+    // the 12 - 16 % "issue of the next slab's loads" of profiles/r04/v12_gram_bwd_phase_clocks.log.
     auto gload = [&](float4 (&rg)[NPASS][4], int d0) {
-        const bool in = d0 + 4 * d4 < D;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = RPP * p + 4 * jg + rr;
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (in && row < N) ? (row * D + 4 * d4) * 4 : 0x7ffffff0, d0 * 4, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(zr, (row < N) ? (row * D + 4 * d4) * 4 : 0x7ffffff0, d0 * 4, 0);
                 rg[p][rr] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
     };
@@ -203,11 +208,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gram_bwd_rows_f16x2_
         for (int reg = 0; reg < 4; ++reg) {
             const int lr = 16 * wave + 4 * q + reg, row = r0 + lr;
             const float u = rowinv[lr];
+#ifdef DKT_GRAM_BWD_BRANCHY_STORES        // the round-4 form (A/B builds)
             if (row < N && d < D) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const f32x2 o = {acc[0][reg] * u, acc[1][reg] * u};
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(dZb + (size_t)row * D + d));
             }
+#else
+            // Branch-free (round 5, as in gram_bwd_ep_f16x2_kernel): behind a branch the compiler counts no store as outstanding and waits `vmcnt(0)` for the
+            // last register of the next slab -- which drains THIS slab's stores (their write acknowledgements) before the staging can go on, with one
+            // workgroup per CU and nothing else to run.  Rows past N fall behind the descriptor's end by themselves; a feature past D needs the mask.
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 o = {__float_as_uint(acc[0][reg] * u), __float_as_uint(acc[1][reg] * u)};
+            __builtin_amdgcn_raw_buffer_store_b64(o, dzr, (d < D) ? (row * D + d) * 4 : 0x7ffffff0, 0, 2);
+#endif
         }
         GBW_CLK(3);                                          // dZ stores
         if constexpr (NBUF == 1) __syncthreads();
