@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
                                                          const float* __restrict__ lengthscale) {
     __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
     __shared__ f32x4 part[WGT ? 3 : 1][NB * (NB + 1) / 2][64];      // WGT: the partial Grams of waves 1..3
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    // (wave through readfirstlane: as a plain threadIdx.x >> 6 it is a VGPR value to the compiler, and every buffer load whose scalar offset or descriptor
+    // depends on it gets a readfirstlane / compare / branch "waterfall" loop around it -- round 5, found in the ISA of the workgroup-per-task kernels)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
     const int b = WGT ? blockIdx.x : blockIdx.x * 4 + wave;
     if (b >= B) return;                  // (wave per task: no workgroup barrier below, the LDS scratch is per wave; WGT: b is the workgroup's)
     const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
@@ -148,21 +150,32 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
 template <bool WGT>
 __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z, float* __restrict__ dZ,
                                                              int B, int N, int D, const float* __restrict__ ep_scale) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int b = WGT ? blockIdx.x : blockIdx.x * 4 + wave;
     if (b >= B) return;
     const float sc = ep_scale ? ep_scale[b] : 1.0f;
-    const float* Wb = W + (size_t)b * N * N;
     const int nq = (N + 3) >> 2;                                       // k-quads: rows j = 4 kk + g of Z
-    // A operands: lane (g, r = c): s (W + W^T)[16 ib + r][4 kk + g]
+    // A operands: lane (g, r = c): s (W + W^T)[16 ib + r][4 kk + g].  All 32 loads in flight at once (buffer loads, out-of-range offset outside the
+    // matrix): as `(i < N && j < N) ? W[..] + W[..] : 0` the compiler branched around every pair and waited for it on the spot -- sixteen dependent memory
+    // round trips at the head of every wave (round 5, found in the ISA).
+    const brsrc wr = sm_rsrc(W + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
     float a[2][8];
+    {
+        float w1[2][8], w2[2][8];
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
+        for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int i = 16 * ib + c, j = 4 * kk + g;
-            a[ib][kk] = (i < N && j < N) ? sc * (Wb[(size_t)i * N + j] + Wb[(size_t)j * N + i]) : 0.f;
-        }
+            for (int kk = 0; kk < 8; ++kk) {
+                const int i = 16 * ib + c, j = 4 * kk + g;
+                const bool ok = i < N && j < N;
+                w1[ib][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, ok ? (i * N + j) * 4 : SM_OOB, 0, 0));
+                w2[ib][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, ok ? (j * N + i) * 4 : SM_OOB, 0, 0));
+            }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a[ib][kk] = sc * (w1[ib][kk] + w2[ib][kk]);
+    }
     const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
     const brsrc dr = sm_rsrc(dZ + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
     const bool two = N > 16;
@@ -171,8 +184,8 @@ __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __rest
     auto load = [&](f32x4 (&zb)[8], const int ch) {
         const bool in = ch < nchunk && 64 * ch + 4 * c < D;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-            zb[kk] = (kk < nq) ? sm_load4(zr, (in && 4 * kk + g < N) ? ((4 * kk + g) * D + 4 * c) * 4 : SM_OOB, ch * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < 8; ++kk)      // (unconditional: a k-quad past N loads zeros through the descriptor.  Behind the uniform `kk < nq` branch the compiler could not
+            zb[kk] = sm_load4(zr, (in && 4 * kk + g < N) ? ((4 * kk + g) * D + 4 * c) * 4 : SM_OOB, ch * 256);      //  count the loads and waited `vmcnt(0)` -- for the prefetch too)
     };
     auto chunk = [&](const f32x4 (&zb)[8], const int ch) {
         f32x4 acc[2][4];
