@@ -127,6 +127,88 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd(const float* __restric
     }
 }
 
+// The same chain rule for N <= 128 and C <= 8 (round 5; every 5-way episode): the kernel above walks a row element by element and class by class -- one
+// 4-byte load, one exp, one LDS read-modify-write and a division per step, each class's load issued after the previous class was consumed: 0.26 of HBM at
+// N = 105, C = 5.  Here a wave owns a row per trip (lanes = columns j and j + 64), issues the row's 2 (C + 1) loads at once (buffer loads; columns past N and
+// classes past C through an out-of-range offset: no branch), keeps the per-class constants and the parameter-gradient partials in registers, and
+// stores through the descriptor as well.  Same sums in the same order per output element as the kernel above up to the factoring of -2 u / l.
+template <int KIND>
+__global__ __launch_bounds__(CKB_T) void class_kernel_bwd_n128(const float* __restrict__ W, const float* __restrict__ base,
+                                                             const float* __restrict__ param, int power, float* __restrict__ Wp,
+                                                             float* __restrict__ dparam, int C, int N, int nsplit) {
+    constexpr int CM = 8;
+    __shared__ float red[CM][8];
+    const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows_per = (N + nsplit - 1) / nsplit, row0 = sp * rows_per, row1 = min(N, row0 + rows_per);
+    const int nn = N * N;
+    typedef __amdgpu_buffer_rsrc_t brs;
+    const brs wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (size_t)b * C * nn), 0, (unsigned)(C * nn * 4), 0x00020000);
+    const brs br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (size_t)b * nn), 0, (unsigned)(nn * 4), 0x00020000);
+    const brs pr = __builtin_amdgcn_make_buffer_rsrc(Wp + (size_t)b * nn, 0, (unsigned)(nn * 4), 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    float prm[CM], il2[CM], m2p[CM], dp[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const float p = c < C ? param[c] : 1.0f;
+        prm[c] = c < C ? p : 0.0f;                                       // POLY: offset
+        il2[c] = c < C ? 1.0f / (p * p) : 0.0f;
+        m2p[c] = -2.0f / p;
+        dp[c] = 0.f;
+    }
+    const bool in0 = lane < N, in1 = lane + 64 < N;
+    for (int i = row0 + wave; i < row1; i += CKB_T / 64) {
+        const int o0 = in0 ? (i * N + lane) * 4 : OOB, o1 = in1 ? (i * N + lane + 64) * 4 : OOB;
+        float v[2], w[CM][2];
+        v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, o0, 0, 0));
+        v[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(br, o1, 0, 0));
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            w[c][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, c < C ? o0 : OOB, c * nn * 4, 0));
+            w[c][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, c < C ? o1 : OOB, c * nn * 4, 0));
+        }
+        float a[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                float f, df;
+                if constexpr (KIND == DKT_CLASSMAP_POLY) {
+                    class_map<KIND>(v[e] + prm[c], power, f, df);
+                    const float g = w[c][e] * df;
+                    a[e] += g;
+                    dp[c] += g;
+                } else {
+                    const float u = v[e] * il2[c];
+                    class_map<KIND>(u, power, f, df);
+                    const float g = w[c][e] * df;
+                    a[e] = __builtin_fmaf(2.0f * g, il2[c], a[e]);
+                    dp[c] = __builtin_fmaf(g, u * m2p[c], dp[c]);
+                }
+            }
+        }
+        if constexpr (KIND == DKT_CLASSMAP_POLY) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[0]), pr, o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[1]), pr, o1, 0, 0);
+        } else {
+            const float rowsum = wave_allsum(a[0] + a[1]);
+            const float adiag = wave_allsum((lane == i ? a[0] : 0.f) + (lane + 64 == i ? a[1] : 0.f));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lane == i ? rowsum - adiag : -a[0]), pr, o0, 0, 0);      // Wp = diag(A 1) - A
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lane + 64 == i ? rowsum - adiag : -a[1]), pr, o1, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const float s = wave_allsum(dp[c]);
+        if (lane == 0) red[c][wave] = s;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const float* d = red[tid];
+        dparam[(size_t)blockIdx.x * C + tid] = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    }
+}
+
 // The same chain rule for 128 < N <= 512 (round 4; the large episodes of the one-launch per-class path, N <= 447) with 16-byte accesses and the per-class parameter
 // partials in REGISTERS: the kernel above reads 4 bytes per lane and load, issues a class's load only after the previous class was consumed, and
 // read-modify-writes an LDS slot per element and class -- 1.0-1.5 TB/s of the W stream (0.91 of the 3.4 ms of a 20-way rbf step of 64 episodes).
@@ -269,8 +351,12 @@ extern "C" int dkt_class_kernel_f32(const float* base, int kind, const float* pa
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
-static int g_ck_v4 = -1;
-void dkt_classkernel_reload_env() { g_ck_v4 = -1; }                     // dkt_reload_env()
+static int g_ck_v4 = -1, g_ck_n128 = -1;
+void dkt_classkernel_reload_env() { g_ck_v4 = -1; g_ck_n128 = -1; }     // dkt_reload_env()
+static bool class_bwd_n128() {                                         // DKT_CLASS_BWD_N128=0 (twins library): the dword kernel for N <= 128 too (A/B, twin test)
+    if (g_ck_n128 < 0) { const char* v = dkt_variant_env("DKT_CLASS_BWD_N128"); g_ck_n128 = (v && v[0] == '0') ? 0 : 1; }
+    return g_ck_n128 != 0;
+}
 
 extern "C" int dkt_class_kernel_bwd_nsplit(int B, int N) {
     if (B <= 0 || N <= 0) return 1;
@@ -288,7 +374,19 @@ extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int k
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * nsplit), block(CKB_T);
     if (g_ck_v4 < 0) { const char* v = dkt_variant_env("DKT_CLASS_BWD_V4"); g_ck_v4 = (v && v[0] == '0') ? 0 : 1; }      // (0: the dword kernel, a measurement twin)
-    // (N <= 128: a row of 4-column groups leaves more than half of a wave's lanes idle -- 0.58 vs 0.28 ms at N = 105, C = 5, 2048 episodes: the dword kernel stays)
+    // round 5: all loads of a row in flight, constants and partials in registers.  Same-box A/B (tools/class_bwd_ab.py, profiles/r05/v12_class_bwd_ab.log; 2048 episodes,
+    // C = 5): N = 105 rbf 0.294 -> 0.139 ms (0.27 -> 0.57 of HBM), matern 0.351 -> 0.214, poly 0.241 -> 0.132, N = 80 0.204 -> 0.096; C = 8, N = 128: 0.213 -> 0.145;
+    // N = 25 (a row fills 25 of a wave's 128 column slots) 0.092 -> 0.128: from 65 rows.
+    if (N > 64 && N <= 128 && C <= 8 && class_bwd_n128()) {
+        switch (kind) {
+            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_RBF>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_POLY>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            default: return DKT_ERR_BAD_ARG;
+        }
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    }
+    // (N <= 128: a row of 4-column groups leaves more than half of a wave's lanes idle -- 0.58 vs 0.28 ms at N = 105, C = 5, 2048 episodes: the dword kernel stays for C > 8)
     if (N > 128 && N <= 512 && g_ck_v4 != 0) {
         switch (kind) {
             case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_RBF>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;

@@ -1905,6 +1905,50 @@ def test_one_pass_statistics_and_gram_train_mode(cuda, b, n, d, affine):
     assert torch.equal(e, e3) and torch.equal(st["a"], st3["a"])
 
 
+@pytest.mark.parametrize("b,c,n,cmap,power", [(3, 5, 105, "rbf", 1), (2, 5, 80, "matern", 1), (4, 3, 33, "poly", 2), (1, 8, 128, "rbf", 1), (2, 2, 7, "poly", 1), (70, 5, 25, "rbf", 1)])
+def test_class_kernel_backward_row_kernel_twin(cuda, monkeypatch, b, c, n, cmap, power):
+    """dkt_class_kernel_bwd_f32 at N <= 128, C <= 8 (round 5: all loads of a row in flight, per-class constants and partials in registers) against the
+    element-by-element kernel of round 3 (DKT_CLASS_BWD_N128=0) and float64."""
+    rng = np.random.default_rng(n * 3 + c)
+    base = rng.uniform(0.0, 2.0, (b, n, n))
+    base = (0.5 * (base + base.transpose(0, 2, 1))).astype(np.float32)
+    w = rng.standard_normal((b, c, n, n)) * 0.05
+    w = (w + w.transpose(0, 1, 3, 2)).astype(np.float32)
+    param = np.linspace(0.7, 1.5, c).astype(np.float32)
+    km = {"rbf": ops.CLASSMAP_RBF, "matern": ops.CLASSMAP_MATERN25, "poly": ops.CLASSMAP_POLY}[cmap]
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("DKT_CLASS_BWD_N128", v)
+        out[v] = ops.class_kernel_bwd(dev_t(w, cuda), dev_t(base, cuda), km, power, dev_t(param, cuda))
+    monkeypatch.delenv("DKT_CLASS_BWD_N128")
+    # float64: E_c = f_c(base), obj = sum_c <W_c, E_c>;  Wp and dparam are the gradients w.r.t. the (squared-distance / Gram) base and the parameter
+    bt = torch.tensor(base, dtype=torch.float64, requires_grad=True)
+    pt = torch.tensor(param, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    if cmap == "poly":
+        e = (bt.unsqueeze(1) + pt.view(1, c, 1, 1)) ** power
+    else:
+        u = bt.unsqueeze(1) / pt.view(1, c, 1, 1) ** 2
+        if cmap == "rbf":
+            e = torch.exp(-0.5 * u)
+        else:
+            r = torch.sqrt(5.0 * u.clamp_min(1e-30))
+            e = (1.0 + r + r * r / 3.0) * torch.exp(-r)
+    (wt * e).sum().backward()
+    for v in ("0", "1"):
+        wp, dparam = out[v]
+        if cmap == "poly":
+            ref_wp = bt.grad.numpy()
+        else:                                                     # distance kinds: Wp = diag(A 1) - A with A = 2 d obj / d d2 (what dkt_gram_bwd_f32 turns into dZ)
+            a = 2.0 * bt.grad.numpy()
+            ref_wp = -a
+            idx = np.arange(n)
+            ref_wp[:, idx, idx] = a.sum(2) - a[:, idx, idx]
+        assert rel_l2(wp.cpu().numpy(), ref_wp) < 2e-6, (v, rel_l2(wp.cpu().numpy(), ref_wp))
+        assert rel_l2(dparam.sum(0).cpu().numpy(), pt.grad.numpy()) < 2e-5, v
+    assert rel_l2(out["1"][0].cpu().numpy(), out["0"][0].cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("b,n,d,kind", [(5, 19, 2916, "rbf"), (3, 25, 1600, "linear"), (6, 32, 2052, "linear"), (2, 17, 4096, "rbf"), (7, 10, 2916, "rbf")])
 def test_small_gram_workgroup_per_task_twin(cuda, monkeypatch, b, n, d, kind):
     """N <= 32 with long rows (round 5): a workgroup per task (DKT_GRAM_SMALL_WG=1; the default from 2048 / 1024 features) against the wave-per-task kernels
