@@ -1905,6 +1905,26 @@ def test_one_pass_statistics_and_gram_train_mode(cuda, b, n, d, affine):
     assert torch.equal(e, e3) and torch.equal(st["a"], st3["a"])
 
 
+@pytest.mark.parametrize("n,d", [(105, 64), (20, 64), (85, 100)])
+def test_fused_train_forward_optional_outputs_at_the_c_abi(cuda, n, d):
+    """dkt_gram_bn_train_f32 called at the C ABI with var_unbiased = NULL and gamma = beta = NULL (empty descriptors inside the f16 kernel): same E / rnorm / statistics
+    as the full call; nothing is written through the NULL pointer."""
+    L = dkt_amd._lib.load()
+    rng = np.random.default_rng(n + d)
+    x = dev_t(_relu_like(rng, 3, n, d), cuda)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    full = ops.gram_bn_train(x, None, None, 1e-5)
+    outs = {k: torch.full((3, d), float("nan"), device=cuda) for k in ("mean", "rstd", "a", "s")}
+    e = torch.empty(3, n, n, device=cuda)
+    rn = torch.empty(3, n, device=cuda)
+    rc = L.dkt_gram_bn_train_f32(p(x), 0, 0, 1e-5, p(outs["mean"]), p(outs["rstd"]), p(outs["a"]), p(outs["s"]), 0, p(e), p(rn), 3, n, d, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(e, full[0]) and torch.equal(rn, full[1])
+    for k in outs:
+        assert torch.equal(outs[k], full[2][k]), k
+
+
 @pytest.mark.parametrize("b,c,n,cmap,power", [(3, 5, 105, "rbf", 1), (2, 5, 80, "matern", 1), (4, 3, 33, "poly", 2), (1, 8, 128, "rbf", 1), (2, 2, 7, "poly", 1), (70, 5, 25, "rbf", 1)])
 def test_class_kernel_backward_row_kernel_twin(cuda, monkeypatch, b, c, n, cmap, power):
     """dkt_class_kernel_bwd_f32 at N <= 128, C <= 8 (round 5: all loads of a row in flight, per-class constants and partials in registers) against the
