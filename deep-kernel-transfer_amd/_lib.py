@@ -92,7 +92,8 @@ SPILL_BUDGET = {
     # mll_h2e_kernel (wave per episode, the bench kernel since round 3): no entry = 0 spills allowed, at 254 of 256 VGPRs
     r"mll_h2_kernelILi7ELb1ELb1": 20,              # wave per matrix <NT = 7, GRAD, 5 waves per episode> at its 168-VGPR cap (batches < 1024 episodes): 16
     r"mll_h2_kernelILi[67]E": 12,                  # its forward-only / other-class-count instantiations: 8
-    r"gram_sym_ep_split_kernelILi8ELi2ELi2": 24,   # Gram forward for 112 < N <= 128 (36 accumulator tiles), unit rows: 24
+    # (gram_sym_ep_split_kernel<8, 2, 2, ...>, the unit-row Gram forward for 112 < N <= 128, had 24 here until round 5: the spills sat in the slab loop, every
+    #  scratch reload is a vmcnt(0) that drains the prefetch -- built for two workgroups per CU it has none and runs 1.89 -> 1.36 ms per 8192 episodes of 128 x 1600)
     r"gram_sym_ep_split_kernelILi[78]ELi1ELi1": 8,  # the bf16-split default at NT = 7 / 8
     # tile-array factorisation / inverse at 3 workgroups per CU (168 VGPRs), MC = 7 (N >= 384): values parked in scratch around the diagonal-tile sweep, none in the K loop
     r"tiled_factor_kernelILi\dELb1ELi3E": 28,

@@ -824,7 +824,8 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit
 #endif
         // the product: unit rows -> scaled 2-way f16 split, 2 stage buffers, prefetch depth 2, 3 workgroups per CU, non-temporal Z loads (22232);
         // any rows -> exact 3-way bf16 split, 1 buffer, depth 1 (11)
-        if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        // (NT = 8 at TWO workgroups per CU: built for three it spills 24 registers into the slab loop, and every scratch reload is a `vmcnt(0)` that drains the prefetch)
+        if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, NT == 8 ? 2 : 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         else hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         return;
     }
