@@ -106,6 +106,20 @@ def test_no_wide_buffer_store_is_followed_by_a_write_of_its_data_registers():
     assert all("buffer_store_dwordx4" in h[1] for h in found)
 
 
+def test_spill_reloads_stay_out_of_the_streaming_loops():
+    """A scratch reload waits `vmcnt(0)`; inside a loop that prefetches it drains the prefetch on every trip (round 5: 1.89 instead of 1.36 ms for the unit-row Gram
+    forward at 112 < N <= 128).  Audit of the product library's disassembly: only the three kernels whose reloads were looked at and accepted -- the wave-per-matrix
+    marginal likelihood at NT = 7 (class loop; batches under 1024 episodes) and the tile-array factor / invert at 3 workgroups per CU (around the diagonal-tile sweeps,
+    not in the K loop; 3 vs 2 workgroups re-measured in profiles/r05/v14_tiled_wgs_ab.log) -- reload a spilled register inside a loop that also loads from memory."""
+    import re
+    found = dkt_amd._lib.spill_reloads_in_streaming_loops(dkt_amd._lib.LIB_PATH)
+    allowed = (r"mll_h2_kernelILi7E", r"tiled_factor_kernelILi7ELb1ELi3E", r"tiled_invert_kernelILi7ELb1ELb1ELi3E")
+    for k in found:
+        assert any(re.search(a, k) for a in allowed), (k, found[k])
+    for hot in ("gram_sym_ep_split_kernel", "gram_bwd_ep_f16x2_kernel", "mll_h2e_kernel", "gram_bn_train_f16_kernel", "gram_bn_bwd_ep_kernel", "lowrank_", "gram_small"):
+        assert not any(hot in k for k in found), hot
+
+
 def test_library_selection_product_unless_twins_are_asked_for(monkeypatch):
     """ops._lib_now(): the product library for every call, the twins library only with DKT_TWINS=1 AND (a variant switch set | the call names a twin)."""
     ops, L = dkt_amd.ops, dkt_amd._lib
