@@ -1,8 +1,8 @@
 #!/bin/bash
 # HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of the kernels behind the from-trunk and RBF paths:
-# gpurun_out/prof_r03/other_paths_pmc.txt (copied to profiles/r03/).  Runs on the GPU box via gpurun.
+# gpurun_out/prof_r05/other_paths_pmc.txt (copied to profiles/r0N/).  Runs on the GPU box via gpurun.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_r05
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 : > $OUT/other_paths_pmc.txt
@@ -22,7 +22,7 @@ for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg[k][0] += 1; agg[k][1] += v; agg[k][2] = max(agg[k][2], v)
 print("== tools/%s.py, --pmc %s (KB per dispatch: mean over all dispatches of the tool's batch sizes / max = the largest batch)" % (name, pmc))
 for k, (n, s, mx) in sorted(agg.items()):
-    if any(t in k for t in ("gram_bn", "class_kernel", "mll_h2", "gram_bwd_ep", "gram_nt")):
+    if any(t in k for t in ("gram_bn", "class_kernel", "mll_h2", "gram_bwd_ep", "gram_nt", "gram_sym")):
         print("%-80s dispatches %4d  mean %.6g  max %.6g" % (k, n, s / max(n, 1), mx))
 PY
     rm -rf $OUT/pm_${name}_$pmc
