@@ -220,7 +220,7 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd_v4(const float* __rest
                                                            const float* __restrict__ param, int power, float* __restrict__ Wp,
                                                            float* __restrict__ dparam, int C, int N, int nsplit) {
     __shared__ float red[32][8];
-    __shared__ float prm[32], prm_il2[32];
+    __shared__ float prm[32], prm_il2[32], prm_m2p[32];
     const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int rows_per = (N + nsplit - 1) / nsplit, row0 = sp * rows_per, row1 = min(N, row0 + rows_per);
     const size_t nn = (size_t)N * N;
@@ -233,6 +233,8 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd_v4(const float* __rest
         const float p = tid < C ? param[tid] : 1.0f;
         prm[tid] = p;
         prm_il2[tid] = 1.0f / (p * p);
+        prm_m2p[tid] = -2.0f / p;                                        // d u / d l = -2 u / l as ONE multiply per element and class (round 5: the division was
+                                                                         // ~8 of the ~20 VALU instructions of an element-class step of a VALU-bound kernel)
     }
     __syncthreads();
     float dp[32];
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd_v4(const float* __rest
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) {
                             const int c = c0 + cc;
-                            const float p = prm[c], il2 = prm_il2[c];
+                            const float p = prm[c], il2 = prm_il2[c], m2p = prm_m2p[c];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float w = (j + e < N) ? __uint_as_float(w4[cc][e]) : 0.f;       // (past the row end: the next row's values)
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(CKB_T) void class_kernel_bwd_v4(const float* __rest
                                     class_map<KIND>(u, power, f, df);
                                     const float g = w * df;                 // d obj / d u_c,ij
                                     a[ch][e] = __builtin_fmaf(2.0f * g, il2, a[ch][e]);             // A = 2 d obj / d d2
-                                    dp[c] = __builtin_fmaf(g, -2.0f * u / p, dp[c]);                // d u / d l = -2 u / l
+                                    dp[c] = __builtin_fmaf(g, u * m2p, dp[c]);                      // d u / d l = -2 u / l
                                 }
                             }
                         }
