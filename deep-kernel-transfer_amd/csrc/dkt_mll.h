@@ -52,6 +52,10 @@ bool dkt_mll_tiled_supports(int N, unsigned flags, int C = 1);
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
 size_t dkt_mll_tiled_workspace_bytes_form(int B, int C, int N, bool per_class);
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
+// Shared-E band path (dkt_mll_band.hip): ONE orthogonal reduction per episode instead of C factorisations (128 <= N <= 447, 8 <= C <= 32; the default there).
+bool dkt_mll_band_supports(int N, unsigned flags, int C);
+size_t dkt_mll_band_workspace_bytes(int B, int C, int N);
+int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes
 // -- with the full jitter-retry ladder -- only the episodes the blocked path reported as failed.  No host synchronisation.
 void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipStream_t st);

@@ -32,7 +32,7 @@ def rel_l2(a, b):
 
 
 def test_loaded_native_library(cuda, lib):
-    assert lib.dkt_abi_version() == 4
+    assert lib.dkt_abi_version() == 5
     assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -1024,11 +1024,11 @@ def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
     noise = np.full(c, 0.1)
     cw = np.full(c, -1.0 / (c * n))
     args = [dev_t(x, cuda) for x in (e_np, y, sv, mean, noise)]
-    ref = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    ref = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_tiled=True)      # (C = 20 would take the band reduction by default)
     k, v = switch.split("=")
     os.environ[k] = v
     try:
-        o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+        o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_tiled=True)
     finally:
         del os.environ[k]
     assert int(o["info"].abs().max().item()) == 0 and torch.equal(o["w"], o["w"].transpose(1, 2))
@@ -1047,6 +1047,92 @@ def test_mll_tile_array_pipeline_twins(cuda, n, c, switch):
             assert abs(o["logp"][bi, kc].item() - logp) < MLL_RTOL * abs(logp)
             w_ref += cw[kc] * sv[kc] * 0.5 * (np.outer(alpha, alpha) - np.linalg.inv(kk))
         assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
+
+
+# ----------------------------------------------------------------------------------------------
+# shared base matrix, many classes: ONE band reduction per episode (csrc/dkt_mll_band.hip, round 6)
+# ----------------------------------------------------------------------------------------------
+def _band_problem(b, n, c, d, corr, seed):
+    """SURVEY 8d's synthetic episodes (oracle.synthetic_features: N(0,1) -> BatchNorm(train) -> L2 normalise; corr: 0.9 class mean + 0.1 noise before the
+    BatchNorm, cond(K) ~ 1e2 .. 1e3 -- what trained features look like), class-major one-vs-rest targets, distinct hyper-parameters per class."""
+    per = n // c
+    z = np.zeros((b, n, d))
+    z[:, :per * c] = O.synthetic_features(b, per * c, d, seed, c if corr else 0)
+    if per * c < n:                                                 # N not a multiple of C: the tail rows join the last class
+        z[:, per * c:] = O.synthetic_features(b, n - per * c, d, seed + 1, 0)
+    cls = np.minimum(np.arange(n) // per, c - 1)
+    e = np.einsum("bnd,bmd->bnm", z, z).astype(np.float32).astype(np.float64)
+    y = np.where(cls[None, :] == np.arange(c)[:, None], 1.0, -1.0)
+    sv = 0.5 + 0.04 * np.arange(c)
+    mean = 0.01 * np.arange(c)
+    noise = np.full(c, 0.1)
+    cw = np.full(c, -1.0 / (c * n))
+    return e, y, sv, mean, noise, cw
+
+
+@pytest.mark.parametrize("n,c,d,corr", [(128, 8, 48, False), (150, 10, 64, True), (257, 16, 64, False), (320, 20, 128, False), (420, 20, 512, True),
+                                        (431, 9, 64, True), (447, 32, 96, False)])
+def test_mll_band_reduction_vs_float64_and_tile_array_twin(cuda, n, c, d, corr):
+    """The default of a shared-E call with 8 <= C <= 31 and 128 <= N <= 447: one orthogonal reduction of E to block-tridiagonal form per episode, every class a
+    block LDL^T of B + mu_c I (methods/DKT.py:148-149, 161-163 at the 20-way shapes of train.py:132-133).  Against float64 on every episode and against the tile-array
+    twin (force_tiled: one factorisation per class matrix); with and without gradients; W bitwise symmetric.  The tolerances are the file's (1e-4 / 1e-3) on
+    uncorrelated AND on class-correlated features, where the reduction's backward error would cost 1e-4 on the quadratic form without the residual step."""
+    b = 3
+    e, y, sv, mean, noise, cw = _band_problem(b, n, c, d, corr, 100 * n + c)
+    args = [dev_t(x, cuda) for x in (e, y, sv, mean, noise)]
+    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    o_fwd = ops.mll(*args, want_grad=False)
+    twin = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_tiled=True)
+    assert int(o["info"].abs().max().item()) == 0 and float(o["jitter"].abs().max().item()) == 0.0
+    assert torch.equal(o["w"], o["w"].transpose(1, 2))
+    worst = 0.0
+    for bi in range(b):
+        w_ref = np.zeros((n, n))
+        hyper = ([], [], [])
+        for k in range(c):
+            kk = sv[k] * e[bi] + noise[k] * np.eye(n)
+            r = y[k] - mean[k]
+            kinv = np.linalg.inv(kk)
+            alpha = kinv @ r
+            logp = -0.5 * r @ alpha - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+            worst = max(worst, abs(o["logp"][bi, k].item() - logp) / abs(logp))
+            assert abs(o["logp"][bi, k].item() - logp) < 0.1 * MLL_RTOL * abs(logp), (bi, k, o["logp"][bi, k].item(), logp)
+            assert abs(o_fwd["logp"][bi, k].item() - logp) < MLL_RTOL * abs(logp)
+            assert rel_l2(o["alpha"][bi, k].cpu().numpy(), alpha) < 2e-4
+            assert rel_l2(o_fwd["alpha"][bi, k].cpu().numpy(), alpha) < 2e-4
+            m = 0.5 * (np.outer(alpha, alpha) - kinv)
+            w_ref += cw[k] * sv[k] * m
+            hyper[0].append((m * e[bi]).sum()); hyper[1].append(np.trace(m)); hyper[2].append(alpha.sum())
+        assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
+        for key, ref in zip(("dsv", "dnoise", "dmean"), hyper):
+            assert rel_l2(o[key][bi].cpu().numpy(), np.array(ref)) < GRAD_RTOL, key
+    assert rel_l2(o["w"].cpu().numpy(), twin["w"].cpu().numpy()) < 2e-4
+    np.testing.assert_allclose(o["logp"].cpu().numpy(), twin["logp"].cpu().numpy(), rtol=1e-4)
+    for key in ("dsv", "dmean", "dnoise"):
+        assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
+    # bitwise repeatable
+    o2 = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    for key in ("logp", "alpha", "w", "dsv", "dmean", "dnoise"):
+        assert torch.equal(o[key], o2[key]), key
+
+
+def test_mll_band_reduction_failure_goes_through_the_jitter_ladder(cuda):
+    """A class whose matrix is singular at attempt 0 (rank-deficient E, zero noise): the band path runs attempt 0 only, flags the episode, and the generic kernel's
+    fix-up launch redoes it with psd_safe_cholesky's ladder -- jitter, info and every output equal to the tile-array twin's (which ends in the same fix-up)."""
+    rng = np.random.default_rng(5)
+    b, c, n = 3, 8, 160
+    z = rng.standard_normal((b, n, 16))
+    e = np.einsum("bnd,bmd->bnm", z, z)
+    y = np.where(np.arange(n)[None, :] % c == np.arange(c)[:, None], 1.0, -1.0)
+    noise = np.full(c, 1e-2)
+    noise[3] = 0.0
+    args = [dev_t(x, cuda) for x in (e, y, np.ones(c), np.zeros(c), noise)]
+    cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
+    o = ops.mll(*args, want_grad=True, cls_weight=cw)
+    twin = ops.mll(*args, want_grad=True, cls_weight=cw, force_tiled=True)
+    assert float(o["jitter"][:, 3].min().item()) > 0.0 and float(o["jitter"][:, [0, 1, 2, 4, 5, 6, 7]].abs().max().item()) == 0.0
+    for key in ("jitter", "info", "logp", "alpha", "w", "dsv", "dmean", "dnoise"):
+        assert torch.equal(o[key], twin[key]), key
 
 
 @pytest.mark.parametrize("b,n,d", [(72, 190, 512), (72, 320, 512), (72, 420, 512), (72, 431, 36), (72, 290, 64), (72, 447, 100), (136, 190, 512), (130, 250, 128)])
