@@ -98,6 +98,10 @@ SPILL_BUDGET = {
     # tile-array factorisation / inverse at 3 workgroups per CU (168 VGPRs), MC = 7 (N >= 384): values parked in scratch around the diagonal-tile sweep, none in the K loop
     r"tiled_factor_kernelILi\dELb1ELi3E": 28,
     r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 24,
+    # band reduction (QR + fused pass at 256 VGPRs): lane constants parked at kernel entry; the forward kernel reloads one per QR column, both a few per panel --
+    # none inside the tile loop
+    r"band_sym_kernelILb0E": 24,
+    r"band_sym_kernelILb1E": 16,
 }
 
 

@@ -52,7 +52,7 @@ bool dkt_mll_tiled_supports(int N, unsigned flags, int C = 1);
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
 size_t dkt_mll_tiled_workspace_bytes_form(int B, int C, int N, bool per_class);
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
-// Shared-E band path (dkt_mll_band.hip): ONE orthogonal reduction per episode instead of C factorisations (128 <= N <= 447, 8 <= C <= 32; the default there).
+// Shared-E band path (dkt_mll_band.hip): ONE orthogonal reduction per episode instead of C factorisations (128 <= N <= 432, 8 <= C <= 32; the default there).
 bool dkt_mll_band_supports(int N, unsigned flags, int C);
 size_t dkt_mll_band_workspace_bytes(int B, int C, int N);
 int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);

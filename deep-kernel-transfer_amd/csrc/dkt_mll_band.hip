@@ -1,5 +1,5 @@
 // dkt_mll_band.hip -- exact-GP marginal likelihood of the C one-vs-rest models of an episode that SHARE their base matrix (linear / cossim / bncossim,
-// 128 <= N <= 447, 8 <= C <= 32: the 20-way shapes of train.py:132-133) through ONE orthogonal reduction per episode instead of C factorisations.
+// 128 <= N <= 432, 8 <= C <= 32: the 20-way shapes of train.py:132-133) through ONE orthogonal reduction per episode instead of C factorisations.
 //
 // Replaces the same reference lines as dkt_mll_tiled.hip (methods/DKT.py:161-163 at C = 20: GPyTorch's psd_safe_cholesky / inv_quad_logdet / cholesky_solve
 // and their autograd backward).  DKT.py:148-149 hands every class model the same z_train and :346-347 freezes the noise, so the class matrices are shifts of
@@ -16,13 +16,13 @@
 // Everything is 16 x 16 tiles of 1 KB in the MFMA accumulator layout (lane (g, c) register q <-> element [4g + q][c]), every product is D += X^T Y =
 // 4 x v_mfma_f32_16x16x4_f32 (dkt_mfma_tiles.h) -- exact fp32 throughout, no split, no range contract.  Kernels (workspace per episode in `BandGeo`):
 //   band_init_kernel      E[b] -> full tile array A (both triangles), U = [y_c - m_c] as tiles
-//   band_twosided_kernel<false>  (workgroup = episode)  panels k = 0 .. NT-3: Householder QR of block column k below the band (rows over threads, one
+//   band_sym_kernel<false>  (workgroup = episode)  panels k = 0 .. NT-3: Householder QR of block column k below the band (rows over threads, one
 //                         exchange per column), T_k by the larft recurrence from V^T V, U <- H^T U, and the two-sided update A <- H^T A H as
 //                         X = A V, S = V^T X, Y = X Th^T - 0.5 V (Th S Th^T), A -= V Y^T + Y V^T with V and Y in LDS
 //   band_class_kernel     (wave = class matrix)  block LDL^T chain of B + mu_c I on the diagonal-tile sweep of dkt_mfma_tiles.h: pivots, P_j^-1, G_j = S_j P_j^-1,
 //                         forward / backward substitution for a_c, Z_jj = diagonal blocks of (B + mu_c)^-1, all scalars of the class
 //   band_chain_kernel     (wave = block columns)  Z_ji = -G_j^T Z_{j+1,i} upwards from the diagonal, accumulated over the classes in registers, + the rank-C term
-//   band_twosided_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same code with Th = T), a <- H_k a; then W[b] and alpha[b] are stored
+//   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same code with Th = T), a <- H_k a; then W[b] and alpha[b] are stored
 // Attempt 0 only (no jitter): an episode with a failed class is redone -- jitter ladder and all -- by the generic kernel's fix-up launch, as in the tile-array path.
 #include "dkt_mfma_tiles.h"
 
@@ -30,9 +30,10 @@ namespace {
 
 using namespace dkt_mfma;
 
-constexpr int BAND_MAXNT = 28;             // N <= 447
+constexpr int BAND_MAXNT = 27;             // N <= 432 (the accumulators of the pass / chain kernels are sized for it)
 constexpr int LDP = 20;                    // row stride (floats) of the panel-shaped LDS arrays: 16-byte aligned rows
-constexpr int BAND_CHUNK = 1024;           // episodes per pass over the workspace
+constexpr int BAND_CHUNK = 1024;
+static_assert(BAND_MAXNT % 9 == 0, "the partial-sum rounds walk the tiles nine at a time");           // episodes per pass over the workspace
 
 struct BandGeo {
     int N, NT, C, CP;                      // CP = class-column tiles of U / A
@@ -55,7 +56,7 @@ BandGeo band_geo(int N, int C) {
     g.N = N; g.NT = (N + 15) / 16; g.C = C; g.CP = (C + 15) / 16;
     int o = 0;
     auto take = [&](int tiles) { const int r = o; o += tiles * 256; return r; };
-    g.oA = take(g.NT * g.NT);
+    g.oA = take(g.NT * (g.NT + 1) / 2);           // the lower block triangle, tile (i, j) at i (i + 1) / 2 + j
     g.oV = take(g.NT * (g.NT - 1) / 2);
     g.oT = take(g.NT);
     g.oU = take(g.NT * g.CP);
@@ -75,7 +76,7 @@ __device__ __forceinline__ f32x4 neg4(const f32x4 v) { return (f32x4){-v[0], -v[
 constexpr f32x4 ZERO4 = {0.f, 0.f, 0.f, 0.f};
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-// E[b] -> A tiles (full: both triangles), U tiles
+// E[b] -> A tiles (lower block triangle), U tiles
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void band_init_kernel(BandArgs t) {
     const BandGeo& G = t.g;
@@ -84,8 +85,11 @@ __global__ __launch_bounds__(256) void band_init_kernel(BandArgs t) {
     const int slot = blockIdx.x * 4 + wave, bl = blockIdx.y;
     float* ep = t.ws + (size_t)bl * G.ep_floats;
     const int b = t.b0 + bl;
-    if (slot < NT * NT) {
-        const int i = slot / NT, j = slot - i * NT;
+    const int ntt = NT * (NT + 1) / 2;
+    if (slot < ntt) {
+        int i = 0, rem = slot;
+        while (rem > i) { rem -= i + 1; ++i; }
+        const int j = rem;                                  // i >= j
         // element [4g + q][c] = E[16i + 4g + q][16j + c] = E[16j + c][16i + 4g + q] (symmetric): one 16-byte load per lane
         const brsrc Er = mk_rsrc(t.a.E + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
         const int row = 16 * j + c16, col = 16 * i + g4;
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256) void band_init_kernel(BandArgs t) {
                 e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
         }
         st4(ep + G.oA + (size_t)slot * 256 + lane * 4, e);
-    } else if (slot < NT * NT + NT * G.CP) {
-        const int u = slot - NT * NT, i = u / G.CP, p = u - i * G.CP;
+    } else if (slot < ntt + NT * G.CP) {
+        const int u = slot - ntt, i = u / G.CP, p = u - i * G.CP;
         const int cls = 16 * p + c16;
         const float* Y = t.a.Y + (size_t)b * t.a.y_bstride;
         f32x4 v;
@@ -113,40 +117,72 @@ __global__ __launch_bounds__(256) void band_init_kernel(BandArgs t) {
             v[q] = x;
         }
         st4(ep + G.oU + (size_t)u * 256 + lane * 4, v);
-    } else if (slot < NT * NT + 3 * NT * G.CP) {
+    } else if (slot < ntt + 3 * NT * G.CP) {
         // A / A^T tiles: the class kernel writes the columns of its classes only; the others (the padding) must read as zero
-        st4(ep + G.oAm + (size_t)(slot - NT * NT - NT * G.CP) * 256 + lane * 4, ZERO4);       // (oAmT follows oAm)
+        st4(ep + G.oAm + (size_t)(slot - ntt - NT * G.CP) * 256 + lane * 4, ZERO4);       // (oAmT follows oAm)
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-// The two-sided kernel: BACK = false: reduction of A to block-tridiagonal form (panels in order); BACK = true: M <- Q M Q^T (panels in reverse)
+// The two-sided kernel.  BACK = false: reduction of A to block-tridiagonal form, panels k = 0 .. NT-3 in order; BACK = true: M <- Q M Q^T, panels in reverse.
+// A lives as its LOWER block triangle (tile (i, j), i >= j, slot i (i + 1) / 2 + j: tile rows contiguous).  Per panel ONE pass over the stored tiles does both
+// the update with the panel just finished (V, Y in LDS) and the product X' = A V' with the next panel (V' known: the forward pass factors block column k + 1
+// right after updating it; the back pass reads V' from the workspace): every stored tile is read once and written once per panel.
+//   wave = tile rows (snake order).  Tile (i, j):  A_ij -= V_i Y_j^T + Y_i V_j^T;   Xt'_j += V'_i^T A_ij  (per-wave partial accumulators for every j, in registers);
+//   Xt'_i += V'_j^T A_ij^T for j < i (the tile transposed through 1 KB of wave-private LDS).  The partials of the four waves meet in LDS in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-struct TsLds {
-    float* Vs;       // [NP - 16][LDP]  V of the panel, row-major, panel-local rows
-    float* Xs;       // [NP][LDP]       X, then Y, rows = global rows; aliased by the partial tiles of the G / V^T U reductions before X exists
-    float* Ts;       // [16][LDP]       T row-major
-    float* Part;     // [4][256]        per-wave partial tile (S)
-    float* Gs;       // [256]           reduced tile (G, then S is reduced in registers)
-    float* Wus;      // [2][256]        V^T U reduced
-    float* red;      // [2][4][17]      QR exchange
-    float* rowj;     // [2][16]
-};
-
-__host__ __device__ inline int ts_lds_floats(const int NT) {
-    const int NP = 16 * NT;
-    const int xs = NP * LDP > 3072 ? NP * LDP : 3072;            // the X region also holds 4 x 3 partial tiles before X exists
-    return (NP - 16) * LDP + xs + 16 * LDP + 4 * 256 + 256 + 2 * 256 + 2 * 4 * 17 + 2 * 16 + 8;
-}
+__device__ __forceinline__ int lslot(const int i, const int j) { return (i * (i + 1)) / 2 + j; }          // i >= j
 
 #ifdef DKT_BAND_CLOCKS
-#define BCLK(i) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) clk[i] += __builtin_amdgcn_s_memtime() - tlast; tlast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BCLK(i) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0) clkl[i] += (float)(__builtin_amdgcn_s_memtime() - tlast); tlast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define BCLK(i) do { } while (0)
 #endif
 
+// Sums of 16 per-lane values over the 64 lanes of a wave with 17 exchanges instead of 16 full reductions: every stage halves the values a lane carries (it keeps the
+// half its lane bit selects and adds the partner's copy of that half).  On return lane l holds the total of value index 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l).
+__device__ __forceinline__ float wave_sum16(const float (&v)[16], const int lane) {
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (h5 ? v[8 + i] : v[i]) + __shfl_xor(h5 ? v[i] : v[8 + i], 32, DKT_WAVE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (h4 ? a[4 + i] : a[i]) + __shfl_xor(h4 ? a[i] : a[4 + i], 16, DKT_WAVE);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (h3 ? b[2 + i] : b[i]) + __shfl_xor(h3 ? b[i] : b[2 + i], 8, DKT_WAVE);
+    float d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, DKT_WAVE);
+    d += __shfl_xor(d, 2, DKT_WAVE);
+    d += __shfl_xor(d, 1, DKT_WAVE);
+    return d;
+}
+
+struct SymLds {
+    float* Vs;       // [NP - 16][LDP]  V of the finished panel, row-major, panel-local rows (row 0 = global row 16 r_prev)
+    float* Ys;       // [NP][LDP]       Y of the finished panel / X' of the next one, rows = global rows
+    float* Ts;       // [16][LDP]       T row-major
+    float* Part;     // [4][256]        per-wave partial tile (S)
+    float* Gs;       // [256]           V'^T V'
+    float* Wus;      // [2][256]        V'^T U
+    float* red;      // [2][4][17]      QR exchange
+    float* rowj;     // [2][16]
+    float* taus;     // [16]            tau of the panel being factored
+    float* Tsc;      // [4][16][17]     wave-private transposition scratch
+};
+constexpr int TSC_LD = 17;
+
+__host__ __device__ inline int sym_lds_floats(const int NT) {
+    const int NP = 16 * NT;
+    return (NP - 16) * LDP + NP * LDP + 16 * LDP + 4 * 256 + 256 + 2 * 256 + 2 * 4 * 17 + 2 * 16 + 16 + 4 * 16 * TSC_LD + 16;          // (TSC: 272 floats per wave >= the 256 of the sink above; + the phase clocks of the measurement build)
+}
+
+// the wave that owns tile row i: rows dealt in snake order from the longest (i = NT - 1) down, so that the four waves get about the same number of tiles
+__device__ __forceinline__ int row_owner(const int NT, const int i) {
+    const int idx = NT - 1 - i;
+    return (idx & 4) ? 3 - (idx & 3) : (idx & 3);
+}
+
 template <bool BACK>
-__global__ __launch_bounds__(256, 2) void band_twosided_kernel(BandArgs t) {
+__global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const BandGeo& G = t.g;
     const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
@@ -158,318 +194,347 @@ __global__ __launch_bounds__(256, 2) void band_twosided_kernel(BandArgs t) {
     float* Vg = ep + G.oV;
     float* Tg = ep + G.oT;
     float* Ut = ep + (BACK ? G.oAm : G.oU);
-    TsLds L;
+    const brsrc Ar = mk_rsrc(At, (unsigned)((size_t)NT * (NT + 1) / 2 * 1024));
+    const brsrc Vr = mk_rsrc(Vg, (unsigned)((size_t)NT * (NT - 1) / 2 * 1024));
+    SymLds L;
     L.Vs = smem;
-    L.Xs = L.Vs + (NP - 16) * LDP;
-    L.Ts = L.Xs + (NP * LDP > 3072 ? NP * LDP : 3072);
+    L.Ys = L.Vs + (NP - 16) * LDP;
+    L.Ts = L.Ys + NP * LDP;
     L.Part = L.Ts + 16 * LDP;
     L.Gs = L.Part + 4 * 256;
     L.Wus = L.Gs + 256;
     L.red = L.Wus + 2 * 256;
     L.rowj = L.red + 2 * 4 * 17;
+    L.taus = L.rowj + 2 * 16;
+    L.Tsc = L.taus + 16 + wave * 16 * TSC_LD;
 #ifdef DKT_BAND_CLOCKS
-    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    float* const clkl = L.Tsc - wave * 16 * TSC_LD + 4 * 16 * TSC_LD;        // 12 floats of LDS behind the scratch (thread 0 only)
+    if (tid == 0) for (int i = 0; i < 12; ++i) clkl[i] = 0.f;
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    const bool want_m = !BACK || t.grad;
+    const bool want_m = !BACK || t.grad;          // the back pass without gradients only carries the class vectors (alpha)
+    const int npan = NT - 2;
+    const int lane16 = lane * 16;
 
-    for (int kk = 0; kk < NT - 2; ++kk) {
-        const int k = BACK ? NT - 3 - kk : kk;
-        const int r0 = 16 * (k + 1), m = NP - r0, mt = NT - k - 1;
-        float tau[16];
+    for (int it = 0; it <= npan; ++it) {
+        const bool have_prev = it > 0, have_next = it < npan;
+        const int kp = BACK ? NT - 2 - it : it - 1, kn = BACK ? NT - 3 - it : it;       // finished panel / next panel
+        const int r_prev = kp + 1, r_next = kn + 1;                                      // first tile row of V / of V'
+        const int mtn = NT - r_next;                                                     // tiles of V'
+        const int vb_next = band_voff(NT, kn);
         if constexpr (!BACK) {
-            // ---- Householder QR of the panel: thread t owns the panel rows t and t + 256 (16 columns each in registers) ----
-            float p0[16], p1[16];
-            const int lr0 = tid, lr1 = tid + 256;
-            {
-                const int ra = r0 + lr0, rb = r0 + lr1;
-                const float* ta = At + ((size_t)(ra >> 4) * NT + k) * 256 + 64 * ((ra & 15) >> 2) + (ra & 3);
-                const float* tb = At + ((size_t)(rb >> 4) * NT + k) * 256 + 64 * ((rb & 15) >> 2) + (rb & 3);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    p0[c] = (lr0 < m) ? ta[4 * c] : 0.f;
-                    p1[c] = (lr1 < m) ? tb[4 * c] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool b0 = lr0 > j;
-                const float x0 = b0 ? p0[j] : 0.f, x1 = p1[j];
-                float part[16];
-                part[j] = x0 * x0 + x1 * x1;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) part[c] = x0 * p0[c] + x1 * p1[c];
-#pragma unroll
-                for (int c = j; c < 16; ++c) part[c] = wave_reduce_dpp<false>(part[c]);
-                float* rd = L.red + (j & 1) * 68;
-                float* rj = L.rowj + (j & 1) * 16;
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = j; c < 16; ++c) rd[wave * 17 + c] = part[c];
-                }
-                if (tid == j) {
-#pragma unroll
-                    for (int c = j; c < 16; ++c) rj[c] = p0[c];
-                }
-                __syncthreads();
-                const float ss = rd[j] + rd[17 + j] + rd[34 + j] + rd[51 + j];
-                const float alpha = rj[j];
-                float tj = 0.f;
-                if (ss > 0.f) {                                                       // uniform
-                    const float norm = sqrtf(alpha * alpha + ss);
-                    const float beta = alpha >= 0.f ? -norm : norm;
-                    tj = (beta - alpha) / beta;
-                    const float scale = 1.0f / (alpha - beta);
-                    const float v0 = b0 ? x0 * scale : (lr0 == j ? 1.0f : 0.f), v1 = x1 * scale;
-                    const float tv0 = tj * v0, tv1 = tj * v1;
-#pragma unroll
-                    for (int c = j + 1; c < 16; ++c) {
-                        const float w = rj[c] + scale * (rd[c] + rd[17 + c] + rd[34 + c] + rd[51 + c]);
-                        p0[c] -= tv0 * w;
-                        p1[c] -= tv1 * w;
+            if (have_next) {
+                // ---- block column kn: update with the finished panel, then its Householder QR (thread t owns the panel rows t and t + 256) ----
+                if (have_prev) {
+                    const f32x4 ytj = ld4(L.Ys + (16 * kn + c16) * LDP + g4), vtj = ld4(L.Vs + (c16) * LDP + g4);      // j = kn = r_prev: V's first tile
+                    for (int i = kn + wave; i < NT; i += 4) {
+                        const f32x4 nvt = neg4(ld4(L.Vs + (16 * (i - r_prev) + c16) * LDP + g4)), nyt = neg4(ld4(L.Ys + (16 * i + c16) * LDP + g4));
+                        float* ap = At + (size_t)lslot(i, kn) * 256 + lane * 4;
+                        st4(ap, xty(nyt, vtj, xty(nvt, ytj, ld4(ap))));
                     }
-                    p0[j] = b0 ? v0 : (lr0 == j ? beta : p0[j]);
-                    p1[j] = v1;
-                } else {
-                    p0[j] = b0 ? 0.f : p0[j];
-                    p1[j] = 0.f;
+                    __syncthreads();
                 }
-                tau[j] = tj;
-            }
-            // V -> LDS (unit lower trapezoidal), R -> the band tiles (k, k+1) = R^T and (k+1, k) = R
-            if (lr0 < m) {
+                BCLK(7);
+                float p0[16], p1[16];
+                const int lr0 = tid, lr1 = tid + 256, m = NP - 16 * r_next;
+                {
+                    const int ra = 16 * r_next + lr0, rb = 16 * r_next + lr1;
+                    const float* ta = At + (size_t)lslot(ra >> 4, kn) * 256 + 64 * ((ra & 15) >> 2) + (ra & 3);
+                    const float* tb = At + (size_t)lslot(rb >> 4, kn) * 256 + 64 * ((rb & 15) >> 2) + (rb & 3);
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    f32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int c = 4 * c4 + q; v[q] = (lr0 > c) ? p0[c] : (lr0 == c ? 1.0f : 0.f); }
-                    st4(L.Vs + lr0 * LDP + 4 * c4, v);
+                    for (int c = 0; c < 16; ++c) {
+                        p0[c] = (lr0 < m) ? ta[4 * c] : 0.f;
+                        p1[c] = (lr1 < m) ? tb[4 * c] : 0.f;
+                    }
                 }
-            }
-            if (lr1 < m) {
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) st4(L.Vs + lr1 * LDP + 4 * c4, (f32x4){p1[4 * c4], p1[4 * c4 + 1], p1[4 * c4 + 2], p1[4 * c4 + 3]});
-            }
-            if (tid < 16) {
-                float* tu = At + ((size_t)k * NT + k + 1) * 256;       // tile (k, k+1)[a][b] = R[b][a]
-                float* tl = At + ((size_t)(k + 1) * NT + k) * 256;     // tile (k+1, k)[b][a] = R[b][a]
-                const int bq = tid;
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    const float r = (a >= bq) ? p0[a] : 0.f;
-                    tu[64 * (a >> 2) + 4 * bq + (a & 3)] = r;
-                    tl[64 * (bq >> 2) + 4 * a + (bq & 3)] = r;
-                }
-            }
-            __syncthreads();
-            // V tiles -> global (the back transform reads them)
-            for (int it = wave; it < mt; it += 4) {
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = L.Vs[(16 * it + g4 + q) * LDP + c16];
-                st4(Vg + (size_t)(band_voff(NT, k) + it) * 256 + lane * 4, v);
-            }
-        } else {
-            // ---- V_k, T_k from the workspace ----
-            for (int it = wave; it < mt; it += 4) {
-                const f32x4 v = ld4(Vg + (size_t)(band_voff(NT, k) + it) * 256 + lane * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) L.Vs[(16 * it + g4 + q) * LDP + c16] = v[q];
-            }
-            if (wave == 0) {
-                const f32x4 tt = ld4(Tg + (size_t)k * 256 + lane * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) L.Ts[(g4 + q) * LDP + c16] = tt[q];
-            }
-            __syncthreads();
-        }
-        BCLK(0);
-        // ---- per-wave partial tiles of G = V^T V (forward: T is built from it) and Wu = V^T U, into the X region (not live yet) ----
-        {
-            f32x4 gp = ZERO4, wu[2] = {ZERO4, ZERO4};
-            for (int it = wave; it < mt; it += 4) {
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = L.Vs[(16 * it + g4 + q) * LDP + c16];
-                if constexpr (!BACK) gp = xty(v, v, gp);
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    if (p < CP) wu[p] = xty(v, ld4(Ut + ((size_t)(k + 1 + it) * CP + p) * 256 + lane * 4), wu[p]);
-            }
-            float* pp = L.Xs + wave * 768;
-            st4(pp + lane * 4, gp);
-            st4(pp + 256 + lane * 4, wu[0]);
-            st4(pp + 512 + lane * 4, wu[1]);
-        }
-        __syncthreads();
-        {
-            const float* pp = L.Xs;
-            if constexpr (!BACK) L.Gs[tid] = pp[tid] + pp[768 + tid] + pp[1536 + tid] + pp[2304 + tid];
-            L.Wus[tid] = pp[256 + tid] + pp[768 + 256 + tid] + pp[1536 + 256 + tid] + pp[2304 + 256 + tid];
-            L.Wus[256 + tid] = pp[512 + tid] + pp[768 + 512 + tid] + pp[1536 + 512 + tid] + pp[2304 + 512 + tid];
-        }
-        __syncthreads();
-        if constexpr (!BACK) {
-            // T by rows (larft): T[i][i] = tau_i, T[i][j] = -tau_j sum_{l=i}^{j-1} T[i][l] G[l][j]; thread i < 16 owns row i
-            if (tid < 16) {
-                float tr[16];
-                float ti = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) ti = (tid == j) ? tau[j] : ti;
+                BCLK(8);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    float s = 0.f;
+                    const bool b0 = lr0 > j;
+                    const float x0 = b0 ? p0[j] : 0.f, x1 = p1[j];
+                    float part[16];
 #pragma unroll
-                    for (int l = 0; l < j; ++l) s += tr[l] * L.Gs[64 * (l >> 2) + 4 * j + (l & 3)];
-                    tr[j] = (j > tid) ? -tau[j] * s : (j == tid ? ti : 0.f);
+                    for (int c = 0; c < j; ++c) part[c] = 0.f;
+                    part[j] = x0 * x0 + x1 * x1;
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) part[c] = x0 * p0[c] + x1 * p1[c];
+                    const float tot = wave_sum16(part, lane);
+                    float* rd = L.red + (j & 1) * 68;
+                    float* rj = L.rowj + (j & 1) * 16;
+                    if ((lane & 3) == 0) rd[4 * (((lane >> 2) & 1) + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1) * 4 + ((lane >> 5) & 1) * 8) + wave] = tot;        // [column][wave]
+                    if (tid == j) {
+#pragma unroll
+                        for (int c = j; c < 16; ++c) rj[c] = p0[c];
+                    }
+                    __syncthreads();
+                    const f32x4 ssp = ld4(rd + 4 * j);
+                    const float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
+                    const float alpha = rj[j];
+                    float tj = 0.f;
+                    if (ss > 0.f) {                                                       // uniform
+                        const float norm = sqrtf(alpha * alpha + ss);
+                        const float beta = alpha >= 0.f ? -norm : norm;
+                        tj = (beta - alpha) / beta;
+                        const float scale = 1.0f / (alpha - beta);
+                        const float v0 = b0 ? x0 * scale : (lr0 == j ? 1.0f : 0.f), v1 = x1 * scale;
+                        const float tv0 = tj * v0, tv1 = tj * v1;
+#pragma unroll
+                        for (int c = j + 1; c < 16; ++c) {
+                            const f32x4 dp = ld4(rd + 4 * c);
+                            const float w = rj[c] + scale * ((dp[0] + dp[1]) + (dp[2] + dp[3]));
+                            p0[c] -= tv0 * w;
+                            p1[c] -= tv1 * w;
+                        }
+                        p0[j] = b0 ? v0 : (lr0 == j ? beta : p0[j]);
+                        p1[j] = v1;
+                    } else {
+                        p0[j] = b0 ? 0.f : p0[j];
+                        p1[j] = 0.f;
+                    }
+                    if (tid == 0) L.taus[j] = tj;
                 }
+                BCLK(9);
+                // V' (unit lower trapezoidal) -> its tiles in the workspace; R -> tile (kn + 1, kn)
+                if (lr0 < m) {
+                    float* vt = Vg + (size_t)(vb_next + (lr0 >> 4)) * 256 + 64 * ((lr0 & 15) >> 2) + (lr0 & 3);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) L.Ts[tid * LDP + j] = tr[j];
-            }
-            __syncthreads();
-            if (wave == 0) {
-                f32x4 tt;
+                    for (int c = 0; c < 16; ++c) vt[4 * c] = (lr0 > c) ? p0[c] : (lr0 == c ? 1.0f : 0.f);
+                }
+                if (lr1 < m) {
+                    float* vt = Vg + (size_t)(vb_next + (lr1 >> 4)) * 256 + 64 * ((lr1 & 15) >> 2) + (lr1 & 3);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tt[q] = L.Ts[(g4 + q) * LDP + c16];
-                st4(Tg + (size_t)k * 256 + lane * 4, tt);
+                    for (int c = 0; c < 16; ++c) vt[4 * c] = p1[c];
+                }
+                if (tid < 16) {
+                    float* tl = At + (size_t)lslot(kn + 1, kn) * 256;     // tile (kn + 1, kn)[b][a] = R[b][a]
+                    const int bq = tid;
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) tl[64 * (bq >> 2) + 4 * a + (bq & 3)] = (a >= bq) ? p0[a] : 0.f;
+                }
+                __syncthreads();
             }
         }
-        // ThT = Th^T in the accumulator layout: forward Th = T^T, back Th = T
-        f32x4 ThT;
+        BCLK(0);
+        // ---- the pass over the stored tiles ----
+        f32x4 part[BAND_MAXNT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ThT[q] = BACK ? L.Ts[c16 * LDP + g4 + q] : L.Ts[(g4 + q) * LDP + c16];
-        // ---- U <- (I - V Th V^T) U :  Z_p = Th Wu_p,  U_ip -= V_i Z_p ----
-        {
-            f32x4 z[2];
+        for (int j = 0; j < BAND_MAXNT; ++j) part[j] = ZERO4;
+        f32x4 gp = ZERO4, wu[2] = {ZERO4, ZERO4};
+        const int jlo = BACK ? 0 : (have_next ? r_next : r_prev);
+        const int ilo = BACK ? (have_next ? r_next : r_prev) : jlo;
+        if (want_m || have_next) {
+            for (int i = NT - 1; i >= ilo; --i) {
+                if (row_owner(NT, i) != wave) continue;
+                const bool upd = want_m && have_prev && i >= r_prev, xf = have_next && i >= r_next;
+                const f32x4 nvt = upd ? neg4(ld4(L.Vs + (16 * (i - r_prev) + c16) * LDP + g4)) : ZERO4;
+                const f32x4 nyt = upd ? neg4(ld4(L.Ys + (16 * i + c16) * LDP + g4)) : ZERO4;
+                const f32x4 vni = xf ? bload4(Vr, lane16, (vb_next + i - r_next) * 1024) : ZERO4;
+                if (xf) {
+                    if constexpr (!BACK) gp = xty(vni, vni, gp);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) z[p] = (p < CP) ? xty0(ThT, ld4(L.Wus + p * 256 + lane * 4)) : ZERO4;
-            for (int it = wave; it < mt; it += 4) {
-                const f32x4 nvt = neg4(ld4(L.Vs + (16 * it + c16) * LDP + g4));
+                    for (int p = 0; p < 2; ++p)
+                        if (p < CP) wu[p] = xty(vni, ld4(Ut + ((size_t)i * CP + p) * 256 + lane * 4), wu[p]);
+                }
+                if (!want_m) continue;
+                f32x4 xo = ZERO4;
+                const int rowbase = lslot(i, 0);
+                f32x4 a_nx = bload4(Ar, lane16, (rowbase + jlo) * 1024);
+                f32x4 vn_nx = (have_next && jlo >= r_next && jlo < i) ? bload4(Vr, lane16, (vb_next + jlo - r_next) * 1024) : ZERO4;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    if (p < CP) {
-                        float* up = Ut + ((size_t)(k + 1 + it) * CP + p) * 256 + lane * 4;
-                        st4(up, xty(nvt, z[p], ld4(up)));
+                for (int j = 0; j < BAND_MAXNT; ++j) {
+                    if (j >= jlo && j <= i) {                                               // uniform
+                        f32x4 a = a_nx;
+                        const f32x4 vnj = vn_nx;
+                        a_nx = bload4(Ar, lane16, (j + 1 <= i) ? (rowbase + j + 1) * 1024 : OOB);
+                        vn_nx = bload4(Vr, lane16, (have_next && j + 1 >= r_next && j + 1 < i) ? (vb_next + j + 1 - r_next) * 1024 : OOB);
+                        if (upd) {
+                            a = xty(nvt, ld4(L.Ys + (16 * j + c16) * LDP + g4), a);
+                            if (j >= r_prev) a = xty(nyt, ld4(L.Vs + (16 * (j - r_prev) + c16) * LDP + g4), a);
+                            bstore4(Ar, a, lane16, (rowbase + j) * 1024);
+                        }
+                        if (xf) part[j] = xty(vni, a, part[j]);                             // V'_i^T A_ij -> Xt'_j
+                        if (have_next && j >= r_next && j < i) {
+                            // Xt'_i += V'_j^T A_ij^T: the tile transposed through the wave's scratch
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) L.Tsc[c16 * TSC_LD + g4 + q] = a[q];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            f32x4 at;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) at[q] = L.Tsc[(g4 + q) * TSC_LD + c16];
+                            xo = xty(vnj, at, xo);
+                        }
+                        if (j == i) part[j] += xo;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from hoisting the next tiles' operand loads: 27 unrolled bodies)
+                }
+            }
+        }
+        __syncthreads();
+        BCLK(1);
+        if (have_next) {
+            // ---- the waves' partials meet in LDS in a fixed order: X' (over the dead Y), V'^T V', V'^T U ----
+            for (int r = 0; r < 4; ++r) {
+                if (wave == r) {
+                    if (want_m) {
+                        // straight-line code: a tile outside the range goes to the wave's scratch instead (28 uniform branches around out-of-line bodies cost
+                        // more than the 28 LDS round trips: measured 4 k cycles per round)
+                        float* const sink = L.Tsc + lane * 4;
+#pragma unroll
+                        for (int j0 = 0; j0 < BAND_MAXNT; j0 += 9) {
+                            f32x4 old[9];
+                            float* xp[9];
+#pragma unroll
+                            for (int u = 0; u < 9; ++u) {
+                                const int j = j0 + u;
+                                xp[u] = (j >= jlo && j < NT) ? L.Ys + (16 * j + c16) * LDP + g4 : sink;
+                                old[u] = ld4(xp[u]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 9; ++u) st4(xp[u], r == 0 ? part[j0 + u] : part[j0 + u] + old[u]);
+                        }
+                    }
+                    if constexpr (!BACK) st4(L.Gs + lane * 4, r == 0 ? gp : gp + ld4(L.Gs + lane * 4));
+                    st4(L.Wus + lane * 4, r == 0 ? wu[0] : wu[0] + ld4(L.Wus + lane * 4));
+                    st4(L.Wus + 256 + lane * 4, r == 0 ? wu[1] : wu[1] + ld4(L.Wus + 256 + lane * 4));
+                }
+                __syncthreads();
+            }
+            BCLK(2);
+            // ---- V' -> LDS, T' ----
+            for (int i2 = wave; i2 < mtn; i2 += 4) {
+                const f32x4 v = ld4(Vg + (size_t)(vb_next + i2) * 256 + lane * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) L.Vs[(16 * i2 + g4 + q) * LDP + c16] = v[q];
+            }
+            if constexpr (!BACK) {
+                // T by rows (larft): T[i][i] = tau_i, T[i][j] = -tau_j sum_{l=i}^{j-1} T[i][l] G[l][j]; thread i < 16 owns row i
+                if (tid < 16) {
+                    float tr[16];
+                    const float ti = L.taus[tid];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int l = 0; l < j; ++l) s += tr[l] * L.Gs[64 * (l >> 2) + 4 * j + (l & 3)];
+                        tr[j] = (j > tid) ? -L.taus[j] * s : (j == tid ? ti : 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) L.Ts[tid * LDP + j] = tr[j];
+                }
+            } else {
+                if (wave == 0) {
+                    const f32x4 tt = ld4(Tg + (size_t)kn * 256 + lane * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) L.Ts[(g4 + q) * LDP + c16] = tt[q];
+                }
+            }
+            __syncthreads();
+            if constexpr (!BACK) {
+                if (wave == 0) {
+                    f32x4 tt;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt[q] = L.Ts[(g4 + q) * LDP + c16];
+                    st4(Tg + (size_t)kn * 256 + lane * 4, tt);
+                }
+            }
+            BCLK(3);
+            // ThT = Th^T in the accumulator layout: forward Th = T^T, back Th = T
+            f32x4 ThT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ThT[q] = BACK ? L.Ts[c16 * LDP + g4 + q] : L.Ts[(g4 + q) * LDP + c16];
+            // ---- U <- (I - V' Th V'^T) U;  per-wave partial of S = V'^T X' ----
+            {
+                f32x4 z[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) z[p] = (p < CP) ? xty0(ThT, ld4(L.Wus + p * 256 + lane * 4)) : ZERO4;
+                f32x4 sp = ZERO4;
+                for (int i2 = wave; i2 < mtn; i2 += 4) {
+                    const int i = r_next + i2;
+                    const f32x4 nvt = neg4(ld4(L.Vs + (16 * i2 + c16) * LDP + g4));
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        if (p < CP) {
+                            float* up = Ut + ((size_t)i * CP + p) * 256 + lane * 4;
+                            st4(up, xty(nvt, z[p], ld4(up)));
+                        }
+                    }
+                    if (want_m) {
+                        f32x4 xi, vi;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { xi[q] = L.Ys[(16 * i + g4 + q) * LDP + c16]; vi[q] = L.Vs[(16 * i2 + g4 + q) * LDP + c16]; }
+                        sp = xty(vi, xi, sp);
                     }
                 }
+                st4(L.Part + wave * 256 + lane * 4, sp);
             }
-        }
-        BCLK(1);
-        if (want_m) {
-            const int ilo = BACK ? 0 : k + 1;
-            // ---- Xt_i = sum_{j > k} V_j^T A_ji  -> Xs (row-major X), per-wave partial of S = V^T X ----
-            __syncthreads();                                  // the partial tiles in the X region have been consumed
-            f32x4 sp = ZERO4;
-            for (int i = ilo + wave; i < NT; i += 4) {
-                f32x4 acc0 = ZERO4, acc1 = ZERO4;
-                const float* acol = At + (size_t)i * 256 + lane * 4;
-                int jt = 0;
-                for (; jt + 1 < mt; jt += 2) {
-                    f32x4 v0, v1;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { v0[q] = L.Vs[(16 * jt + g4 + q) * LDP + c16]; v1[q] = L.Vs[(16 * jt + 16 + g4 + q) * LDP + c16]; }
-                    const f32x4 a0 = ld4(acol + (size_t)(k + 1 + jt) * NT * 256), a1 = ld4(acol + (size_t)(k + 2 + jt) * NT * 256);
-                    acc0 = xty(v0, a0, acc0);
-                    acc1 = xty(v1, a1, acc1);
-                }
-                if (jt < mt) {
-                    f32x4 v0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v0[q] = L.Vs[(16 * jt + g4 + q) * LDP + c16];
-                    acc0 = xty(v0, ld4(acol + (size_t)(k + 1 + jt) * NT * 256), acc0);
-                }
-                acc0 += acc1;
-                st4(L.Xs + (16 * i + c16) * LDP + g4, acc0);                 // Xt_i[a][b] = X[16 i + b][a]
-                if (i > k) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    f32x4 xi, vi;
-                    const int it = i - k - 1;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { xi[q] = L.Xs[(16 * i + g4 + q) * LDP + c16]; vi[q] = L.Vs[(16 * it + g4 + q) * LDP + c16]; }
-                    sp = xty(vi, xi, sp);
-                }
-            }
-            st4(L.Part + wave * 256 + lane * 4, sp);
             __syncthreads();
-            BCLK(2);
-            // ---- Wm = Th S Th^T;  Yt_j = Th Xt_j - 0.5 Wm Vt_j  (in place over X) ----
-            {
+            BCLK(4);
+            // ---- Wm = Th S Th^T;  Yt_j = Th Xt_j - 0.5 Wm Vt_j  (in place over X') ----
+            if (want_m) {
                 const f32x4 s = ld4(L.Part + lane * 4) + ld4(L.Part + 256 + lane * 4) + ld4(L.Part + 512 + lane * 4) + ld4(L.Part + 768 + lane * 4);
                 const f32x4 tmp = xty0(s, ThT);                   // S Th^T
                 f32x4 hwm = xty0(ThT, tmp);                       // Th S Th^T
                 hwm *= -0.5f;
-                for (int j = ilo + wave; j < NT; j += 4) {
-                    float* xp = L.Xs + (16 * j + c16) * LDP + g4;
+                for (int j = (BACK ? 0 : r_next) + wave; j < NT; j += 4) {
+                    float* xp = L.Ys + (16 * j + c16) * LDP + g4;
                     f32x4 y = xty0(ThT, ld4(xp));
-                    if (j > k) y = xty(hwm, ld4(L.Vs + (16 * (j - k - 1) + c16) * LDP + g4), y);
+                    if (j >= r_next) y = xty(hwm, ld4(L.Vs + (16 * (j - r_next) + c16) * LDP + g4), y);
                     st4(xp, y);
                 }
             }
             __syncthreads();
-            BCLK(3);
-            // ---- A_ij -= V_i Y_j^T + Y_i V_j^T ----
-            for (int i = ilo + wave; i < NT; i += 4) {
-                const bool vi_ok = i > k;
-                const f32x4 nvt = vi_ok ? neg4(ld4(L.Vs + (16 * (i - k - 1) + c16) * LDP + g4)) : ZERO4;
-                const f32x4 nyt = neg4(ld4(L.Xs + (16 * i + c16) * LDP + g4));
-                float* arow = At + (size_t)i * NT * 256 + lane * 4;
-                const int jlo = vi_ok ? ilo : k + 1;               // rows without V only meet the columns with V
-                int j = jlo;
-                for (; j + 1 < NT; j += 2) {
-                    f32x4 a0 = ld4(arow + (size_t)j * 256), a1 = ld4(arow + (size_t)(j + 1) * 256);
-                    if (vi_ok) {
-                        a0 = xty(nvt, ld4(L.Xs + (16 * j + c16) * LDP + g4), a0);
-                        a1 = xty(nvt, ld4(L.Xs + (16 * j + 16 + c16) * LDP + g4), a1);
-                    }
-                    if (j > k) a0 = xty(nyt, ld4(L.Vs + (16 * (j - k - 1) + c16) * LDP + g4), a0);
-                    if (j + 1 > k) a1 = xty(nyt, ld4(L.Vs + (16 * (j - k) + c16) * LDP + g4), a1);
-                    st4(arow + (size_t)j * 256, a0);
-                    st4(arow + (size_t)(j + 1) * 256, a1);
-                }
-                if (j < NT) {
-                    f32x4 a0 = ld4(arow + (size_t)j * 256);
-                    if (vi_ok) a0 = xty(nvt, ld4(L.Xs + (16 * j + c16) * LDP + g4), a0);
-                    if (j > k) a0 = xty(nyt, ld4(L.Vs + (16 * (j - k - 1) + c16) * LDP + g4), a0);
-                    st4(arow + (size_t)j * 256, a0);
-                }
-            }
-            BCLK(4);
+            BCLK(5);
         }
-        __syncthreads();
     }
     if constexpr (BACK) {
-        // ---- W[b] = 0.5 (M + M^T) row-major, alpha[b, c, :] = a_c / sv_c ----
+        // ---- W[b] row-major (both triangles from the stored one), alpha[b, c, :] = a_c / sv_c ----
         const int b = t.b0 + bl;
         if (t.grad) {
             float* Wb = t.a.W + (size_t)b * N * N;
-            f32x4 iden;
+            f32x4 hiden;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) iden[q] = (g4 + q == c16) ? 0.5f : 0.f;
+            for (int q = 0; q < 4; ++q) hiden[q] = (g4 + q == c16) ? 0.5f : 0.f;
+            const bool wvec = (N & 3) == 0;
             const int ntt = NT * (NT + 1) / 2;
-            for (int s = wave; s < ntt; s += 4) {
-                int i = 0, rem = s;
-                while (rem >= NT - i) { rem -= NT - i; ++i; }
-                const int j = i + rem;                                                     // i <= j
-                const f32x4 a = ld4(At + ((size_t)i * NT + j) * 256 + lane * 4), bt = ld4(At + ((size_t)j * NT + i) * 256 + lane * 4);
-                f32x4 w = xty0(bt, iden);                                                  // 0.5 M_ji^T
-                w += 0.5f * a;
-                // tile (i, j)[4g + q][c] = W[16i + 4g + q][16j + c] = W[16j + c][16i + 4g + q]: a 16-byte store per lane into row 16j + c ...
-                const int row = 16 * j + c16, col = 16 * i + g4;
-                if (row < N) {
+            int ti = 0, tj = wave;                                                         // the wave's slots wave, wave + 4, ...: (ti, tj) walks along with the slot
+            while (tj > ti) { tj -= ti + 1; ++ti; }
+            for (int s0 = wave; s0 < ntt; s0 += 16) {                                      // four tiles in flight
+                f32x4 wv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col + q < N) Wb[(size_t)row * N + col + q] = w[q];
-                }
-                if (i != j) {                                                              // ... and its mirror, row 16i + 4g + q, columns 16j + c
+                for (int u = 0; u < 4; ++u) wv[u] = bload4(Ar, lane16, (s0 + 4 * u < ntt) ? (s0 + 4 * u) * 1024 : OOB);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r2 = 16 * i + g4 + q, c2 = 16 * j + c16;
-                        if (r2 < N && c2 < N) Wb[(size_t)r2 * N + c2] = w[q];
+                for (int u = 0; u < 4; ++u) {
+                    if (s0 + 4 * u < ntt) {
+                        const int i = ti, j = tj;
+                        f32x4 w = wv[u];
+                        if (i == j) w = xty(w, hiden, 0.5f * w);                           // a diagonal tile carries both halves: 0.5 (M_ii + M_ii^T), bitwise symmetric
+                        // tile (i, j)[4g + q][c] = W[16i + 4g + q][16j + c] and, W being symmetric, = W[16j + c][16i + 4g + q]
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r2 = 16 * i + g4 + q, c2 = 16 * j + c16;
+                            if (r2 < N && c2 < N) Wb[(size_t)r2 * N + c2] = w[q];
+                        }
+                        if (i != j) {                                                      // the mirror: 16 bytes per lane into row 16j + c
+                            const int row = 16 * j + c16, col = 16 * i + g4;
+                            if (row < N) {
+                                if (wvec && col + 3 < N) st4(Wb + (size_t)row * N + col, w);
+                                else {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        if (col + q < N) Wb[(size_t)row * N + col + q] = w[q];
+                                }
+                            }
+                        }
+                        tj += 4;
+                        while (tj > ti) { tj -= ti + 1; ++ti; }
                     }
                 }
             }
         }
+        BCLK(10);
         for (int u = wave; u < NT * CP; u += 4) {
             const int i = u / CP, p = u - i * CP;
             const int cls = 16 * p + c16;
@@ -484,6 +549,7 @@ __global__ __launch_bounds__(256, 2) void band_twosided_kernel(BandArgs t) {
                 }
             }
         }
+        BCLK(11);
         // ---- the quadratic form against the ORIGINAL matrix.  The reduction's backward error (a few eps |E|) moves the small eigenvalues of K_c by a relative
         //      eps |E| sv / noise, which the quadratic form r^T K^-1 r feels in full (the log-determinant averages it out: measured 1e-6 against 3e-5 ... 9e-5 on
         //      class-correlated features, tools/band_mll_model.py).  With the residual rho = r - K alpha of the computed alpha, r^T K^-1 r = (r + rho)^T alpha up to
@@ -494,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void band_twosided_kernel(BandArgs t) {
             float qp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // per class column: (2r - E a~ - mu a~).a~,  a~.E a~,  a~.a~,  sum a~
             for (int i = wave; i < NT; i += 4) {
                 f32x4 ea[2] = {ZERO4, ZERO4};
+#pragma unroll 4
                 for (int j = 0; j < NT; ++j) {
                     // tile (j, i) of E in the accumulator layout: element [4g + q][c] = E[16j + 4g + q][16i + c] = E[16i + c][16j + 4g + q]
                     const int row = 16 * i + c16, col = 16 * j + g4;
@@ -562,9 +629,17 @@ __global__ __launch_bounds__(256, 2) void band_twosided_kernel(BandArgs t) {
         }
     }
 #ifdef DKT_BAND_CLOCKS
-    if (tid == 0 && t.a.dnoise && bl < 64) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(t.ws + (size_t)t.bcnt * G.ep_floats) + (BACK ? 512 : 0) + bl * 8;
-        for (int i = 0; i < 8; ++i) out[i] = clk[i];
+    // measurement build (tools/band_phase_clocks.py): thread 0's accumulated s_memtime ticks per phase, reported through alpha[b, 0 / 1, 0..7] (overwriting it)
+    __syncthreads();
+    if (tid == 0) {
+        float* cw = t.ws + (size_t)t.bcnt * G.ep_floats + (size_t)bl * 12;
+        if constexpr (!BACK) {
+            for (int i = 0; i < 12; ++i) cw[i] = clkl[i];
+        } else {
+            BCLK(6);
+            float* al = t.a.alpha + (size_t)(t.b0 + bl) * G.C * N;
+            for (int i = 0; i < 12; ++i) { al[i] = cw[i]; al[N + i] = clkl[i]; }
+        }
     }
 #endif
 }
@@ -596,17 +671,17 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     const int pu = cls >> 4, cu = cls & 15;                                 // U column of this class
     const bool col0 = c16 == 0;
 
-    f32x4 ngt_prev = ZERO4, yprev = ZERO4;
+    f32x4 ngt_prev = ZERO4, yprev = ZERO4, st_prev = ZERO4;
     float lsum = 0.f;
     int fail_at = 0;
     for (int j = 0; j < NT; ++j) {
-        f32x4 P = ld4(At + ((size_t)j * NT + j) * 256 + lane * 4);
+        f32x4 P = ld4(At + (size_t)lslot(j, j) * 256 + lane * 4);
         float dmax = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (g4 + q == c16) P[q] = (16 * j + c16 < N) ? P[q] + mu : 1.0f;
         }
-        if (j > 0) P = xty(ngt_prev, ld4(At + ((size_t)(j - 1) * NT + j) * 256 + lane * 4), P);       // - G_{j-1} S_{j-1}^T
+        if (j > 0) P = xty(ngt_prev, st_prev, P);                                        // - G_{j-1} S_{j-1}^T
 #pragma unroll
         for (int q = 0; q < 4; ++q) dmax = (g4 + q == c16) ? fmaxf(dmax, P[q]) : dmax;
         dmax = wave_reduce_dpp<true>(dmax);
@@ -639,7 +714,10 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
         st4(Pg + (size_t)j * 256 + lane * 4, Pinv);
         if (col0) st4(Zv + j * 16 + g4, z);
         if (j + 1 < NT) {
-            const f32x4 St = ld4(At + ((size_t)j * NT + j + 1) * 256 + lane * 4);
+            // S_j^T in the accumulator layout from the stored tile (j + 1, j) = S_j: lane (g, c) register q <- S_j[c][4g + q]
+            const float* sp = At + (size_t)lslot(j + 1, j) * 256 + 64 * (c16 >> 2) + 4 * g4 + (c16 & 3);
+            const f32x4 St = {sp[0], sp[4], sp[8], sp[12]};
+            st_prev = St;
             const f32x4 Gj = xty0(St, Pinv);                                             // S_j P^-1
             ngt_prev = neg4(xty0(Pinv, St));                                             // -(P^-1 S_j^T) = -G_j^T
             st4(Gg + (size_t)j * 256 + lane * 4, Gj);
@@ -692,15 +770,26 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-// M = sum_c 0.5 cw_c (a_c a_c^T / sv_c - Z^c): a wave owns block columns, accumulates them over the classes in registers
+// M = sum_c 0.5 cw_c (a_c a_c^T / sv_c - Z^c), Z^c = (B + mu_c)^-1: block column i of Z^c follows from its diagonal block upwards, Z_ji = -G_j^T Z_{j+1,i}.
+// Workgroup = episode, 16 waves; wave w owns the block columns NT-1-w and NT-32+w (23 .. 27 tiles together) and keeps their tiles as accumulators over the
+// classes; the G tiles of a class are staged once through LDS (double buffered, one barrier per class), the diagonal blocks come straight from memory.
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_chain_kernel(BandArgs t) {
+constexpr int CHAIN_WAVES = 8;
+constexpr int NACC_P = BAND_MAXNT, NACC_Q = 2 * BAND_MAXNT - 31 + 1;
+
+// one step of a column chain: z <- G_j^T z (the G tile from the LDS image), accumulate with the alternating sign
+__device__ __forceinline__ void chain_step(f32x4& z, f32x4& a, const float* gtile, const float sg) {
+    z = xty0(ld4(gtile), z);
+    a += sg * z;
+}
+
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void band_chain_kernel(BandArgs t) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const BandGeo& G = t.g;
     const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = G.NT, C = G.C, CP = G.CP;
     const int bl = blockIdx.x;
-    const int nw = 4 * gridDim.y, wv = blockIdx.y * 4 + wave;
     float* ep = t.ws + (size_t)bl * G.ep_floats;
     float* At = ep + G.oA;
     const float* Gg = ep + G.oG;
@@ -708,11 +797,69 @@ __global__ __launch_bounds__(256) void band_chain_kernel(BandArgs t) {
     const float* AmT = ep + G.oAmT;
     const int b = t.b0 + bl;
     const int32_t* info = t.a.info + (size_t)b * C;
+    // the wave's four block columns, by distance from the last one: e = w, 31 - w (accumulators P: the first from the front, the second from the back) and
+    // e = 15 - w, 16 + w (accumulators Q); column i = NT - 1 - e has i + 1 tiles (j = i .. 0), a negative i means "none".  46 .. 50 tiles per wave.
+    const int i0 = NT - 1 - wave, i3 = NT - 32 + wave, i1 = NT - 16 + wave, i2 = NT - 17 - wave;
+    const int l0 = i0 + 1, l3 = i3 >= 0 ? i3 + 1 : 0, l1 = i1 >= 0 ? i1 + 1 : 0, l2 = i2 >= 0 ? i2 + 1 : 0;
+    f32x4 P[NACC_P], Q[NACC_Q];
+#pragma unroll
+    for (int s = 0; s < NACC_P; ++s) P[s] = ZERO4;
+#pragma unroll
+    for (int s = 0; s < NACC_Q; ++s) Q[s] = ZERO4;
+    const int ngt = NT - 1;                                        // G tiles per class
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(1))) const unsigned char glb_u8;
+    // the G tiles of class c straight into LDS buffer bufi (global_load_lds_dwordx4: no staging registers), tiles wave, wave + 8, ...
+    auto fetch = [&](const int c, const int bufi) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tile = wave + CHAIN_WAVES * u;
+            if (tile < ngt)
+                __builtin_amdgcn_global_load_lds((glb_u8*)(Gg + ((size_t)c * NT + tile) * 256) + lane * 16,
+                                                 (lds_u8*)(smem + ((size_t)bufi * BAND_MAXNT + tile) * 256), 16, 0, 0);
+        }
+    };
+    fetch(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);                   // vmcnt(0)
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        const float* gb = smem + (c & 1) * (BAND_MAXNT * 256) + lane * 4;
+        if (c + 1 < C) fetch(c + 1, (c + 1) & 1);
+        if (info[c] == 0) {                                        // (a failed class leaves the episode to the fix-up launch)
+            const float wz = -0.5f * (t.a.cls_weight ? t.a.cls_weight[c] : 1.0f);
+            const float* zc = Zg + (size_t)c * NT * 256 + lane * 4;
+            {   // columns e = w and e = 31 - w
+                f32x4 za = ld4(zc + (size_t)i0 * 256), zb = l3 ? ld4(zc + (size_t)i3 * 256) : ZERO4;
+                P[0] += wz * za;
+                P[NACC_P - 1] += wz * zb;
+#pragma unroll
+                for (int s = 1; s < NACC_P; ++s) {
+                    const float sg = (s & 1) ? -wz : wz;           // Z_ji = (-1)^s G_j^T ... G_{i-1}^T Z_ii
+                    if (s < l0) chain_step(za, P[s], gb + (size_t)(i0 - s) * 256, sg);
+                    if (s < l3) chain_step(zb, P[NACC_P - 1 - s], gb + (size_t)(i3 - s) * 256, sg);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // columns e = 15 - w and e = 16 + w
+                f32x4 za = l1 ? ld4(zc + (size_t)i1 * 256) : ZERO4, zb = l2 ? ld4(zc + (size_t)i2 * 256) : ZERO4;
+                Q[0] += wz * za;
+                Q[NACC_Q - 1] += wz * zb;
+#pragma unroll
+                for (int s = 1; s < NACC_Q; ++s) {
+                    const float sg = (s & 1) ? -wz : wz;
+                    if (s < l1) chain_step(za, Q[s], gb + (size_t)(i1 - s) * 256, sg);
+                    if (s < l2) chain_step(zb, Q[NACC_Q - 1 - s], gb + (size_t)(i2 - s) * 256, sg);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);               // vmcnt(0): the next class' tiles have landed
+        __syncthreads();
+    }
+    // rank-C term M_ji += sum_p (A^T_pj)^T diag(ka) A^T_pi, then the stored triangle: tile (i, j) = M_ji^T
     f32x4 iden;
 #pragma unroll
     for (int q = 0; q < 4; ++q) iden[q] = (g4 + q == c16) ? 1.0f : 0.f;
-    // weights of the rank-C term by the class rows of an A^T tile: 0.5 cw_c / sv_c (0 beyond C and for a failed class)
-    f32x4 ka[2];
+    f32x4 ka[2];                                                   // 0.5 cw_c / sv_c by the class rows of an A^T tile (0 beyond C and for a failed class)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -720,47 +867,34 @@ __global__ __launch_bounds__(256) void band_chain_kernel(BandArgs t) {
             const int c = 16 * p + g4 + q;
             ka[p][q] = (c < C && info[c < C ? c : 0] == 0) ? 0.5f * (t.a.cls_weight ? t.a.cls_weight[c] : 1.0f) / t.a.sv[c] : 0.f;
         }
-    // zig-zag assignment of the block columns: wv, 2 nw - 1 - wv, 2 nw + wv, ...
-    for (int base = 0; base < NT; base += 2 * nw) {
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int i = half == 0 ? base + wv : base + 2 * nw - 1 - wv;
-            if (i >= NT) continue;
-            f32x4 acc[BAND_MAXNT];
+    auto finish = [&](f32x4 m, const int i, const int s, const f32x4 (&ai)[2]) {       // + the rank-C term, store tile (i, i - s) = M_ji^T
+        const int j = i - s;
 #pragma unroll
-            for (int s = 0; s < BAND_MAXNT; ++s) acc[s] = ZERO4;
-            for (int c = 0; c < C; ++c) {
-                if (info[c] != 0) continue;
-                const float wz = -0.5f * (t.a.cls_weight ? t.a.cls_weight[c] : 1.0f);
-                f32x4 z = ld4(Zg + ((size_t)c * NT + i) * 256 + lane * 4);
-                acc[0] += wz * z;
+        for (int p = 0; p < 2; ++p)
+            if (p < CP) m = xty(ld4(AmT + ((size_t)p * NT + j) * 256 + lane * 4), ai[p], m);
+        st4(At + (size_t)lslot(i, j) * 256 + lane * 4, s > 0 ? xty0(m, iden) : m);
+    };
+    auto col_ops = [&](const int i, f32x4 (&ai)[2]) {
 #pragma unroll
-                for (int s = 1; s < BAND_MAXNT; ++s) {
-                    if (s <= i) {
-                        z = xty0(ld4(Gg + ((size_t)c * NT + i - s) * 256 + lane * 4), z);          // G_j^T z;  the sign alternates
-                        acc[s] += ((s & 1) ? -wz : wz) * z;
-                    }
-                }
-            }
-            // rank-C term: M_ji += sum_p (A^T_pj)^T diag(ka) A^T_pi
-            f32x4 ai[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                ai[p] = (p < CP) ? ld4(AmT + ((size_t)p * NT + i) * 256 + lane * 4) : ZERO4;
-                ai[p] *= ka[p];
-            }
-#pragma unroll
-            for (int s = 0; s < BAND_MAXNT; ++s) {
-                if (s <= i) {
-                    const int j = i - s;
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        if (p < CP) acc[s] = xty(ld4(AmT + ((size_t)p * NT + j) * 256 + lane * 4), ai[p], acc[s]);
-                    st4(At + ((size_t)j * NT + i) * 256 + lane * 4, acc[s]);
-                    if (s > 0) st4(At + ((size_t)i * NT + j) * 256 + lane * 4, xty0(acc[s], iden));
-                }
-            }
+        for (int p = 0; p < 2; ++p) {
+            ai[p] = (p < CP && i >= 0) ? ld4(AmT + ((size_t)p * NT + i) * 256 + lane * 4) : ZERO4;
+            ai[p] *= ka[p];
         }
+    };
+    f32x4 a0[2], a1[2];
+    col_ops(i0, a0);
+    col_ops(i3, a1);
+#pragma unroll
+    for (int s = 0; s < NACC_P; ++s) {
+        if (s < l0) finish(P[s], i0, s, a0);
+        if (s < l3) finish(P[NACC_P - 1 - s], i3, s, a1);
+    }
+    col_ops(i1, a0);
+    col_ops(i2, a1);
+#pragma unroll
+    for (int s = 0; s < NACC_Q; ++s) {
+        if (s < l1) finish(Q[s], i1, s, a0);
+        if (s < l2) finish(Q[NACC_Q - 1 - s], i2, s, a1);
     }
 }
 
@@ -774,7 +908,7 @@ bool dkt_mll_band_supports(int N, unsigned flags, int C) {
 size_t dkt_mll_band_workspace_bytes(int B, int C, int N) {
     const BandGeo g = band_geo(N, C);
     const int bc = B < BAND_CHUNK ? B : BAND_CHUNK;
-    size_t fl = (size_t)bc * g.ep_floats + 4096;
+    size_t fl = (size_t)bc * g.ep_floats + 12 * (size_t)bc + 64;      // (+ 12 floats per episode: the phase clocks of the measurement build)
     const size_t gen = dkt_mll_generic_global_floats(bc, N);               // the fix-up pass works in the same region
     return (fl > gen ? fl : gen) * sizeof(float);
 }
@@ -787,11 +921,11 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
     t.ws = (float*)workspace;
     t.grad = (a.flags & DKT_MLL_WANT_GRAD) ? 1 : 0;
     const int NT = t.g.NT;
-    const size_t lds = (size_t)ts_lds_floats(NT) * sizeof(float);
+    const size_t lds = (size_t)sym_lds_floats(NT) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)band_twosided_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) return DKT_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)band_twosided_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) return DKT_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)band_sym_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) return DKT_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)band_sym_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) return DKT_ERR_LAUNCH;
         attr_done = true;
     }
     const int Bc = a.B < BAND_CHUNK ? a.B : BAND_CHUNK;
@@ -799,12 +933,12 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
         const int bcnt = (a.B - b0 < Bc) ? a.B - b0 : Bc;
         t.b0 = b0;
         t.bcnt = bcnt;
-        const int slots = NT * NT + 3 * NT * t.g.CP;
+        const int slots = NT * (NT + 1) / 2 + 3 * NT * t.g.CP;
         hipLaunchKernelGGL(band_init_kernel, dim3((slots + 3) / 4, bcnt), dim3(256), 0, st, t);
-        hipLaunchKernelGGL(band_twosided_kernel<false>, dim3(bcnt), dim3(256), lds, st, t);
+        hipLaunchKernelGGL(band_sym_kernel<false>, dim3(bcnt), dim3(256), lds, st, t);
         hipLaunchKernelGGL(band_class_kernel, dim3(bcnt, (a.C + 3) / 4), dim3(256), 0, st, t);
-        if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt, 2), dim3(256), 0, st, t);
-        hipLaunchKernelGGL(band_twosided_kernel<true>, dim3(bcnt), dim3(256), lds, st, t);
+        if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt), dim3(64 * CHAIN_WAVES), 2 * BAND_MAXNT * 1024, st, t);
+        hipLaunchKernelGGL(band_sym_kernel<true>, dim3(bcnt), dim3(256), lds, st, t);
         MllArgs f = a;
         f.only_failed = a.info;
         dkt_mll_generic_global_launch(f, b0, bcnt, t.ws, st);
