@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
         assert hasattr(lib, name), "libdkt_hip.so lacks %s" % name
         assert name in dkt_amd._lib.SIGNATURES, "no ctypes signature for %s" % name
     assert sorted(dkt_amd._lib.SIGNATURES) == declared
-    assert lib.dkt_abi_version() == 4
+    assert lib.dkt_abi_version() == 5
     # pure host queries (no GPU needed)
     assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # register resident
     # N > 127: blocked path, per (episode, class) four N x N matrices + two vectors + bookkeeping
@@ -71,7 +71,7 @@ def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches()
     upath = os.path.join(os.path.dirname(dkt_amd._lib.LIB_PATH), "build", "libdkt_hip.so.resource_usage.json")       # written by the build in this checkout
     if os.path.exists(upath):
         usage = __import__("json").load(open(upath))
-        assert len(usage) <= 235 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
+        assert len(usage) <= 240 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
         assert dkt_amd._lib.check_resources(usage) == []
 
 
@@ -113,7 +113,10 @@ def test_spill_reloads_stay_out_of_the_streaming_loops():
     not in the K loop; 3 vs 2 workgroups re-measured in profiles/r05/v14_tiled_wgs_ab.log) -- reload a spilled register inside a loop that also loads from memory."""
     import re
     found = dkt_amd._lib.spill_reloads_in_streaming_loops(dkt_amd._lib.LIB_PATH)
-    allowed = (r"mll_h2_kernelILi7E", r"tiled_factor_kernelILi7ELb1ELi3E", r"tiled_invert_kernelILi7ELb1ELb1ELi3E")
+    # round 6: + the two-sided kernels of the band reduction (256 VGPRs: 27 partial accumulators + the operands of the fused pass).  Their reloads sit in the panel
+    # loop -- one per Householder column of the forward kernel, a few per panel in both -- and none in the unrolled tile loop of the pass (the ISA was read:
+    # profiles/r06/INDEX.md); the panel loop "also loads from memory", which is what this audit keys on.
+    allowed = (r"mll_h2_kernelILi7E", r"tiled_factor_kernelILi7ELb1ELi3E", r"tiled_invert_kernelILi7ELb1ELb1ELi3E", r"band_sym_kernelILb[01]E")
     for k in found:
         assert any(re.search(a, k) for a in allowed), (k, found[k])
     for hot in ("gram_sym_ep_split_kernel", "gram_bwd_ep_f16x2_kernel", "mll_h2e_kernel", "gram_bn_train_f16_kernel", "gram_bn_bwd_ep_kernel", "lowrank_", "gram_small"):
