@@ -100,7 +100,7 @@ SPILL_BUDGET = {
     r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 24,
     # band reduction (QR + fused pass at 256 VGPRs): lane constants parked at kernel entry; the forward kernel reloads one per QR column, both a few per panel --
     # none inside the tile loop
-    r"band_sym_kernelILb0E": 24,
+    r"band_sym_kernelILb0E": 32,
     r"band_sym_kernelILb1E": 16,
 }
 

@@ -52,8 +52,9 @@ bool dkt_mll_tiled_supports(int N, unsigned flags, int C = 1);
 size_t dkt_mll_tiled_workspace_bytes(int B, int C, int N);
 size_t dkt_mll_tiled_workspace_bytes_form(int B, int C, int N, bool per_class);
 int dkt_mll_tiled_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
-// Shared-E band path (dkt_mll_band.hip): ONE orthogonal reduction per episode instead of C factorisations (128 <= N <= 432, 8 <= C <= 32; the default there).
+// Shared-E band path (dkt_mll_band.hip): ONE orthogonal reduction per episode instead of C factorisations (128 <= N <= 432, C <= 32; the default from 12 classes and 192 episodes per call).
 bool dkt_mll_band_supports(int N, unsigned flags, int C);
+bool dkt_mll_band_applies(int B, int C, int N, unsigned flags);      // the default dispatch window (C >= 12, B >= 192) or DKT_MLL_FORCE_BAND
 size_t dkt_mll_band_workspace_bytes(int B, int C, int N);
 int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipStream_t st);
 // Generic kernel (dkt_mll.hip) over episodes [b0, b0 + count), global working matrices in `ws`; with a.only_failed set it recomputes

@@ -232,7 +232,7 @@ extern "C" size_t dkt_mll_workspace_bytes_for(int B, int C, int N, unsigned flag
     const size_t gen = mll_fits_lds(N) ? 0 : (size_t)(pc ? (B < 128 ? B : 128) * C : B) * mll_mat_floats(N) * sizeof(float);
     if (flags & DKT_MLL_FORCE_GENERIC) return gen;
     if (N + 1 <= 128) return (flags & DKT_MLL_WANT_CHOL) && (N + 1 + 15) / 16 > 2 ? gen : 0;      // (Cholesky output beyond N = 31: the generic kernel, LDS-resident up to N ~ 190)
-    if (dkt_mll_band_supports(N, flags, C)) return dkt_mll_band_workspace_bytes(B, C, N);
+    if (dkt_mll_band_applies(B, C, N, flags)) return dkt_mll_band_workspace_bytes(B, C, N);
     if (!(flags & DKT_MLL_FORCE_BLOCKED) && dkt_mll_tiled_supports(N, flags, C)) return dkt_mll_tiled_workspace_bytes_form(B, C, N, pc);
     if (pc) return gen;                                                                               // N > 447 with per-class matrices: the generic kernel
     const size_t big = dkt_mll_big_workspace_bytes(B, C, N);
@@ -284,7 +284,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG)) && dkt_mll_mfma_launch(a, st)) return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     // shared base matrix, many classes, 128 <= N <= 447: one orthogonal reduction per episode (dkt_mll_band.hip); DKT_MLL_FORCE_TILED = the tile-array twin
-    if (dkt_mll_band_supports(N, flags, C) && workspace && workspace_bytes >= dkt_mll_band_workspace_bytes(B, C, N))
+    if (dkt_mll_band_applies(B, C, N, flags) && workspace && workspace_bytes >= dkt_mll_band_workspace_bytes(B, C, N))
         return dkt_mll_band_launch(a, workspace, workspace_bytes, st);
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_BLOCKED)) && dkt_mll_tiled_supports(N, flags, C) && workspace &&
         workspace_bytes >= dkt_mll_tiled_workspace_bytes_form(B, C, N, false))

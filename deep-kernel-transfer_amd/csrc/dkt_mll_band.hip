@@ -1,5 +1,5 @@
 // dkt_mll_band.hip -- exact-GP marginal likelihood of the C one-vs-rest models of an episode that SHARE their base matrix (linear / cossim / bncossim,
-// 128 <= N <= 432, 8 <= C <= 32: the 20-way shapes of train.py:132-133) through ONE orthogonal reduction per episode instead of C factorisations.
+// 128 <= N <= 432, 12 <= C <= 32, >= 192 episodes per call: the 20-way shapes of train.py:132-133) through ONE orthogonal reduction per episode instead of C factorisations.
 //
 // Replaces the same reference lines as dkt_mll_tiled.hip (methods/DKT.py:161-163 at C = 20: GPyTorch's psd_safe_cholesky / inv_quad_logdet / cholesky_solve
 // and their autograd backward).  DKT.py:148-149 hands every class model the same z_train and :346-347 freezes the noise, so the class matrices are shifts of
@@ -24,7 +24,7 @@
 //   band_chain_kernel     (wave = block columns)  Z_ji = -G_j^T Z_{j+1,i} upwards from the diagonal, accumulated over the classes in registers, + the rank-C term
 //   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same code with Th = T), a <- H_k a; then W[b] and alpha[b] are stored
 // Attempt 0 only (no jitter): an episode with a failed class is redone -- jitter ladder and all -- by the generic kernel's fix-up launch, as in the tile-array path.
-#include "dkt_mfma_tiles.h"
+#include "dkt_h2_tiles.h"
 
 namespace {
 
@@ -32,12 +32,13 @@ using namespace dkt_mfma;
 
 constexpr int BAND_MAXNT = 27;             // N <= 432 (the accumulators of the pass / chain kernels are sized for it)
 constexpr int LDP = 20;                    // row stride (floats) of the panel-shaped LDS arrays: 16-byte aligned rows
-constexpr int BAND_CHUNK = 1024;
+constexpr int BAND_CHUNK = 1024;           // episodes per pass over the workspace
+constexpr float BAND_KAPPA_MAX = 2.0e4f;   // a-priori condition bound above which an episode goes to the generic kernel (3 eps kappa < 4e-3 on alpha / W below it: measured 1e-5 .. 1e-4 at kappa ~ 1e2 .. 1e3)
 static_assert(BAND_MAXNT % 9 == 0, "the partial-sum rounds walk the tiles nine at a time");           // episodes per pass over the workspace
 
 struct BandGeo {
     int N, NT, C, CP;                      // CP = class-column tiles of U / A
-    int oA, oV, oT, oU, oAm, oAmT, oG, oZd, oPi, oZv;      // offsets (floats) into the episode's workspace
+    int oA, oV, oT, oU, oAm, oAmT, oG, oZd, oPi, oZv, oSc, oVsp;      // offsets (floats) into the episode's workspace
     int ep_floats;
 };
 
@@ -66,6 +67,8 @@ BandGeo band_geo(int N, int C) {
     g.oZd = take(C * g.NT);
     g.oPi = take(C * g.NT);
     g.oZv = take((C * g.NT + 15) / 16);     // 16 floats per (class, block)
+    g.oSc = take(1);                        // per class: a.a (the bound of |M| the back pass scales its f16 splits with)
+    g.oVsp = take(g.NT);                    // the back pass: the next panel's V tiles, split
     g.ep_floats = o;
     return g;
 }
@@ -73,6 +76,13 @@ BandGeo band_geo(int N, int C) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 neg4(const f32x4 v) { return (f32x4){-v[0], -v[1], -v[2], -v[3]}; }
+// the negative of an operand tile: fp32 elements, or (SPLIT) the four packed f16 pairs of a split tile -- the sign bits of both halves
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 negop(const f32x4 v) {
+    if constexpr (!SPLIT) return neg4(v);
+    else return (f32x4){__uint_as_float(__float_as_uint(v[0]) ^ 0x80008000u), __uint_as_float(__float_as_uint(v[1]) ^ 0x80008000u),
+                        __uint_as_float(__float_as_uint(v[2]) ^ 0x80008000u), __uint_as_float(__float_as_uint(v[3]) ^ 0x80008000u)};
+}
 constexpr f32x4 ZERO4 = {0.f, 0.f, 0.f, 0.f};
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
@@ -215,6 +225,35 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
     const bool want_m = !BACK || t.grad;          // the back pass without gradients only carries the class vectors (alpha)
     const int npan = NT - 2;
     const int lane16 = lane * 16;
+    // The back pass runs its tile products as scaled 2-way f16 splits (3 x v_mfma_f32_16x16x16_f16 = 24 cycles instead of 4 x 32; dkt_h2_tiles.h).  It transforms
+    // M by ORTHOGONAL similarities, so every entry it ever holds is bounded by |M|_2 <= sum_c 0.5 |cw_c| (sv_c / noise_c + a_c.a_c / sv_c) -- known before the
+    // pass -- the Householder vectors by 1, and Y by its own maximum, taken when it is formed: the splits keep 22 bits below those bounds, and a rounding here is
+    // NOT amplified by the conditioning of K (the forward reduction, where it would be, stays exact fp32).
+    constexpr float sV = 32768.0f, isV = 1.0f / 32768.0f;
+    float sA = 1.0f, isA = 1.0f, sY = 1.0f, isY = 1.0f;
+    [[maybe_unused]] const brsrc Vsr = mk_rsrc(ep + G.oVsp, (unsigned)(NT * 1024));
+    if constexpr (BACK) {
+        if (want_m) {
+            float bm = 0.f;
+            if (tid < G.C) {
+                const float cwc = t.a.cls_weight ? t.a.cls_weight[tid] : 1.0f, svc = t.a.sv[tid];
+                bm = 0.5f * fabsf(cwc) * (svc / t.a.noise[tid] + ep[G.oSc + tid] / svc);
+            }
+            if (wave == 0) {
+                bm = wave_reduce_dpp<false>(bm);
+                if (lane == 0) L.red[0] = bm;
+            }
+            __syncthreads();
+            bm = L.red[0];
+            if (bm > 0.f && bm < 1e30f) sA = scale_for(bm, isA);
+            {                                                                               // the first panel's tiles, split
+                const int k0 = NT - 3, vb0 = band_voff(NT, k0);
+                for (int i2 = wave; i2 < NT - k0 - 1; i2 += 4)
+                    bstore4(Vsr, split_h2(ld4(Vg + (size_t)(vb0 + i2) * 256 + lane * 4), sV), lane16, i2 * 1024);
+            }
+            __syncthreads();
+        }
+    }
 
     for (int it = 0; it <= npan; ++it) {
         const bool have_prev = it > 0, have_next = it < npan;
@@ -272,10 +311,15 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                     const float alpha = rj[j];
                     float tj = 0.f;
                     if (ss > 0.f) {                                                       // uniform
-                        const float norm = sqrtf(alpha * alpha + ss);
+                        const float nn = alpha * alpha + ss;
+                        float norm = nn * __builtin_amdgcn_rsqf(nn);                          // sqrt to 1 ulp + one Newton step: norm <- 0.5 (norm + nn / norm)
+                        norm = 0.5f * (norm + nn * __builtin_amdgcn_rcpf(norm));
                         const float beta = alpha >= 0.f ? -norm : norm;
-                        tj = (beta - alpha) / beta;
-                        const float scale = 1.0f / (alpha - beta);
+                        float rb = __builtin_amdgcn_rcpf(beta), rs = __builtin_amdgcn_rcpf(alpha - beta);
+                        rb = rb * (2.0f - beta * rb);                                         // one Newton step each: <= 1 ulp
+                        rs = rs * (2.0f - (alpha - beta) * rs);
+                        tj = (beta - alpha) * rb;
+                        const float scale = rs;
                         const float v0 = b0 ? x0 * scale : (lr0 == j ? 1.0f : 0.f), v1 = x1 * scale;
                         const float tv0 = tj * v0, tv1 = tj * v1;
 #pragma unroll
@@ -326,9 +370,11 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
             for (int i = NT - 1; i >= ilo; --i) {
                 if (row_owner(NT, i) != wave) continue;
                 const bool upd = want_m && have_prev && i >= r_prev, xf = have_next && i >= r_next;
-                const f32x4 nvt = upd ? neg4(ld4(L.Vs + (16 * (i - r_prev) + c16) * LDP + g4)) : ZERO4;
-                const f32x4 nyt = upd ? neg4(ld4(L.Ys + (16 * i + c16) * LDP + g4)) : ZERO4;
+                // (back pass: V and Y sit in LDS as split pairs -- their negation flips the sign bits of both halves)
+                const f32x4 nvt = upd ? negop<BACK>(ld4(L.Vs + (16 * (i - r_prev) + c16) * LDP + g4)) : ZERO4;
+                const f32x4 nyt = upd ? negop<BACK>(ld4(L.Ys + (16 * i + c16) * LDP + g4)) : ZERO4;
                 const f32x4 vni = xf ? bload4(Vr, lane16, (vb_next + i - r_next) * 1024) : ZERO4;
+                [[maybe_unused]] const f32x4 vnis = (BACK && xf) ? bload4(Vsr, lane16, (i - r_next) * 1024) : ZERO4;
                 if (xf) {
                     if constexpr (!BACK) gp = xty(vni, vni, gp);
 #pragma unroll
@@ -338,43 +384,76 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                 if (!want_m) continue;
                 f32x4 xo = ZERO4;
                 const int rowbase = lslot(i, 0);
-                f32x4 a_nx = bload4(Ar, lane16, (rowbase + jlo) * 1024);
-                f32x4 vn_nx = (have_next && jlo >= r_next && jlo < i) ? bload4(Vr, lane16, (vb_next + jlo - r_next) * 1024) : ZERO4;
+                [[maybe_unused]] const float kap = sV * sY, ikap = isV * isY;
+                // Tiles and the next panel's V tiles arrive through rings of PF / 2 registers, refilled PF / 2 tiles ahead.  Every memory instruction of the row
+                // sits OUTSIDE the uniform branches (an absent tile reads / writes an offset the descriptor rejects: no traffic), so the in-order memory counter is
+                // known statically and a tile's wait is vmcnt(2 PF + ...) instead of vmcnt(0); only arithmetic and LDS traffic are conditional.
+                constexpr int PF = BACK ? 4 : 2;                    // (forward: its fp32 products leave no room for more tiles in flight -- measured)
+                f32x4 ring[PF], vring[2];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ring[u] = bload4(Ar, lane16, (u >= jlo && u <= i) ? (rowbase + u) * 1024 : OOB);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool vok = have_next && u >= r_next && u < i;
+                    vring[u] = BACK ? bload4(Vsr, lane16, vok ? (u - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + u - r_next) * 1024 : OOB);
+                }
 #pragma unroll
                 for (int j = 0; j < BAND_MAXNT; ++j) {
-                    if (j >= jlo && j <= i) {                                               // uniform
-                        f32x4 a = a_nx;
-                        const f32x4 vnj = vn_nx;
-                        a_nx = bload4(Ar, lane16, (j + 1 <= i) ? (rowbase + j + 1) * 1024 : OOB);
-                        vn_nx = bload4(Vr, lane16, (have_next && j + 1 >= r_next && j + 1 < i) ? (vb_next + j + 1 - r_next) * 1024 : OOB);
+                    const bool in = j >= jlo && j <= i;                                     // uniform
+                    f32x4 a = ring[j % PF];
+                    const f32x4 vnj = vring[j & 1];
+                    ring[j % PF] = bload4(Ar, lane16, (j + PF >= jlo && j + PF <= i) ? (rowbase + j + PF) * 1024 : OOB);
+                    {
+                        const bool vok = have_next && j + 2 >= r_next && j + 2 < i;
+                        vring[j & 1] = BACK ? bload4(Vsr, lane16, vok ? (j + 2 - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + j + 2 - r_next) * 1024 : OOB);
+                    }
+                    if (in) {
                         if (upd) {
-                            a = xty(nvt, ld4(L.Ys + (16 * j + c16) * LDP + g4), a);
-                            if (j >= r_prev) a = xty(nyt, ld4(L.Vs + (16 * (j - r_prev) + c16) * LDP + g4), a);
-                            bstore4(Ar, a, lane16, (rowbase + j) * 1024);
+                            if constexpr (BACK) {
+                                a *= kap;                                                   // the products below come in units of sV sY
+                                a = xtyh(nvt, ld4(L.Ys + (16 * j + c16) * LDP + g4), a);
+                                if (j >= r_prev) a = xtyh(nyt, ld4(L.Vs + (16 * (j - r_prev) + c16) * LDP + g4), a);
+                                a *= ikap;
+                            } else {
+                                // (two independent accumulator chains of four MFMAs instead of one of eight)
+                                a = xty(nvt, ld4(L.Ys + (16 * j + c16) * LDP + g4), a);
+                                if (j >= r_prev) a += xty0(nyt, ld4(L.Vs + (16 * (j - r_prev) + c16) * LDP + g4));
+                            }
                         }
-                        if (xf) part[j] = xty(vni, a, part[j]);                             // V'_i^T A_ij -> Xt'_j
+                        if (xf) {                                                           // V'_i^T A_ij -> Xt'_j
+                            if constexpr (BACK) part[j] = xtyh(vnis, split_h2(a, sA), part[j]);
+                            else part[j] = xty(vni, a, part[j]);
+                        }
                         if (have_next && j >= r_next && j < i) {
                             // Xt'_i += V'_j^T A_ij^T: the tile transposed through the wave's scratch
+                            // (no fence: the LDS serves a wave's instructions in order, and a release fence would also drain the tiles in flight -- vmcnt(0) on
+                            //  every tile, measured as one memory latency per tile; the two index patterns may alias, so the compiler keeps their order)
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
                             for (int q = 0; q < 4; ++q) L.Tsc[c16 * TSC_LD + g4 + q] = a[q];
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                             f32x4 at;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) at[q] = L.Tsc[(g4 + q) * TSC_LD + c16];
-                            xo = xty(vnj, at, xo);
+                            if constexpr (BACK) xo = xtyh(vnj, split_h2(at, sA), xo);
+                            else xo = xty(vnj, at, xo);
                         }
                         if (j == i) part[j] += xo;
                     }
-                    __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from hoisting the next tiles' operand loads: 27 unrolled bodies)
+                    bstore4(Ar, a, lane16, (in && upd) ? (rowbase + j) * 1024 : OOB);
                 }
             }
         }
         __syncthreads();
         BCLK(1);
         if (have_next) {
+            if constexpr (BACK) {
+                if (want_m) {
+                    const float un = isV * isA;                                             // the accumulators are in units of sV sA
+#pragma unroll
+                    for (int j = 0; j < BAND_MAXNT; ++j) part[j] *= un;
+                }
+            }
             // ---- the waves' partials meet in LDS in a fixed order: X' (over the dead Y), V'^T V', V'^T U ----
             for (int r = 0; r < 4; ++r) {
                 if (wave == r) {
@@ -478,14 +557,42 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                 const f32x4 tmp = xty0(s, ThT);                   // S Th^T
                 f32x4 hwm = xty0(ThT, tmp);                       // Th S Th^T
                 hwm *= -0.5f;
+                float ymax = 0.f;
                 for (int j = (BACK ? 0 : r_next) + wave; j < NT; j += 4) {
                     float* xp = L.Ys + (16 * j + c16) * LDP + g4;
                     f32x4 y = xty0(ThT, ld4(xp));
                     if (j >= r_next) y = xty(hwm, ld4(L.Vs + (16 * (j - r_next) + c16) * LDP + g4), y);
                     st4(xp, y);
+                    if constexpr (BACK) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+                }
+                if constexpr (BACK) {
+                    ymax = wave_reduce_dpp<true>(ymax);
+                    if (lane == 0) L.red[wave] = ymax;
                 }
             }
             __syncthreads();
+            if constexpr (BACK) {
+                if (want_m) {
+                    // ---- V' and Y' become split pairs in place (Y by its own maximum), V' also as split accumulator-layout tiles in the workspace ----
+                    const float ym = fmaxf(fmaxf(L.red[0], L.red[1]), fmaxf(L.red[2], L.red[3]));
+                    sY = 1.0f; isY = 1.0f;
+                    if (ym > 0.f && ym < 1e30f) sY = scale_for(ym, isY);
+                    for (int j = wave; j < NT; j += 4) {
+                        float* xp = L.Ys + (16 * j + c16) * LDP + g4;
+                        st4(xp, split_h2(ld4(xp), sY));
+                    }
+                    for (int i2 = wave; i2 < mtn; i2 += 4) {
+                        float* vp = L.Vs + (16 * i2 + c16) * LDP + g4;
+                        st4(vp, split_h2(ld4(vp), sV));
+                    }
+                    if (it + 1 < npan) {                                                    // the panel after the next: its tiles split, for the next pass' products
+                        const int vb2 = band_voff(NT, kn - 1);
+                        for (int i2 = wave; i2 < mtn + 1; i2 += 4)
+                            bstore4(Vsr, split_h2(ld4(Vg + (size_t)(vb2 + i2) * 256 + lane * 4), sV), lane16, i2 * 1024);
+                    }
+                    __syncthreads();
+                }
+            }
             BCLK(5);
         }
     }
@@ -560,21 +667,31 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
             float qp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // per class column: (2r - E a~ - mu a~).a~,  a~.E a~,  a~.a~,  sum a~
             for (int i = wave; i < NT; i += 4) {
                 f32x4 ea[2] = {ZERO4, ZERO4};
-#pragma unroll 4
-                for (int j = 0; j < NT; ++j) {
-                    // tile (j, i) of E in the accumulator layout: element [4g + q][c] = E[16j + 4g + q][16i + c] = E[16i + c][16j + 4g + q]
+                // tile (j, i) of E in the accumulator layout: element [4g + q][c] = E[16j + 4g + q][16i + c] = E[16i + c][16j + 4g + q]; three tiles in flight
+                auto etile = [&](const int j) {
                     const int row = 16 * i + c16, col = 16 * j + g4;
                     f32x4 e;
                     if (vec_ok) {
-                        e = bload4(Er, (row < N && col < N) ? (row * N + col) * 4 : OOB, 0);
+                        e = bload4(Er, (j < NT && row < N && col < N) ? (row * N + col) * 4 : OOB, 0);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
+                            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (j < NT && row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
                     }
+                    return e;
+                };
+                f32x4 e0 = etile(0), e1 = etile(1), e2 = etile(2);
+                for (int j = 0; j < NT; j += 3) {
+                    const f32x4 c0 = e0, c1 = e1, c2 = e2;
+                    e0 = etile(j + 3); e1 = etile(j + 4); e2 = etile(j + 5);
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        if (p < CP) ea[p] = xty(e, ld4(Ut + ((size_t)j * CP + p) * 256 + lane * 4), ea[p]);
+                    for (int p = 0; p < 2; ++p) {
+                        if (p < CP) {
+                            ea[p] = xty(c0, ld4(Ut + ((size_t)j * CP + p) * 256 + lane * 4), ea[p]);
+                            if (j + 1 < NT) ea[p] = xty(c1, ld4(Ut + ((size_t)(j + 1) * CP + p) * 256 + lane * 4), ea[p]);
+                            if (j + 2 < NT) ea[p] = xty(c2, ld4(Ut + ((size_t)(j + 2) * CP + p) * 256 + lane * 4), ea[p]);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -672,14 +789,17 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     const bool col0 = c16 == 0;
 
     f32x4 ngt_prev = ZERO4, yprev = ZERO4, st_prev = ZERO4;
-    float lsum = 0.f;
+    float lsum = 0.f, trb = 0.f;
     int fail_at = 0;
     for (int j = 0; j < NT; ++j) {
         f32x4 P = ld4(At + (size_t)lslot(j, j) * 256 + lane * 4);
         float dmax = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (g4 + q == c16) P[q] = (16 * j + c16 < N) ? P[q] + mu : 1.0f;
+            if (g4 + q == c16) {
+                trb += (16 * j + c16 < N) ? P[q] : 0.f;                                   // trace B = trace E
+                P[q] = (16 * j + c16 < N) ? P[q] + mu : 1.0f;
+            }
         }
         if (j > 0) P = xty(ngt_prev, st_prev, P);                                        // - G_{j-1} S_{j-1}^T
 #pragma unroll
@@ -728,7 +848,7 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     float* Am = ep + G.oAm;
     float* AmT = ep + G.oAmT;
     f32x4 a_next = ZERO4, zd_next = ZERO4;
-    float trz = 0.f;
+    float trz = 0.f, aa = 0.f;
     for (int j = NT - 1; j >= 0; --j) {
         const f32x4 Pinv = ld4(Pg + (size_t)j * 256 + lane * 4);
         const f32x4 z = col0 ? ld4(Zv + j * 16 + g4) : ZERO4;
@@ -746,7 +866,7 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
             st4(Am + ((size_t)j * CP + pu) * 256 + (4 * g4 + cu) * 4, a);
             float* at = AmT + ((size_t)pu * NT + j) * 256 + 64 * (cu >> 2) + (cu & 3);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) at[4 * (g4 + q)] = a[q];
+            for (int q = 0; q < 4; ++q) { at[4 * (g4 + q)] = a[q]; aa += a[q] * a[q]; }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) trz += (g4 + q == c16 && 16 * j + c16 < N) ? zd[q] : 0.f;
@@ -755,6 +875,12 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     }
     lsum = wave_reduce_dpp<false>(lsum);
     trz = wave_reduce_dpp<false>(trz);
+    aa = wave_reduce_dpp<false>(aa);
+    trb = wave_reduce_dpp<false>(trb);
+    // The reduction's backward error (a few eps |E|) is amplified by sv |E| / noise in alpha and W (the quadratic form is repaired from the residual, the log-determinant
+    // averages it out).  A class whose a-priori condition bound 1 + sv trace(E) / noise exceeds BAND_KAPPA_MAX hands its episode to the generic kernel's fix-up launch
+    // (exact fp32 on the matrix itself, jitter ladder included) -- the reference's frozen noise 0.1 and unit-norm rows stay below it for outputscales up to ~ 4.5 at N = 420.
+    if (fail_at == 0 && !(1.0f + sv * trb / nz <= BAND_KAPPA_MAX)) fail_at = -1;
     if (lane == 0) {
         const size_t bc = (size_t)b * C + cls;
         const float qnan = __int_as_float(0x7fc00000);
@@ -766,6 +892,7 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
         // the hyper-gradients are finished by the back kernel from alpha in the original coordinates (alpha^T E alpha, alpha^T alpha against the ORIGINAL E);
         // tr (B + mu)^-1 travels there in dnoise[]
         if (t.grad) t.a.dnoise[bc] = ok ? trz : qnan;
+        ep[G.oSc + cls] = aa;
     }
 }
 
@@ -902,7 +1029,15 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void band_chain_kernel(BandArgs t
 
 bool dkt_mll_band_supports(int N, unsigned flags, int C) {
     if (flags & (DKT_MLL_WANT_CHOL | DKT_MLL_E_PER_CLASS | DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_BLOCKED | DKT_MLL_FORCE_F32MFMA | DKT_MLL_FORCE_TILED)) return false;
-    return N >= 128 && (N + 15) / 16 <= BAND_MAXNT && C >= 8 && C <= 32;
+    return N >= 128 && (N + 15) / 16 <= BAND_MAXNT && C >= 2 && C <= 32;
+}
+
+// The default dispatch: from 12 classes and 192 episodes per call (tools/band_crossover.py, profiles/r06/band_crossover.log: the reduction costs about the same for 8 and for
+// 32 classes, the tile arrays grow with C; below 192 episodes the per-episode chain of 2 x 25 panels does not fill the GPU and the tile arrays' 20 x more workgroups win).
+bool dkt_mll_band_applies(int B, int C, int N, unsigned flags) {
+    if (!dkt_mll_band_supports(N, flags, C)) return false;
+    if (flags & DKT_MLL_FORCE_BAND) return true;
+    return C >= 12 && B >= 192;
 }
 
 size_t dkt_mll_band_workspace_bytes(int B, int C, int N) {

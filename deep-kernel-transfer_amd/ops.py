@@ -34,6 +34,7 @@ MLL_FORCE_BLOCKED = 16
 MLL_FORCE_F32MFMA = 32
 MLL_E_PER_CLASS = 64
 MLL_FORCE_TILED = 128
+MLL_FORCE_BAND = 256
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -167,7 +168,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
 def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
         jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False,
-        force_blocked: bool = False, force_f32mfma: bool = False, force_tiled: bool = False) -> dict:
+        force_blocked: bool = False, force_f32mfma: bool = False, force_tiled: bool = False, force_band: bool = False) -> dict:
     """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N] (one base matrix shared by the class models) or
     [B,C,N,N] (one per class model: DKT_MLL_E_PER_CLASS -- then w is [B,C,N,N] too); y:[C,N] (shared) or [B,C,N].
     force_*: the parity-tested twins of the default kernels (DKT_MLL_FORCE_* of include/dkt_abi.h)."""
@@ -198,7 +199,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
     flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
-             (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0) | (MLL_FORCE_TILED if force_tiled else 0))
+             (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0) | (MLL_FORCE_TILED if force_tiled else 0) | (MLL_FORCE_BAND if force_band else 0))
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL

@@ -32,8 +32,8 @@ extern "C" {
                              3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32; \
                              4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
                                           + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_lowrank_* (linear kernels in feature space, D <= 64 < N); \
-                             5 (round 6): shared-E calls with 8 <= C <= 32 classes and 128 <= N <= 432 take ONE band reduction per episode (dkt_mll_band.hip); \
-                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin) */
+                             5 (round 6): shared-E calls with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes take ONE band reduction per episode (dkt_mll_band.hip); \
+                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND */
 
 /* status codes */
 #define DKT_OK 0
@@ -68,7 +68,9 @@ extern "C" {
 #define DKT_MLL_FORCE_F32MFMA 32u /* exact-fp32 arithmetic instead of the f16-split kernels (N <= 127; no range contract, see below).  The product library serves it
                                      with its generic exact-fp32 kernel; the exact-fp32 MFMA twin of the split kernels lives in the twins library */
 #define DKT_MLL_FORCE_TILED 128u /* validation aid (ABI 5): the tile-array kernels (one factorisation per class matrix) instead of the shared band reduction of
-                                    dkt_mll_band.hip, which is the default for a shared base matrix with 8 <= C <= 32 classes and 128 <= N <= 432 */
+                                    dkt_mll_band.hip, which is the default for a shared base matrix with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes per call */
+#define DKT_MLL_FORCE_BAND 256u  /* validation / measurement aid (ABI 5): the band reduction wherever it is defined (shared base matrix, 128 <= N <= 432, 2 <= C <= 32), also
+                                    outside the window in which it is the default */
 #define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */
 
 int dkt_abi_version(void);

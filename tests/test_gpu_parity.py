@@ -1071,17 +1071,17 @@ def _band_problem(b, n, c, d, corr, seed):
 
 
 @pytest.mark.parametrize("n,c,d,corr", [(128, 8, 48, False), (150, 10, 64, True), (257, 16, 64, False), (320, 20, 128, False), (420, 20, 512, True),
-                                        (431, 9, 64, True), (447, 32, 96, False)])
+                                        (431, 9, 64, True), (432, 32, 96, False), (400, 2, 64, False)])
 def test_mll_band_reduction_vs_float64_and_tile_array_twin(cuda, n, c, d, corr):
-    """The default of a shared-E call with 8 <= C <= 31 and 128 <= N <= 447: one orthogonal reduction of E to block-tridiagonal form per episode, every class a
+    """The band reduction (the default of a shared-E call with 12 <= C <= 32, 128 <= N <= 432 and >= 192 episodes; named here through force_band): one orthogonal reduction of E to block-tridiagonal form per episode, every class a
     block LDL^T of B + mu_c I (methods/DKT.py:148-149, 161-163 at the 20-way shapes of train.py:132-133).  Against float64 on every episode and against the tile-array
     twin (force_tiled: one factorisation per class matrix); with and without gradients; W bitwise symmetric.  The tolerances are the file's (1e-4 / 1e-3) on
     uncorrelated AND on class-correlated features, where the reduction's backward error would cost 1e-4 on the quadratic form without the residual step."""
     b = 3
     e, y, sv, mean, noise, cw = _band_problem(b, n, c, d, corr, 100 * n + c)
     args = [dev_t(x, cuda) for x in (e, y, sv, mean, noise)]
-    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
-    o_fwd = ops.mll(*args, want_grad=False)
+    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_band=True)          # (three episodes: below the default window of >= 192 episodes)
+    o_fwd = ops.mll(*args, want_grad=False, force_band=True)
     twin = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_tiled=True)
     assert int(o["info"].abs().max().item()) == 0 and float(o["jitter"].abs().max().item()) == 0.0
     assert torch.equal(o["w"], o["w"].transpose(1, 2))
@@ -1111,7 +1111,7 @@ def test_mll_band_reduction_vs_float64_and_tile_array_twin(cuda, n, c, d, corr):
     for key in ("dsv", "dmean", "dnoise"):
         assert rel_l2(o[key].cpu().numpy(), twin[key].cpu().numpy()) < 2e-3, key
     # bitwise repeatable
-    o2 = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda))
+    o2 = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_band=True)
     for key in ("logp", "alpha", "w", "dsv", "dmean", "dnoise"):
         assert torch.equal(o[key], o2[key]), key
 
@@ -1128,11 +1128,43 @@ def test_mll_band_reduction_failure_goes_through_the_jitter_ladder(cuda):
     noise[3] = 0.0
     args = [dev_t(x, cuda) for x in (e, y, np.ones(c), np.zeros(c), noise)]
     cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
-    o = ops.mll(*args, want_grad=True, cls_weight=cw)
+    o = ops.mll(*args, want_grad=True, cls_weight=cw, force_band=True)
     twin = ops.mll(*args, want_grad=True, cls_weight=cw, force_tiled=True)
     assert float(o["jitter"][:, 3].min().item()) > 0.0 and float(o["jitter"][:, [0, 1, 2, 4, 5, 6, 7]].abs().max().item()) == 0.0
     for key in ("jitter", "info", "logp", "alpha", "w", "dsv", "dmean", "dnoise"):
         assert torch.equal(o[key], twin[key]), key
+
+
+def test_mll_band_reduction_dispatch_window_and_condition_guard(cuda):
+    """(i) The default takes the band reduction from 12 classes and 192 episodes per call and the tile-array kernels below (bitwise equal to the named paths).
+    (ii) A class whose a-priori condition bound 1 + sv trace(E) / noise exceeds 2e4 (here: noise 1e-3 on unit rows) is not trusted to the reduction -- its episode is
+    redone by the generic kernel on the matrix itself, so every output of the flagged episodes equals the generic twin's bit for bit and holds the file's tolerances."""
+    n, c = 128, 12
+    e, y, sv, mean, noise, cw = _band_problem(192, n, c, 32, False, 77)
+    args = [dev_t(x, cuda) for x in (e, y, sv, mean, noise)]
+    cwt = dev_t(cw, cuda)
+    dflt = ops.mll(*args, want_grad=True, cls_weight=cwt)
+    band = ops.mll(*args, want_grad=True, cls_weight=cwt, force_band=True)
+    args191 = [args[0][:191].contiguous()] + args[1:]
+    dflt191 = ops.mll(*args191, want_grad=True, cls_weight=cwt)
+    tiled191 = ops.mll(*args191, want_grad=True, cls_weight=cwt, force_tiled=True)
+    for key in ("logp", "alpha", "w", "dsv", "dmean", "dnoise"):
+        assert torch.equal(dflt[key], band[key]), key
+        assert torch.equal(dflt191[key], tiled191[key]), key
+    assert not torch.equal(band["w"][:191], tiled191["w"])                      # (two different algorithms)
+    # (ii)
+    noise2 = noise.copy()
+    noise2[5] = 1e-3
+    args2 = [dev_t(x, cuda) for x in (e[:4], y, sv, mean, noise2)]
+    o = ops.mll(*args2, want_grad=True, cls_weight=cwt, force_band=True)
+    gen = ops.mll(*args2, want_grad=True, cls_weight=cwt, force_generic=True)
+    assert int(o["info"].abs().max().item()) == 0
+    for key in ("logp", "alpha", "w", "dsv", "dmean", "dnoise", "jitter"):
+        assert torch.equal(o[key], gen[key]), key
+    kk = sv[5] * e[0] + noise2[5] * np.eye(n)
+    r = y[5] - mean[5]
+    logp = -0.5 * r @ np.linalg.solve(kk, r) - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+    assert abs(o["logp"][0, 5].item() - logp) < MLL_RTOL * abs(logp)
 
 
 @pytest.mark.parametrize("b,n,d", [(72, 190, 512), (72, 320, 512), (72, 420, 512), (72, 431, 36), (72, 290, 64), (72, 447, 100), (136, 190, 512), (130, 250, 128)])
