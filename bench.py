@@ -51,7 +51,7 @@ CONFIGS = {
     "cfg2": (5, 5, 16, 1600, "CUB 5-way 5-shot, Conv4 features (headline)", 116288),
     "cfg3": (5, 1, 16, 512, "miniImagenet 5-way 1-shot, ResNet10 features", 4906816),
     # 20-way: N = 420 is what train_loop builds (20 x (5 + 16)); BASELINE.json quotes a 320 x 320 Gram
-    "cfg4": (20, 5, 16, 512, "miniImagenet 20-way 5-shot, ResNet18 features (N = 420: blocked large-N MLL path)", 11177536),
+    "cfg4": (20, 5, 16, 512, "miniImagenet 20-way 5-shot, ResNet18 features (N = 420: band-reduction MLL path from 192 episodes per call)", 11177536),
     "cfg4_n320": (20, 1, 15, 512, "20-way, N = 320 (the Gram size BASELINE.json quotes)", 11177536),
 }
 
@@ -606,7 +606,34 @@ def _kernel_report(cfg, m, unit_rows, traffic):
                          note="EXECUTED v_mfma_f32_16x16x16_f16 flops (%d tile products x 3 plane products per class matrix) / dense f16 peak; the kernel is "
                               "bound by VALU issue + the dependency chain of the diagonal-tile sweeps, not by this pipe (DESIGN.md 4.2)" % prods)
             other = dict(mat, note="algorithmic fp32-equivalent flops / fp32 MFMA peak (the pipe rounds 1-2 used; kept for comparison across rounds)")
-        if name == "dkt_mll_f32" and n + 1 > 128:
+        band = name == "dkt_mll_f32" and n >= 128 and (n + 15) // 16 <= 27 and 12 <= c <= 32 and b >= 192 and st["kernel"] in ("bncossim", "cossim", "linear")
+        if band:
+            # band reduction (round 6, csrc/dkt_mll_band.hip): ONE orthogonal reduction of E per episode (fp32 MFMA: Householder panels + fused two-sided passes over the
+            # lower block triangle), C block-LDL^T chains + column chains (fp32 MFMA), one similarity transform back (2-way f16 splits).  Executed MFMA work per episode:
+            #   forward   passes it = 0 .. NT-2 over the stored tiles (i >= j >= it + 1): 16 fp32 instructions per off-diagonal tile (8 update + 4 + 4 for X'), 12 per diagonal
+            #   back      rows >= the panel's first row, every column: 12 f16 instructions (6 + 3 + 3) per off-diagonal tile
+            #   chain     C nt (nt + 1) / 2 tile products (4 fp32 instructions), class kernel ~ 14 products per block and class
+            # against the fp32 matrix peak resp. the dense f16 peak.  The kernels are bound by neither pipe nor by HBM: by the per-episode chain of 2 x (NT - 2) panels with
+            # two workgroups per CU (phase clocks: profiles/r06/band_phase_clocks.log) -- `fabric_gbs` / the executed fractions say how far from each roof.
+            nt = (n + 15) // 16
+            fwd_tiles = sum((nt - jl) * (nt - jl + 1) // 2 for jl in range(1, nt))
+            back_tiles = sum(sum(i + 1 for i in range(r, nt)) for r in range(1, nt - 1))
+            ex32 = (fwd_tiles * 16 + c * (nt * (nt + 1) // 2 * 4 + nt * 14 * 4)) * 2048.0 * b / k["ms"] / 1e9
+            ex16 = back_tiles * 12 * 8192.0 * b / k["ms"] / 1e9
+            real = (fwd_tiles * 4 + back_tiles * 4 + c * (nt * (nt + 1) // 2 + nt * 14)) * 8192.0          # tile products x 2 x 16^3
+            first = dict(bound="mfma", achieved=round(ex32, 1), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ex32 / MFMA_F32_PEAK_TFLOPS, 4),
+                         note="band reduction: EXECUTED v_mfma_f32_16x16x4_f32 flops (forward passes, class + column chains) / fp32 matrix peak; the back transform's f16 "
+                              "split products are in executed_f16; the path does %.1f x fewer flops than the C factorisations + inverses `algorithmic_flops_per_launch` "
+                              "counts (the reference algorithm)" % (alg[name]["flops"] / real))
+            first["executed_f16_tflops"] = round(ex16, 1)
+            first["executed_f16_frac"] = round(ex16 / MFMA_F16_PEAK_TFLOPS, 4)
+            first["path"] = "band"
+            other = dict(mat, note="algorithmic fp32 flops of the REFERENCE algorithm (C factorisations + inverses) per second / fp32 MFMA peak -- an equivalent rate, "
+                                    "not executed work (kept for comparison with the tile-array rounds)")
+            if tr:
+                first["fabric_gbs"] = round(tr / k["ms"] / 1e6, 1)
+                first["fabric_frac"] = round(tr / k["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+        if name == "dkt_mll_f32" and n + 1 > 128 and not band:
             # tile-array path (127 < N <= 447): since round 4 the left-looking K loops of the factorisation / inverse and the whole K^-1 product run as
             # f16-split tile products (3 v_mfma_f32_16x16x16_f16 each), the in-block panels / updates and the diagonal sweeps in fp32.  The kernels are
             # bound by their tile streams (traffic-only builds: profiles/r04/v0_tiled_traffic_ceiling.txt), not by a matrix pipe: `fabric_gbs` = PMC
@@ -670,7 +697,7 @@ def _emit(real_fd, obj):
 
 
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
-              "algorithmic_flops_per_launch", "avg_launch_ms", "episodes_per_launch", "fabric_gbs", "fabric_frac", "executed_tflops", "executed_frac")
+              "algorithmic_flops_per_launch", "avg_launch_ms", "episodes_per_launch", "fabric_gbs", "fabric_frac", "executed_tflops", "executed_frac", "executed_f16_tflops", "executed_f16_frac", "path")
 
 
 def _compact_roof(r):
@@ -823,6 +850,21 @@ def run(args):
         out["other_configs"] = others
         del m
         torch.cuda.empty_cache()
+        # SURVEY 8d / BASELINE.md 3: the headline config at B = 1 (what the reference's own loop issues, methods/DKT.py:117), 64, 1024 episodes per step -- the GP path
+        # only (features resident), forward + backward, under the same clock; launches per step = ABI calls of the step
+        sweep = {}
+        for bs in (1, 64, 1024):
+            ss = 50 if bs <= 64 else 20
+            ms_ = _measure(args.config, bs, args, dev, rank, world, lambda st_: None, UNIT_ROWS, 3, 0.0, ss)
+            sweep[str(bs)] = {"value": round(bs * ss / ms_["dt"], 1), "ms_per_step": round(1e3 * ms_["dt"] / ss, 4),
+                              "launches_per_step": round(sum(cnt for cnt, _ in ms_["ktimes"].values()) / (ss * len(ms_["blocks"])), 2), "valid": ms_["valid"]}
+            del ms_
+        out["batch_sweep"] = {"config": args.config, "unit": "episodes/s", "by_episodes_per_step": sweep}
+        torch.cuda.empty_cache()
+        # the dtype question closed by a number: the same headline step with EXACT fp32 arithmetic everywhere -- Gram forward / backward without the f16 split
+        # (DKT_GRAM_SPLIT=0) and the fp32-MFMA marginal likelihood (DKT_MLL_F32MFMA=1) -- from the twins library (same sources, -DDKT_TWINS; a subprocess: the
+        # library reads its switches once)
+        out["exact_fp32"] = _exact_fp32_run(args)
         out["other_paths_cfg2"] = _aux_paths(dev)
         torch.cuda.empty_cache()
         out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 3)
@@ -860,7 +902,7 @@ def run(args):
                                         "ms_per_step": round(1e3 * dt_t, 4),
                                         "workload": "N_support=%d, N_query=%d, D=%d, C=%d: Gram + MLL (no grad) + cross Gram + posterior mean/arg-max"
                                                     % (c * s, c * q, d, c)}
-        if world == 1 and not args.no_cpu_baseline and args.config != "cfg0":
+        if world == 1 and (not args.no_cpu_baseline or args.oracle_check) and args.config != "cfg0":
             import numpy as np
             from oracle import dkt_oracle as O
             nchk = 32                                         # marginal log-likelihood of 32 bench episodes against the float64 oracle
@@ -873,6 +915,7 @@ def run(args):
                 rel = max(rel, float(np.abs((logp[i].cpu().numpy() - ref["logp"]) / ref["logp"]).max()))
             out["mll_rel_err"] = rel
             out["mll_rel_err_episodes"] = nchk
+        if world == 1 and not args.no_cpu_baseline and args.config != "cfg0":
             zs_cpu = z[:32].detach().cpu()
             res = cpu_baseline(zs_cpu, c, raw_s.detach().cpu(), mean.detach().cpu())
             one = res["1"]["episodes_per_s"]
@@ -912,6 +955,21 @@ def run(args):
         _emit(real_stdout, _line_of(out))
 
 
+def _exact_fp32_run(args):
+    """`bench.py --config <headline> --no-other-configs --no-cpu-baseline --no-test-time` in a child with DKT_TWINS=1 DKT_GRAM_SPLIT=0 DKT_MLL_F32MFMA=1: value, ms per step,
+    per-kernel ms and the log-likelihood error of the exact-fp32 twin kernels on the same step."""
+    import subprocess
+    env = dict(os.environ, DKT_TWINS="1", DKT_GRAM_SPLIT="0", DKT_MLL_F32MFMA="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "10", "--warmup", "2", "--no-other-configs", "--no-cpu-baseline", "--no-test-time", "--oracle-check"]
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "kernels_ms": rec.get("kernels_ms"), "mll_rel_err": rec.get("mll_rel_err"), "valid": rec.get("valid"),
+                "library": "libdkt_twins.so", "switches": "DKT_GRAM_SPLIT=0 DKT_MLL_F32MFMA=1"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+
+
 def _line_of(out):
     """The ONE line of the contract (< 8 KB): headline + roofline + roofline_gram_build + cpu_baseline, and one compact record per other config /
     path.  The full per-kernel detail is the `detail` file."""
@@ -933,7 +991,7 @@ def _line_of(out):
                          for name, o in out[key].items()}
     if "test_time_forward" in out:
         line["test_time_forward"] = {k: out["test_time_forward"][k] for k in ("value", "ms_per_step", "episodes_per_step")}
-    for k in ("mll_rel_err", "mll_rel_err_episodes", "speedup_vs_cpu", "speedup_vs_cpu_1thread", "gpytorch_reference", "rccl_selftest", "detail"):
+    for k in ("mll_rel_err", "mll_rel_err_episodes", "speedup_vs_cpu", "speedup_vs_cpu_1thread", "gpytorch_reference", "rccl_selftest", "detail", "batch_sweep", "exact_fp32"):
         if k in out:
             line[k] = out[k]
     if "cpu_baseline" in out:
@@ -1048,6 +1106,7 @@ def main():
                     help="episodes per step per GPU (SURVEY.md 8d: B in {1, 64, 1024, 8192}); default 8192, 1024 for the 20-way shapes")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--oracle-check", action="store_true", help="with --no-cpu-baseline: still check 32 bench episodes against the float64 oracle (mll_rel_err)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="only the --config workload (default: the headline config in full, then every other BASELINE config for 3 "
                          "short blocks each, reported under `other_configs`)")

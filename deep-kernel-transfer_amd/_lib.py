@@ -286,6 +286,11 @@ def device_disassembly(path: str = None) -> list:
     return _disasm_cache[key]
 
 
+# what the two disassembly audits below managed to parse (positive controls for their tests: a toolchain that prints branch operands or `// ADDR:` comments
+# differently would otherwise make them pass without checking anything)
+AUDIT_STATS = {}
+
+
 def spill_reloads_in_streaming_loops(path: str = None) -> dict:
     """{kernel: number of scratch reloads} for every kernel that reloads a spilled register INSIDE a loop that also issues global / buffer loads.  Scratch traffic
     shares the in-order memory counter, and a reload's wait is `vmcnt(0)`: such a reload drains whatever the loop prefetched, on every trip (round 5: the unit-row Gram
@@ -294,6 +299,7 @@ def spill_reloads_in_streaming_loops(path: str = None) -> dict:
     rx_addr = re.compile(r"//\s*([0-9A-Fa-f]+):")
     rx_br = re.compile(r"^\s*s_c?branch\w*\s+(\d+)")
     out = {}
+    AUDIT_STATS["branches"] = AUDIT_STATS["backward_branches"] = AUDIT_STATS["kernels"] = 0
     for text in device_disassembly(path):
         kernel, insns = None, []
 
@@ -306,11 +312,13 @@ def spill_reloads_in_streaming_loops(path: str = None) -> dict:
                 m = rx_br.match(t)
                 if not m:
                     continue
+                AUDIT_STATS["branches"] += 1
                 off = int(m.group(1))
                 off = off - 65536 if off >= 32768 else off
                 tgt = a + 4 + 4 * off
                 if tgt >= a:
                     continue
+                AUDIT_STATS["backward_branches"] += 1
                 body = [tt for aa, tt in insns if tgt <= aa <= a]
                 nsc = sum("scratch_load" in tt for tt in body)
                 if nsc and any(("buffer_load" in tt) or ("global_load" in tt) for tt in body):
@@ -322,6 +330,7 @@ def spill_reloads_in_streaming_loops(path: str = None) -> dict:
             if line.endswith(">:"):
                 flush()
                 kernel, insns = line.split("<")[-1][:-2], []
+                AUDIT_STATS["kernels"] += 1
                 continue
             m = rx_addr.search(line)
             if m and kernel is not None:
@@ -336,9 +345,11 @@ def unprotected_wide_buffer_stores(path: str = None) -> list:
     literal soffset); on gfx950 the store then sends whatever the VALU wrote (round 5: dX of a software-pipelined fused backward came out as run-to-run
     garbage).  The kernels keep the scalar offset in the VGPR offset instead (bstore4, dkt_mfma_tiles.h); this is the audit that they all do."""
     import re
-    rx_store = re.compile(r"^\s*buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi)\b")
-    rx_dst = re.compile(r"^\s*(v_\w+)\s+(v\[(\d+):(\d+)\]|v(\d+))\b")
+    rx_store = re.compile(r"^\s*buffer_store_dwordx[34]\s+([va])\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi)\b")
+    rx_dst = re.compile(r"^\s*(v_\w+)\s+(([va])\[(\d+):(\d+)\]|([va])(\d+))\b")
     hits = []
+    AUDIT_STATS["wide_stores_any"] = AUDIT_STATS["wide_stores_parsed"] = 0
+    rx_any = re.compile(r"^\s*buffer_store_dwordx[34]\s+[va]\[(\d+):(\d+)\]")          # (data in VGPRs or in accumulation registers)
     for text in device_disassembly(path):
         kernel, pending = "?", None
         for line in text.splitlines():
@@ -351,13 +362,16 @@ def unprotected_wide_buffer_stores(path: str = None) -> list:
             if pending is not None:
                 m = rx_dst.match(text_)
                 if m and not m.group(1).startswith(("v_cmp", "v_mfma", "v_readlane", "v_readfirstlane")):
-                    lo, hi = (int(m.group(3)), int(m.group(4))) if m.group(3) else (int(m.group(5)), int(m.group(5)))
-                    if lo <= pending[1] and hi >= pending[0]:
+                    cls = m.group(3) or m.group(6)
+                    lo, hi = (int(m.group(4)), int(m.group(5))) if m.group(3) else (int(m.group(7)), int(m.group(7)))
+                    if cls == pending[3] and lo <= pending[1] and hi >= pending[0]:
                         hits.append((kernel, pending[2].strip(), text_.strip()))
                 pending = None
             m = rx_store.match(text_)
+            AUDIT_STATS["wide_stores_any"] += ("buffer_store_dwordx3" in text_) or ("buffer_store_dwordx4" in text_)
+            AUDIT_STATS["wide_stores_parsed"] += rx_any.match(text_) is not None          # (the operand syntax the audit's regular expressions expect)
             if m:
-                pending = (int(m.group(1)), int(m.group(2)), text_)
+                pending = (int(m.group(2)), int(m.group(3)), text_, m.group(1))
     return hits
 
 

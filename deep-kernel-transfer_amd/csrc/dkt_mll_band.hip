@@ -388,12 +388,12 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                 // Tiles and the next panel's V tiles arrive through rings of PF / 2 registers, refilled PF / 2 tiles ahead.  Every memory instruction of the row
                 // sits OUTSIDE the uniform branches (an absent tile reads / writes an offset the descriptor rejects: no traffic), so the in-order memory counter is
                 // known statically and a tile's wait is vmcnt(2 PF + ...) instead of vmcnt(0); only arithmetic and LDS traffic are conditional.
-                constexpr int PF = BACK ? 4 : 2;                    // (forward: its fp32 products leave no room for more tiles in flight -- measured)
-                f32x4 ring[PF], vring[2];
+                constexpr int PF = BACK ? 4 : 1, VPF = BACK ? 2 : 1;      // (forward: more tiles in flight cost registers -- spills in the QR -- and bought nothing: measured)
+                f32x4 ring[PF], vring[VPF];
 #pragma unroll
                 for (int u = 0; u < PF; ++u) ring[u] = bload4(Ar, lane16, (u >= jlo && u <= i) ? (rowbase + u) * 1024 : OOB);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < VPF; ++u) {
                     const bool vok = have_next && u >= r_next && u < i;
                     vring[u] = BACK ? bload4(Vsr, lane16, vok ? (u - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + u - r_next) * 1024 : OOB);
                 }
@@ -401,11 +401,11 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                 for (int j = 0; j < BAND_MAXNT; ++j) {
                     const bool in = j >= jlo && j <= i;                                     // uniform
                     f32x4 a = ring[j % PF];
-                    const f32x4 vnj = vring[j & 1];
+                    const f32x4 vnj = vring[j % VPF];
                     ring[j % PF] = bload4(Ar, lane16, (j + PF >= jlo && j + PF <= i) ? (rowbase + j + PF) * 1024 : OOB);
                     {
-                        const bool vok = have_next && j + 2 >= r_next && j + 2 < i;
-                        vring[j & 1] = BACK ? bload4(Vsr, lane16, vok ? (j + 2 - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + j + 2 - r_next) * 1024 : OOB);
+                        const bool vok = have_next && j + VPF >= r_next && j + VPF < i;
+                        vring[j % VPF] = BACK ? bload4(Vsr, lane16, vok ? (j + VPF - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + j + VPF - r_next) * 1024 : OOB);
                     }
                     if (in) {
                         if (upd) {

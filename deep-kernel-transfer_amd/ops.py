@@ -120,9 +120,10 @@ _ENV_SWITCHES = _PRODUCT_SWITCHES + _VARIANT_SWITCHES
 _env_seen = {}
 
 
-def _sync_env(lib) -> None:
-    """The library reads its switches once; when a test or an A/B tool changed one inside this process, tell it."""
-    cur = tuple(os.environ.get(k) for k in _ENV_SWITCHES)
+def _sync_env(lib, names=None) -> None:
+    """The library reads its switches once; when a test or an A/B tool changed one inside this process, tell it.  `names`: the switches that can matter for this
+    library (the product reads the 4 product switches only: ~ 4 instead of ~ 30 environment look-ups per call on the launch-bound small-batch paths)."""
+    cur = tuple(os.environ.get(k) for k in (names or _ENV_SWITCHES))
     seen = _env_seen.get(id(lib))
     if cur != seen:
         if seen is not None or any(v is not None for v in cur):
@@ -133,7 +134,12 @@ def _sync_env(lib) -> None:
 def _lib_now(want_twin: bool = False):
     """The library this call goes to: the product, or -- DKT_TWINS=1 and a variant switch set (or `want_twin`: a call that names a validation twin the
     product library serves with its generic kernel, e.g. force_f32mfma) -- the twins build of the same ABI.  DKT_TWINS=force: the twins build for every call."""
-    if os.environ.get("DKT_TWINS") == "force":                # (tests of the twins library's own instantiations)
+    tw = os.environ.get("DKT_TWINS")
+    if tw is None or tw == "0":                               # the product library, no variant switch can apply: one lookup per call, the 4 product switches synced
+        lib = _lib.load()
+        _sync_env(lib, _PRODUCT_SWITCHES)
+        return lib
+    if tw == "force":                                         # (tests of the twins library's own instantiations)
         lib = _lib.load_twins()
     elif os.environ.get("DKT_TWINS") == "1" and (want_twin or os.environ.get("DKT_MLL_F32MFMA") == "1" or any(os.environ.get(k) is not None for k in _VARIANT_SWITCHES)):
         lib = _lib.load_twins()
@@ -302,6 +308,9 @@ def kernel_matrix(a: torch.Tensor, bm: Optional[torch.Tensor], kernel: str, leng
     if kernel in RBF_KINDS:
         return gram(a, bm, KERNEL_RBF, lengthscale)
     if kernel in MATERN_KINDS or kernel in POLY_KINDS:
+        for nm, t in (("lengthscale", lengthscale), ("offset", offset)):
+            if t is not None and t.numel() != 1:           # ONE model: per-class parameters go to kernel_matrix_per_class (a [C] tensor here would silently mean class 0)
+                raise RuntimeError("kernel_matrix: %s must have one element (got %d); use kernel_matrix_per_class for per-class parameters" % (nm, t.numel()))
         return kernel_matrix_per_class(a, bm, kernel, None if lengthscale is None else lengthscale.reshape(-1)[:1],
                                        None if offset is None else offset.reshape(-1)[:1])[:, 0]
     raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
@@ -728,7 +737,10 @@ def _lowrank_forward(z, y, sv_, mean_, noise_in, cw_, jitter0, max_tries, unit_r
     dev = z.device
     lib = _lib_now()
     # the rung of the jitter ladder that lifts the noise floor of the (rank-deficient) N x N matrix above fp32 rounding -- 0 for any sane noise; rows that
-    # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T
+    # went through F.normalize have |z_i|^2 = 1, otherwise one reduction over Z finds the largest diagonal element of Z Z^T.  NOTE: that
+    # maximum is taken over the WHOLE call, so for un-normalised `linear` features with a noise below 2^-22 max K_ii one large-norm row raises the rung of every
+    # episode of the batch (the N x N path and psd_safe_cholesky decide per matrix).  cossim / bncossim (unit rows) and any noise >= 1e-5 are unaffected; the rung is
+    # reported per (episode, class) in `jitter` either way.
     zmax2 = None if unit_rows else z.square().sum(2).amax().reshape(1).contiguous()
     noise_ = torch.empty_like(noise_in)
     pre = torch.empty_like(noise_in)

@@ -83,6 +83,8 @@ def test_no_wide_buffer_store_is_followed_by_a_write_of_its_data_registers():
     L = dkt_amd._lib
     assert len(L.device_code_objects(L.LIB_PATH)) >= len(L.SOURCES)
     assert L.unprotected_wide_buffer_stores(L.LIB_PATH) == []
+    # positive control: the product library's 16-byte buffer stores were seen AND matched the operand syntax the audit expects
+    assert L.AUDIT_STATS["wide_stores_any"] >= 100 and L.AUDIT_STATS["wide_stores_parsed"] == L.AUDIT_STATS["wide_stores_any"], L.AUDIT_STATS
     assert L.unprotected_wide_buffer_stores(L.TWINS_LIB_PATH) == []
     probe = textwrap.dedent("""
         #include <hip/hip_runtime.h>
@@ -117,6 +119,10 @@ def test_spill_reloads_stay_out_of_the_streaming_loops():
     # loop -- one per Householder column of the forward kernel, a few per panel in both -- and none in the unrolled tile loop of the pass (the ISA was read:
     # profiles/r06/INDEX.md); the panel loop "also loads from memory", which is what this audit keys on.
     allowed = (r"mll_h2_kernelILi7E", r"tiled_factor_kernelILi7ELb1ELi3E", r"tiled_invert_kernelILi7ELb1ELb1ELi3E", r"band_sym_kernelILb[01]E")
+    # positive controls: the scanner really parsed branches, backward branches and kernels, and it does find the kernels that are known to reload
+    st = dkt_amd._lib.AUDIT_STATS
+    assert st["kernels"] >= 200 and st["branches"] >= 1000 and st["backward_branches"] >= 200, st
+    assert any(re.search(r"mll_h2_kernelILi7E", k) for k in found) and any(re.search(r"band_sym_kernelILb0E", k) for k in found), sorted(found)
     for k in found:
         assert any(re.search(a, k) for a in allowed), (k, found[k])
     for hot in ("gram_sym_ep_split_kernel", "gram_bwd_ep_f16x2_kernel", "mll_h2e_kernel", "gram_bn_train_f16_kernel", "gram_bn_bwd_ep_kernel", "lowrank_", "gram_small"):

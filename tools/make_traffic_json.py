@@ -37,6 +37,7 @@ KERNEL_TABLE = {
     "tiled_etile_kernel": "dkt_mll_f32", "tiled_factor_kernel": "dkt_mll_f32", "tiled_invert_kernel": "dkt_mll_f32", "tiled_w_kernel": "dkt_mll_f32",
     "tiled_wres_kernel": "dkt_mll_f32", "tiled_invres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
     "big_trmv_kernel": "dkt_mll_f32", "big_finish_kernel": "dkt_mll_f32",
+    "band_init_kernel": "dkt_mll_f32", "band_sym_kernel": "dkt_mll_f32", "band_class_kernel": "dkt_mll_f32", "band_chain_kernel": "dkt_mll_f32",
     # the element-wise chain rules
     "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",
     "class_kernel_fwd": "dkt_class_kernel_f32", "class_kernel_bwd": "dkt_class_kernel_bwd_f32",
@@ -45,7 +46,7 @@ KERNEL_TABLE = {
     "lowrank_gram_kernel": "dkt_lowrank_gram_f32", "lowrank_finish_kernel": "dkt_lowrank_finish_f32", "lowrank_bwd_kernel": "dkt_lowrank_bwd_f32",
     "lowrank_noise_floor_kernel": "dkt_lowrank_noise_floor_f32",
 }
-OURS = re.compile(r"gram|mll_|tiled_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank")
+OURS = re.compile(r"gram|mll_|tiled_|band_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank")
 
 
 def short_name(kernel: str) -> str:

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): for every BASELINE config a rocprofv3 kernel-trace + stats run of bench.py's own step and separate
 # PMC passes (FETCH_SIZE, WRITE_SIZE; for the headline config also the SQ / TCC counters); compact summaries ->
-# gpurun_out/prof_r05/<config>_summary.txt (copied to profiles/r05/ and condensed into profiles/pmc_traffic.json by
+# gpurun_out/prof_r06/<config>_summary.txt (copied to profiles/r05/ and condensed into profiles/pmc_traffic.json by
 # tools/make_traffic_json.py).   usage: tools/prof_all.sh [configs...]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r05
+OUT=$ROOT/gpurun_out/prof_r06
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CONFIGS=${@:-cfg2 cfg1 cfg3 cfg0 cfg4 cfg4_n320}
@@ -42,7 +42,7 @@ with open("%s/%s_summary.txt" % (out, cfg), "w") as f:
                 agg[k][1] += float(r.get("Counter_Value", 0) or 0)
             f.write("== counters (--pmc pass %s, --steps 5 --warmup 2)\n" % os.path.basename(d)[4:])
             for (kn, cn), (n, v) in sorted(agg.items()):
-                if any(t in kn for t in ("dkt", "gram", "mll", "tiled", "bgemm", "chol", "rbf", "sqdist", "big_", "lowrank")):
+                if any(t in kn for t in ("dkt", "gram", "mll", "tiled", "band", "bgemm", "chol", "rbf", "sqdist", "big_", "lowrank")):
                     f.write("%-90s %-28s dispatches %4d  mean %.6g\n" % (kn, cn, n, v / max(n, 1)))
 print(open("%s/%s_summary.txt" % (out, cfg)).read()[:3000])
 PY
