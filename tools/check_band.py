@@ -1,4 +1,4 @@
-"""Band path of the marginal likelihood (shared base matrix, 8 <= C <= 31, 128 <= N <= 447; csrc/dkt_mll_band.hip) against float64 torch and against its
+"""Band path of the marginal likelihood (shared base matrix, C <= 32, 128 <= N <= 432; the default from 12 classes and 192 episodes per call; csrc/dkt_mll_band.hip; named here through force_band) against float64 torch and against its
 tile-array twin (force_tiled), plus timings.  Measurement / bring-up tooling.
 
     python tools/check_band.py            parity on a few shapes
@@ -65,11 +65,11 @@ def problem(b, c, n, d, corr=False):
     return ops.gram(z), y, sv, mean, noise, cw
 
 
-shapes = [(3, 8, 128, 48, False), (2, 20, 320, 128, False), (2, 20, 420, 512, False), (2, 10, 150, 64, True), (2, 31, 447, 96, False), (3, 20, 420, 512, True), (2, 16, 257, 64, False)]
+shapes = [(3, 8, 128, 48, False), (2, 20, 320, 128, False), (2, 20, 420, 512, False), (2, 10, 150, 64, True), (2, 32, 432, 96, False), (3, 20, 420, 512, True), (2, 16, 257, 64, False)]
 for (b, c, n, d, corr) in shapes:
     e, y, sv, mean, noise, cw = problem(b, c, n, d, corr)
     lp, al, ge, gsv, gm, gnz = ref64(e, y, sv, mean, noise, cw)
-    for name, kw in (("band", {}), ("tiled", dict(force_tiled=True))):
+    for name, kw in (("band", dict(force_band=True)), ("tiled", dict(force_tiled=True))):
         o = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw, **kw)
         of = ops.mll(e, y, sv, mean, noise, want_grad=False, cls_weight=cw, **kw)
         rel = lambda x, r: ((x.double() - r).norm() / r.norm()).item()        # noqa: E731
@@ -89,16 +89,16 @@ y = torch.where(torch.arange(n, device=dev).unsqueeze(0) % c == torch.arange(c, 
 sv = torch.ones(c, device=dev); mean = torch.zeros(c, device=dev); noise = torch.full((c,), 1e-2, device=dev)
 noise[3] = 0.0
 cw = torch.full((c,), -1.0 / (c * n), device=dev)
-ot = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw)
+ot = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw, force_band=True)
 ob = ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw, force_tiled=True)
 print("failure case: info band %s tiled %s\n  jitter band %s tiled %s  logp diff %.2e  W diff %.2e" % (
     ot["info"].flatten().tolist(), ob["info"].flatten().tolist(), ot["jitter"].flatten().tolist(), ob["jitter"].flatten().tolist(),
     ((ot["logp"] - ob["logp"]).abs() / ob["logp"].abs()).nan_to_num(0).max().item(), ((ot["w"] - ob["w"]).norm() / ob["w"].norm()).item()), flush=True)
 
 if len(sys.argv) > 1:
-    for (b, c, n, d) in [(1024, 20, 420, 512), (1024, 20, 320, 512), (256, 20, 420, 512), (64, 20, 420, 512), (1, 20, 420, 512), (1024, 10, 200, 64), (1024, 8, 128, 64), (1024, 31, 447, 64)]:
+    for (b, c, n, d) in [(1024, 20, 420, 512), (1024, 20, 320, 512), (256, 20, 420, 512), (64, 20, 420, 512), (1, 20, 420, 512), (1024, 10, 200, 64), (1024, 8, 128, 64), (1024, 32, 432, 64)]:
         e, y, sv, mean, noise, cw = problem(b, c, n, d)
-        tt = timed(lambda: ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw))
+        tt = timed(lambda: ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw, force_band=True))
         tb = timed(lambda: ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw, force_tiled=True))
-        tf = timed(lambda: ops.mll(e, y, sv, mean, noise, want_grad=False, cls_weight=cw))
+        tf = timed(lambda: ops.mll(e, y, sv, mean, noise, want_grad=False, cls_weight=cw, force_band=True))
         print("B=%4d C=%2d N=%3d   band %.3f ms   tiled %.3f ms   band forward-only %.3f ms" % (b, c, n, tt, tb, tf), flush=True)
