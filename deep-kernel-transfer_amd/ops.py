@@ -35,6 +35,7 @@ MLL_FORCE_F32MFMA = 32
 MLL_E_PER_CLASS = 64
 MLL_FORCE_TILED = 128
 MLL_FORCE_BAND = 256
+MLL_NO_KAPPA_GUARD = 512
 
 LINEAR_KINDS = ("linear", "cossim", "bncossim")
 RBF_KINDS = ("rbf", "RBF")
@@ -174,7 +175,7 @@ def gram(a: torch.Tensor, bm: Optional[torch.Tensor] = None, kind: int = KERNEL_
 def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, noise: torch.Tensor,
         want_grad: bool = False, want_chol: bool = False, cls_weight: Optional[torch.Tensor] = None,
         jitter0: float = 1e-6, max_tries: int = 3, force_generic: bool = False, force_reg: bool = False,
-        force_blocked: bool = False, force_f32mfma: bool = False, force_tiled: bool = False, force_band: bool = False) -> dict:
+        force_blocked: bool = False, force_f32mfma: bool = False, force_tiled: bool = False, force_band: bool = False, no_kappa_guard: bool = False) -> dict:
     """Exact-GP marginal log likelihood of C models per episode.  e:[B,N,N] (one base matrix shared by the class models) or
     [B,C,N,N] (one per class model: DKT_MLL_E_PER_CLASS -- then w is [B,C,N,N] too); y:[C,N] (shared) or [B,C,N].
     force_*: the parity-tested twins of the default kernels (DKT_MLL_FORCE_* of include/dkt_abi.h)."""
@@ -205,7 +206,7 @@ def mll(e: torch.Tensor, y: torch.Tensor, sv: torch.Tensor, mean: torch.Tensor, 
     jit = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     info = torch.empty((b_, c_), device=dev, dtype=torch.int32)
     flags = ((MLL_FORCE_GENERIC if force_generic else 0) | (MLL_FORCE_BLOCKED if force_blocked else 0) |
-             (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0) | (MLL_FORCE_TILED if force_tiled else 0) | (MLL_FORCE_BAND if force_band else 0))
+             (MLL_FORCE_F32MFMA if force_f32mfma else 0) | (MLL_E_PER_CLASS if per_class else 0) | (MLL_FORCE_TILED if force_tiled else 0) | (MLL_FORCE_BAND if force_band else 0) | (MLL_NO_KAPPA_GUARD if no_kappa_guard else 0))
     chol = w = dsv = dmean = dnoise = None
     if want_chol:
         flags |= MLL_WANT_CHOL
@@ -751,7 +752,9 @@ def _lowrank_forward(z, y, sv_, mean_, noise_in, cw_, jitter0, max_tries, unit_r
     with _timed("dkt_lowrank_gram_f32"):
         st = lib.dkt_lowrank_gram_f32(_p(z), _p(y), y_bstride, _p(mean_), _p(a), _p(p), b_, c_, n, d, _stream())
     _lib.check(st, "dkt_lowrank_gram_f32")
-    out = mll(a, p, sv_, _zeros_cached(c_, dev), noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries)      # the D x D models
+    # the D x D models.  Unit rows (cossim / bncossim): cond(K') <= 1 + sv lambda_max / noise with lambda_max far below the trace N the kappa guard of dkt_mll_f32 prices
+    # (N = 420 rows would trip it at sv > 1.2 for a true condition of a few hundred); rows without the promise keep the guard
+    out = mll(a, p, sv_, _zeros_cached(c_, dev), noise_, want_grad=True, cls_weight=cw_, jitter0=jitter0, max_tries=max_tries, no_kappa_guard=bool(unit_rows))
     logp = torch.empty((b_, c_), device=dev, dtype=torch.float32)
     alpha = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)
     v = torch.empty((b_, c_, n), device=dev, dtype=torch.float32)

@@ -33,7 +33,7 @@ extern "C" {
                              4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
                                           + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_lowrank_* (linear kernels in feature space, D <= 64 < N); \
                              5 (round 6): shared-E calls with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes take ONE band reduction per episode (dkt_mll_band.hip); \
-                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND */
+                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND; the f16-split kernels (N <= 127) are followed by a kappa-aware fix-up launch (DKT_MLL_NO_KAPPA_GUARD) */
 
 /* status codes */
 #define DKT_OK 0
@@ -71,6 +71,8 @@ extern "C" {
                                     dkt_mll_band.hip, which is the default for a shared base matrix with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes per call */
 #define DKT_MLL_FORCE_BAND 256u  /* validation / measurement aid (ABI 5): the band reduction wherever it is defined (shared base matrix, 128 <= N <= 432, 2 <= C <= 32), also
                                     outside the window in which it is the default */
+#define DKT_MLL_NO_KAPPA_GUARD 512u /* validation / measurement aid (ABI 5): N <= 127 only -- the raw f16-split kernels without the fix-up launch that hands a unit whose
+                                       a-priori condition bound 1 + sv trace(E) / noise exceeds 5e3 to the exact-fp32 generic kernel */
 #define DKT_MLL_E_PER_CLASS 64u  /* every class model has its OWN base matrix: E is [B,C,N,N] and W is [B,C,N,N] (no sum over the classes) */
 
 int dkt_abi_version(void);
