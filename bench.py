@@ -859,6 +859,13 @@ def run(args):
             sweep[str(bs)] = {"value": round(bs * ss / ms_["dt"], 1), "ms_per_step": round(1e3 * ms_["dt"] / ss, 4),
                               "launches_per_step": round(sum(cnt for cnt, _ in ms_["ktimes"].values()) / (ss * len(ms_["blocks"])), 2), "valid": ms_["valid"]}
             del ms_
+            if bs <= 64:
+                # the same step captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed: the launch-bound small-batch step without the per-step Python / autograd
+                # work (the guide's "capture launch-bound inner loops in hipGraphs"); bitwise equal to the eager step (tests/test_gpu_parity.py)
+                gms = _graphed_step_ms(args.config, bs, dev, rank, UNIT_ROWS)
+                if gms is not None:
+                    sweep[str(bs)]["hipgraph_ms_per_step"] = round(gms, 4)
+                    sweep[str(bs)]["hipgraph_value"] = round(bs / gms * 1e3, 1)
         out["batch_sweep"] = {"config": args.config, "unit": "episodes/s", "by_episodes_per_step": sweep}
         torch.cuda.empty_cache()
         # the dtype question closed by a number: the same headline step with EXACT fp32 arithmetic everywhere -- Gram forward / backward without the f16 split
@@ -953,6 +960,33 @@ def run(args):
     if rank == 0:
         out["detail"] = _write_detail(out)
         _emit(real_stdout, _line_of(out))
+
+
+def _graphed_step_ms(cfg, b, dev, rank, unit_rows, reps=300):
+    """ms per step of the config's training step (Gram -> MLL -> Gram backward + the torch glue around them) replayed from ONE captured hipGraph."""
+    try:
+        step, _ = _workload(cfg, b, dev, rank, unit_rows)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps
+    except Exception as exc:  # noqa: BLE001
+        print("hipGraph capture of the %s step at B = %d failed: %s" % (cfg, b, exc), file=sys.stderr)
+        return None
 
 
 def _exact_fp32_run(args):

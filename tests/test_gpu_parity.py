@@ -501,6 +501,47 @@ def test_mll_large_and_small_magnitude_base_matrices(cuda, scale, monkeypatch):
             assert errs["h2e_raw"][k] < split_tol[k], (k, errs["h2e_raw"][k], errs["mfma"][k])
 
 
+def test_small_batch_training_step_replayed_from_a_hipgraph_is_bitwise_the_eager_step(cuda):
+    """The launch-bound end of SURVEY 8d's batch sizes (B = 1: what methods/DKT.py:117 issues): Gram -> marginal likelihood (+ its kappa-aware fix-up launch) -> Gram backward
+    and the torch glue around them captured ONCE into a hipGraph and replayed (bench.py's `batch_sweep.hipgraph_ms_per_step`): loss, log-likelihoods and dZ of every replay equal
+    the eager step bit for bit -- the ABI calls take the capturing stream, allocate nothing themselves and read no host-side state."""
+    c, s_, q_, d = 5, 5, 16, 64
+    n = c * (s_ + q_)
+    for b in (1, 3):
+        z = dev_t(O.synthetic_features(b, n, d, 3 + b), cuda).requires_grad_(True)
+        y = dev_t(O.one_vs_rest_targets(c, s_ + q_), cuda)
+        raw_s = dev_t(np.linspace(-0.3, 0.4, c), cuda).requires_grad_(True)
+        mean = dev_t(0.02 * np.arange(c), cuda).requires_grad_(True)
+        noise = dev_t(np.full(c, 0.1), cuda)
+        cw = dev_t(np.full(c, -1.0 / (c * n)), cuda)
+
+        def step():
+            z.grad = None; raw_s.grad = None; mean.grad = None
+            obj, logp, alpha, info, jit, e = ops.episode_loss_linear(z, y, torch.nn.functional.softplus(raw_s), mean, noise, cw, unit_rows=True)
+            loss = obj.mean()
+            loss.backward()
+            return loss, logp
+
+        side = torch.cuda.Stream(device=cuda)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+            loss_e, logp_e = step()
+            eager = [t.detach().clone() for t in (loss_e, logp_e, z.grad, raw_s.grad, mean.grad)]
+            del loss_e, logp_e                                   # (no reference into the eager step's autograd graph may survive into the capture)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss_g, logp_g = step()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        for a, bb in zip(eager, (loss_g, logp_g, z.grad, raw_s.grad, mean.grad)):
+            assert torch.equal(a, bb)
+
+
 def test_mll_regression_head_noise_at_its_lower_bound_takes_the_exact_kernel(cuda):
     """The regression head learns its noise (`DKT_regression.py:29, 53-54`: GaussianLikelihood, noise = softplus(raw) + 1e-4): driven to the 1e-4 bound, the 19 x 19 RBF
     model has cond(K) ~ sv N / noise ~ 1e5 -- far beyond what the 22-bit f16 splits resolve.  The default dispatch decides on the device (a-priori bound 1 + sv trace(E) / noise
