@@ -1235,6 +1235,30 @@ def test_mll_band_reduction_failure_goes_through_the_jitter_ladder(cuda):
         assert torch.equal(o[key], twin[key]), key
 
 
+def test_mll_band_reduction_per_episode_targets_and_no_class_weights(cuda):
+    """The ABI's other target layout (`Y[B,C,N]` with y_bstride = C N: every episode its own targets) and `cls_weight = NULL` (all ones) through the band reduction,
+    against float64 on every episode and class."""
+    rng = np.random.default_rng(31)
+    b, n, c = 3, 176, 12
+    e, _, sv, mean, noise, _ = _band_problem(b, n, c, 48, True, 31)
+    y = np.sign(rng.standard_normal((b, c, n)))
+    args = [dev_t(x, cuda) for x in (e, y, sv, mean, noise)]
+    o = ops.mll(*args, want_grad=True, force_band=True)
+    assert int(o["info"].abs().max().item()) == 0 and torch.equal(o["w"], o["w"].transpose(1, 2))
+    for bi in range(b):
+        w_ref = np.zeros((n, n))
+        for k in range(c):
+            kk = sv[k] * e[bi] + noise[k] * np.eye(n)
+            r = y[bi, k] - mean[k]
+            kinv = np.linalg.inv(kk)
+            alpha = kinv @ r
+            logp = -0.5 * r @ alpha - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+            assert abs(o["logp"][bi, k].item() - logp) < MLL_RTOL * abs(logp)
+            assert rel_l2(o["alpha"][bi, k].cpu().numpy(), alpha) < 2e-4
+            w_ref += sv[k] * 0.5 * (np.outer(alpha, alpha) - kinv)
+        assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
+
+
 def test_mll_band_reduction_dispatch_window_and_condition_guard(cuda):
     """(i) The default takes the band reduction from 12 classes and 192 episodes per call and the tile-array kernels below (bitwise equal to the named paths).
     (ii) A class whose a-priori condition bound 1 + sv trace(E) / noise exceeds 2e4 (here: noise 1e-3 on unit rows) is not trusted to the reduction -- its episode is
