@@ -465,6 +465,14 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
                  "dkt_lowrank_gram_f32": nd + 4 * 64 * (64 + c), "dkt_lowrank_finish_f32": nd + 4 * c * (64 + 2 * n), "dkt_lowrank_bwd_f32": 2 * nd + 4 * 64 * 64 + 4 * c * (n + 64)}
         roofs = {k: {"bound": "hbm", "achieved": round(alg_b[k] * nb / v / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg_b[k] * nb / v / 1e6 / HBM_PEAK_GBS, 4)} for k, v in kt.items() if k in alg_b and v > 0}
+        # PMC traffic (FETCH x 2 + WRITE) of the fused front-end kernels from the committed profile of this path, scaled to this batch
+        tjf = _traffic_table().get(cfg + "_from_trunk") if name == "from_trunk_features" else None
+        if tjf:
+            for k, r in roofs.items():
+                if k in tjf["kernels"]:
+                    r["traffic"] = round(tjf["kernels"][k]["hbm_bytes"] * nb / tjf["episodes_per_launch"])
+                    r["traffic_over_algorithmic"] = round(r["traffic"] / (alg_b[k] * nb), 3)
+                    r["traffic_source"] = tjf["source"]
         res[name] = {"value": round(nb / dt, 1), "unit": "episodes/s", "episodes_per_step": nb, "ms_per_step": round(1e3 * dt, 4), "roofline": roofs,
                      "valid": bool(int(info.abs().max().item()) == 0 and (x_rbf if fn is rbf else x).grad is not None
                                    and bool(torch.isfinite((x_rbf if fn is rbf else x).grad).all().item())),
@@ -865,7 +873,6 @@ def run(args):
                 gms = _graphed_step_ms(args.config, bs, dev, rank, UNIT_ROWS)
                 if gms is not None:
                     sweep[str(bs)]["hipgraph_ms_per_step"] = round(gms, 4)
-                    sweep[str(bs)]["hipgraph_value"] = round(bs / gms * 1e3, 1)
         out["batch_sweep"] = {"config": args.config, "unit": "episodes/s", "by_episodes_per_step": sweep}
         torch.cuda.empty_cache()
         # the dtype question closed by a number: the same headline step with EXACT fp32 arithmetic everywhere -- Gram forward / backward without the f16 split
@@ -999,7 +1006,7 @@ def _exact_fp32_run(args):
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
         rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
         return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "kernels_ms": rec.get("kernels_ms"), "mll_rel_err": rec.get("mll_rel_err"), "valid": rec.get("valid"),
-                "library": "libdkt_twins.so", "switches": "DKT_GRAM_SPLIT=0 DKT_MLL_F32MFMA=1"}
+                "how": "twins library, DKT_GRAM_SPLIT=0 DKT_MLL_F32MFMA=1"}
     except Exception as exc:  # noqa: BLE001
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
 
@@ -1021,7 +1028,9 @@ def _line_of(out):
             line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
                                 "kernels_ms": o["kernels_ms"],
                                 # per kernel: algorithmic bytes / HIP-event time / 8 TB/s (the full roofline objects are in the detail file)
-                                **({"hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}} if "roofline" in o else {})}
+                                **({"hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}} if "roofline" in o else {}),
+                                **({"traffic_x": {k: r["traffic_over_algorithmic"] for k, r in o["roofline"].items() if "traffic_over_algorithmic" in r}}
+                                   if any("traffic_over_algorithmic" in r for r in o.get("roofline", {}).values()) else {})}
                          for name, o in out[key].items()}
     if "test_time_forward" in out:
         line["test_time_forward"] = {k: out["test_time_forward"][k] for k in ("value", "ms_per_step", "episodes_per_step")}

@@ -27,8 +27,6 @@ struct MllArgs {
     float jitter0;
     int max_tries;
     unsigned flags;
-    float kappa_max;              // generic kernel as the fix-up pass of the f16-split kernels (N <= 127): with only_failed set, ALSO redo a unit whose a-priori condition bound
-                                  // 1 + sv_c trace(E) / noise_c exceeds this (0 = off)
     int p2_guard;                 // wave-per-episode kernel: binades of head room of the f16 scale of M over the diagonal tiles (DKT_MLL_P2_GUARD, default 1)
 };
 

@@ -42,20 +42,11 @@ __global__ __launch_bounds__(256) void mll_generic_kernel(MllArgs a) {
     const size_t unit = epc ? (size_t)a.b0 * C + blockIdx.x : (size_t)a.b0 + blockIdx.x;
     const int b = epc ? (int)(unit / (size_t)C) : (int)unit;
     const int c_first = epc ? (int)(unit % (size_t)C) : 0, c_end = epc ? c_first + 1 : C;
-    if (a.only_failed) {                       // fix-up pass of the blocked / tile-array / f16-split paths: nothing to do for a unit without a failure ...
+    if (a.only_failed) {                       // fix-up pass of the blocked / tile-array / band / f16-split paths: nothing to do for a unit without a flag
         bool need = false;
         for (int c = c_first; c < c_end; ++c) need = need || a.only_failed[(size_t)b * C + c] != 0;
-        if (a.kappa_max > 0.f) {
-            // ... or (fix-up of the f16-split kernels) whose class matrices the 22-bit splits are not trusted with: a-priori condition bound
-            // kappa_c <= 1 + sv_c trace(E) / noise_c from values already on the device, no host read-back
-            const float* Eb0 = a.E + unit * N * N;
-            float tr = 0.f;
-            for (int i = tid; i < N; i += 256) tr += Eb0[(size_t)i * N + i];
-            tr = block_sum_256(tr, smem);
-            for (int c = c_first; c < c_end; ++c) need = need || !(1.0f + a.sv[c] * tr / a.noise[c] <= a.kappa_max);
-        }
+        if (!need) return;                     // (uniform)
         __syncthreads();                       // every thread has read the flags before anybody rewrites info[]
-        if (!need) return;
     }
     float* cs = smem;            // [R]  scaled column of the current sweep step
     float* ldiag = cs + R;       // [R]  diag(L)
@@ -222,17 +213,37 @@ void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipS
 // thousand (the reference's unit-norm rows and frozen noise 0.1: <= 730) and 2 - 3 x the tolerances at 1.6e4 (test_mll_large_and_small_magnitude_base_matrices).  After
 // the split launch the generic kernel -- exact fp32 on the matrix itself, jitter ladder included, LDS-resident at these sizes -- redoes every unit (episode, or matrix
 // with DKT_MLL_E_PER_CLASS) whose a-priori bound 1 + sv trace(E) / noise exceeds MLL_H2_KAPPA_MAX, decided on the device (a launch of B workgroups that read N diagonal
-// elements and leave: 4 - 6 us at 8192 episodes).  DKT_MLL_NO_KAPPA_GUARD = the raw split kernels (tests, A/B tools).
+// elements per unit, then the generic kernel whose workgroups read their flags and leave).  DKT_MLL_NO_KAPPA_GUARD = the raw split kernels (tests, A/B tools).
 constexpr float MLL_H2_KAPPA_MAX = 5.0e3f;
+
+// one wave per unit (episode, or class matrix with DKT_MLL_E_PER_CLASS): trace(E) from the N diagonal elements, then info[b, c] = -1 for every class of the unit
+// whose bound exceeds kappa_max and whose split factorisation had succeeded (a failed one is flagged already)
+__global__ __launch_bounds__(256) void mll_kappa_flag_kernel(MllArgs a, const float kappa_max) {
+    const int lane = threadIdx.x & 63;
+    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
+    const size_t unit = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), units = epc ? (size_t)a.B * a.C : (size_t)a.B;
+    if (unit >= units) return;
+    const int N = a.N, C = a.C;
+    const float* Eb = a.E + unit * N * N;
+    float tr = 0.f;
+    for (int i = lane; i < N; i += 64) tr += Eb[(size_t)i * N + i];
+    tr = wave_allsum(tr);
+    const int c0 = epc ? (int)(unit % (size_t)C) : 0, c1 = epc ? c0 + 1 : C;
+    const size_t b = epc ? unit / (size_t)C : unit;
+    for (int c = c0 + lane; c < c1; c += 64)
+        if (!(1.0f + a.sv[c] * tr / a.noise[c] <= kappa_max) && a.info[b * C + c] == 0) a.info[b * C + c] = -1;
+}
+
 static void mll_kappa_fixup(MllArgs a, hipStream_t st) {
     if ((a.flags & DKT_MLL_NO_KAPPA_GUARD) || !mll_fits_lds(a.N)) return;
-    a.only_failed = a.info;
-    a.kappa_max = MLL_H2_KAPPA_MAX;
-    a.b0 = 0; a.LD = mll_ld(a.N);
     const int upe = (a.flags & DKT_MLL_E_PER_CLASS) ? a.C : 1;
+    const size_t units = (size_t)a.B * upe;
+    hipLaunchKernelGGL(mll_kappa_flag_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a, MLL_H2_KAPPA_MAX);
+    a.only_failed = a.info;                                    // the generic kernel leaves at once (one flag read per class, no barrier) unless the unit is flagged
+    a.b0 = 0; a.LD = mll_ld(a.N);
     const size_t lds = (mll_vec_floats(a.N) + mll_mat_floats(a.N)) * sizeof(float);
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)mll_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
-    hipLaunchKernelGGL(mll_generic_kernel<false>, dim3((unsigned)a.B * upe), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(mll_generic_kernel<false>, dim3((unsigned)units), dim3(256), lds, st, a);
 }
 
 static int g_mll_env_read = 0, g_p2_guard = 1, g_force_f32mfma = 0;
@@ -279,7 +290,7 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
     a.cls_weight = cls_weight; a.logp = logp; a.alpha = alpha; a.L = L; a.W = W; a.dsv = dsv;
     a.dmean = dmean; a.dnoise = dnoise; a.jitter_used = jitter_used; a.info = info;
     a.ws = (float*)workspace; a.only_failed = nullptr; a.b0 = 0; a.B = B; a.C = C; a.N = N; a.LD = mll_ld(N);
-    a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags; a.kappa_max = 0.f;
+    a.jitter0 = jitter0; a.max_tries = max_tries; a.flags = flags;
     if (g_mll_env_read == 0) {
         const char* pg = dkt_variant_env("DKT_MLL_P2_GUARD");      // validation aid: a negative guard forces the grow-on-demand path of dkt_mll_h2.hip
         g_p2_guard = pg ? atoi(pg) : 1;

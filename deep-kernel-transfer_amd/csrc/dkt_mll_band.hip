@@ -791,8 +791,22 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     f32x4 ngt_prev = ZERO4, yprev = ZERO4, st_prev = ZERO4;
     float lsum = 0.f, trb = 0.f;
     int fail_at = 0;
+    // (the tiles of step j + 1 are requested at the top of step j: the chain of a class is ~ 27 x 2 dependent steps, a memory round trip per step would double it)
+    auto load_st = [&](const int j) {       // S_j^T in the accumulator layout from the stored tile (j + 1, j) = S_j: lane (g, c) register q <- S_j[c][4g + q]
+        const float* sp = At + (size_t)lslot(j + 1, j) * 256 + 64 * (c16 >> 2) + 4 * g4 + (c16 & 3);
+        return (f32x4){sp[0], sp[4], sp[8], sp[12]};
+    };
+    f32x4 P_nx = ld4(At + lane * 4), St_nx = NT > 1 ? load_st(0) : ZERO4;
+    f32x4 u_nx = col0 ? ld4(Ut + (size_t)pu * 256 + (4 * g4 + cu) * 4) : ZERO4;
     for (int j = 0; j < NT; ++j) {
-        f32x4 P = ld4(At + (size_t)lslot(j, j) * 256 + lane * 4);
+        f32x4 P = P_nx;
+        const f32x4 St_cur = St_nx, u_cur = u_nx;
+        {
+            const int jn = j + 1 < NT ? j + 1 : j;
+            P_nx = ld4(At + (size_t)lslot(jn, jn) * 256 + lane * 4);
+            St_nx = jn + 1 < NT ? load_st(jn) : ZERO4;
+            u_nx = col0 ? ld4(Ut + ((size_t)jn * CP + pu) * 256 + (4 * g4 + cu) * 4) : ZERO4;
+        }
         float dmax = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -828,15 +842,13 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
         f32x4 Pinv = xty0(M, M);
         Pinv *= ikap;
         // vectors: column 0 of a tile carries the 16 entries of this class' vector
-        f32x4 y = col0 ? ld4(Ut + ((size_t)j * CP + pu) * 256 + (4 * g4 + cu) * 4) : ZERO4;
+        f32x4 y = u_cur;
         if (j > 0) y = xty(ngt_prev, yprev, y);                                          // y_j = u_j - G_{j-1} y_{j-1}
         const f32x4 z = xty0(Pinv, y);
         st4(Pg + (size_t)j * 256 + lane * 4, Pinv);
         if (col0) st4(Zv + j * 16 + g4, z);
         if (j + 1 < NT) {
-            // S_j^T in the accumulator layout from the stored tile (j + 1, j) = S_j: lane (g, c) register q <- S_j[c][4g + q]
-            const float* sp = At + (size_t)lslot(j + 1, j) * 256 + 64 * (c16 >> 2) + 4 * g4 + (c16 & 3);
-            const f32x4 St = {sp[0], sp[4], sp[8], sp[12]};
+            const f32x4 St = St_cur;
             st_prev = St;
             const f32x4 Gj = xty0(St, Pinv);                                             // S_j P^-1
             ngt_prev = neg4(xty0(Pinv, St));                                             // -(P^-1 S_j^T) = -G_j^T
@@ -849,15 +861,20 @@ __global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
     float* AmT = ep + G.oAmT;
     f32x4 a_next = ZERO4, zd_next = ZERO4;
     float trz = 0.f, aa = 0.f;
+    f32x4 Pi_nx = ld4(Pg + (size_t)(NT - 1) * 256 + lane * 4), z_nx = col0 ? ld4(Zv + (NT - 1) * 16 + g4) : ZERO4, G_nx = ZERO4;
     for (int j = NT - 1; j >= 0; --j) {
-        const f32x4 Pinv = ld4(Pg + (size_t)j * 256 + lane * 4);
-        const f32x4 z = col0 ? ld4(Zv + j * 16 + g4) : ZERO4;
+        const f32x4 Pinv = Pi_nx, z = z_nx, Gj = G_nx;
+        {
+            const int jn = j > 0 ? j - 1 : 0;
+            Pi_nx = ld4(Pg + (size_t)jn * 256 + lane * 4);
+            z_nx = col0 ? ld4(Zv + jn * 16 + g4) : ZERO4;
+            G_nx = ld4(Gg + (size_t)jn * 256 + lane * 4);              // (G_{NT-1} does not exist and is not read: the loop starts with the zero tile)
+        }
         f32x4 a, zd;
         if (j == NT - 1) {
             a = z;
             zd = Pinv;
         } else {
-            const f32x4 Gj = ld4(Gg + (size_t)j * 256 + lane * 4);
             a = xty(neg4(Gj), a_next, z);
             zd = xty(Gj, xty0(zd_next, Gj), Pinv);
         }

@@ -106,6 +106,27 @@ def main():
                           "device_kernels": {n_: {"dispatches": k["dispatches"], "fetch_bytes": k["fetch_kb_mean"] * 2048.0, "write_bytes": k["write_kb_mean"] * 1024.0}
                                              for n_, k in sorted(d["kernels"].items())}}
         res["configs"][cfg] = {"episodes_per_launch": episodes, "source": path, "kernels": kernels}
+    # the fused front-end kernels of the from-trunk path (tools/prof_other_paths_pmc.sh -> other_paths_pmc.txt: tools/bench_frontend.py at 2048 cfg2 episodes; the
+    # `max` column = the largest batch of the tool): config "cfg2_from_trunk"
+    for d_ in src_dir.split(","):
+        path = os.path.join(d_, "other_paths_pmc.txt")
+        if not os.path.exists(path):
+            continue
+        sect, kb = None, {}
+        for line in open(path):
+            m = re.match(r"^== tools/(\w+)\.py, --pmc (FETCH_SIZE|WRITE_SIZE)", line)
+            if m:
+                sect = (m.group(1), m.group(2))
+                continue
+            m = re.match(r"^(.*?)\s+dispatches\s+\d+\s+mean\s+[0-9.e+-]+\s+max\s+([0-9.e+-]+)", line)
+            if m and sect and sect[0] == "bench_frontend":
+                for kn, fnm in (("gram_bn_train_f16_kernel", "dkt_gram_bn_train_f32"), ("gram_bn_bwd_ep_kernel", "dkt_gram_bn_bwd_f32")):
+                    if kn in m.group(1):
+                        kb.setdefault(fnm, {})[sect[1]] = float(m.group(2))
+        if kb:
+            res["configs"]["cfg2_from_trunk"] = {"episodes_per_launch": 2048, "source": path, "kernels": {
+                f: {"fetch_bytes": v.get("FETCH_SIZE", 0.0) * 2048.0, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024.0,
+                    "hbm_bytes": v.get("FETCH_SIZE", 0.0) * 2048.0 + v.get("WRITE_SIZE", 0.0) * 1024.0} for f, v in kb.items()}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({c: {k: round(v["hbm_bytes"] / 1e9, 3) for k, v in d["kernels"].items()} for c, d in res["configs"].items()}, indent=1))
 
