@@ -1259,6 +1259,51 @@ def test_mll_band_reduction_per_episode_targets_and_no_class_weights(cuda):
         assert rel_l2(o["w"][bi].cpu().numpy(), w_ref) < 2e-4
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_mll_band_reduction_random_shapes_hypers_and_class_weights(cuda, seed):
+    """Random (N, C, D), outputscales 0.2 ... 3, noises 0.05 ... 0.5, means, class weights of both signs and very different magnitude (one of them zero): the band
+    reduction against the generic exact-fp32 kernel (same inputs, matrix factorised directly) and against float64 on one episode.  Covers tile counts 8 ... 27 with and
+    without a partial last tile, every class-column layout of the chain kernel (waves with 1 ... 4 block columns) and the f16 scales of the back pass (|M| bound from |cw|)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(128, 433))
+    c = int(rng.integers(2, 33))
+    d = int(rng.choice([24, 64, 200]))
+    b = 2
+    z = rng.standard_normal((b, n, d))
+    if seed % 2:
+        cm = rng.standard_normal((b, c, d))
+        z = 0.8 * cm[:, rng.integers(0, c, n)] + 0.3 * z
+    z /= np.linalg.norm(z, axis=2, keepdims=True)
+    e = np.einsum("bnd,bmd->bnm", z, z).astype(np.float32).astype(np.float64)
+    y = np.sign(rng.standard_normal((c, n)))
+    sv = np.exp(rng.uniform(np.log(0.2), np.log(3.0), c))
+    noise = np.exp(rng.uniform(np.log(0.05), np.log(0.5), c))
+    mean = 0.1 * rng.standard_normal(c)
+    cw = rng.standard_normal(c) * 10.0 ** rng.integers(-3, 1, c) / n
+    cw[rng.integers(0, c)] = 0.0
+    if max(1.0 + sv * n / noise) > 1.5e4:                    # stay below the path's own condition guard (2e4): this test is about the reduction
+        sv = sv * 1.5e4 / max(1.0 + sv * n / noise)
+    args = [dev_t(x, cuda) for x in (e, y, sv, mean, noise)]
+    o = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_band=True)
+    gen = ops.mll(*args, want_grad=True, cls_weight=dev_t(cw, cuda), force_generic=True)
+    assert int(o["info"].abs().max().item()) == 0 and torch.equal(o["w"], o["w"].transpose(1, 2))
+    np.testing.assert_allclose(o["logp"].cpu().numpy(), gen["logp"].cpu().numpy(), rtol=MLL_RTOL)
+    assert rel_l2(o["alpha"].cpu().numpy(), gen["alpha"].cpu().numpy()) < 5e-4
+    assert rel_l2(o["w"].cpu().numpy(), gen["w"].cpu().numpy()) < GRAD_RTOL
+    for key in ("dsv", "dmean", "dnoise"):
+        assert rel_l2(o[key].cpu().numpy(), gen[key].cpu().numpy()) < 2 * GRAD_RTOL, key
+    w_ref = np.zeros((n, n))
+    for k in range(c):
+        kk = sv[k] * e[0] + noise[k] * np.eye(n)
+        r = y[k] - mean[k]
+        kinv = np.linalg.inv(kk)
+        alpha = kinv @ r
+        logp = -0.5 * r @ alpha - 0.5 * np.linalg.slogdet(kk)[1] - 0.5 * n * np.log(2 * np.pi)
+        assert abs(o["logp"][0, k].item() - logp) < MLL_RTOL * abs(logp), (n, c, k)
+        w_ref += cw[k] * sv[k] * 0.5 * (np.outer(alpha, alpha) - kinv)
+    assert rel_l2(o["w"][0].cpu().numpy(), w_ref) < GRAD_RTOL, (n, c)
+
+
 def test_mll_band_reduction_dispatch_window_and_condition_guard(cuda):
     """(i) The default takes the band reduction from 12 classes and 192 episodes per call and the tile-array kernels below (bitwise equal to the named paths).
     (ii) A class whose a-priori condition bound 1 + sv trace(E) / noise exceeds 2e4 (here: noise 1e-3 on unit rows) is not trusted to the reduction -- its episode is
