@@ -963,40 +963,46 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void band_chain_kernel(BandArgs t
                                                  (lds_u8*)(smem + ((size_t)bufi * BAND_MAXNT + tile) * 256), 16, 0, 0);
         }
     };
-    fetch(0, 0);
+    // TWO classes per iteration: their chains of one block column have the same length and feed the same accumulator, so every step is one basic block with two
+    // independent dependency chains (one class at a time: ~ 350 cycles per step for 4 dependent MFMAs + an LDS read, measured 31 k cycles per class).  LDS: 2 x 2 class
+    // images, double buffered.
+    const int npair = (C + 1) / 2;
+    auto fetch2 = [&](const int pr, const int half) {
+        fetch(2 * pr, 2 * half);
+        if (2 * pr + 1 < C) fetch(2 * pr + 1, 2 * half + 1);
+    };
+    fetch2(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);                   // vmcnt(0)
     __syncthreads();
-    for (int c = 0; c < C; ++c) {
-        const float* gb = smem + (c & 1) * (BAND_MAXNT * 256) + lane * 4;
-        if (c + 1 < C) fetch(c + 1, (c + 1) & 1);
-        if (info[c] == 0) {                                        // (a failed class leaves the episode to the fix-up launch)
-            const float wz = -0.5f * (t.a.cls_weight ? t.a.cls_weight[c] : 1.0f);
-            const float* zc = Zg + (size_t)c * NT * 256 + lane * 4;
-            {   // columns e = w and e = 31 - w
-                f32x4 za = ld4(zc + (size_t)i0 * 256), zb = l3 ? ld4(zc + (size_t)i3 * 256) : ZERO4;
-                P[0] += wz * za;
-                P[NACC_P - 1] += wz * zb;
-#pragma unroll
-                for (int s = 1; s < NACC_P; ++s) {
-                    const float sg = (s & 1) ? -wz : wz;           // Z_ji = (-1)^s G_j^T ... G_{i-1}^T Z_ii
-                    if (s < l0) chain_step(za, P[s], gb + (size_t)(i0 - s) * 256, sg);
-                    if (s < l3) chain_step(zb, P[NACC_P - 1 - s], gb + (size_t)(i3 - s) * 256, sg);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {   // columns e = 15 - w and e = 16 + w
-                f32x4 za = l1 ? ld4(zc + (size_t)i1 * 256) : ZERO4, zb = l2 ? ld4(zc + (size_t)i2 * 256) : ZERO4;
-                Q[0] += wz * za;
-                Q[NACC_Q - 1] += wz * zb;
-#pragma unroll
-                for (int s = 1; s < NACC_Q; ++s) {
-                    const float sg = (s & 1) ? -wz : wz;
-                    if (s < l1) chain_step(za, Q[s], gb + (size_t)(i1 - s) * 256, sg);
-                    if (s < l2) chain_step(zb, Q[NACC_Q - 1 - s], gb + (size_t)(i2 - s) * 256, sg);
-                }
-            }
+    for (int pr = 0; pr < npair; ++pr) {
+        const int c0 = 2 * pr, c1 = (2 * pr + 1 < C) ? 2 * pr + 1 : c0;       // (an odd class count: the last iteration runs its class twice, the copy with weight 0)
+        const float* g0 = smem + (size_t)(2 * (pr & 1)) * (BAND_MAXNT * 256) + lane * 4;
+        const float* g1 = (2 * pr + 1 < C) ? g0 + BAND_MAXNT * 256 : g0;
+        if (pr + 1 < npair) fetch2(pr + 1, (pr + 1) & 1);
+        // (a failed class leaves the episode to the fix-up launch: weight 0 here, whatever its tiles hold)
+        const float w0 = info[c0] == 0 ? -0.5f * (t.a.cls_weight ? t.a.cls_weight[c0] : 1.0f) : 0.f;
+        const float w1 = (2 * pr + 1 < C && info[c1] == 0) ? -0.5f * (t.a.cls_weight ? t.a.cls_weight[c1] : 1.0f) : 0.f;
+        const float* z0p = Zg + (size_t)c0 * NT * 256 + lane * 4;
+        const float* z1p = Zg + (size_t)c1 * NT * 256 + lane * 4;
+#define DKT_CHAIN_COL(ACC, IDX0, IDXS, I, LEN, NACC)                                                                                   \
+        if ((LEN) > 0) {                                                                                                               \
+            f32x4 za = ld4(z0p + (size_t)(I) * 256), zb = ld4(z1p + (size_t)(I) * 256);                                                \
+            ACC[IDX0] += w0 * za + w1 * zb;                                                                                            \
+            _Pragma("unroll") for (int s = 1; s < (NACC); ++s) {                                                                      \
+                if (s < (LEN)) {                                                                                                       \
+                    za = xty0(ld4(g0 + (size_t)((I) - s) * 256), za);                                                                  \
+                    zb = xty0(ld4(g1 + (size_t)((I) - s) * 256), zb);                                                                  \
+                    const f32x4 sum = w0 * za + w1 * zb;                       /* Z_ji = (-1)^s G_j^T ... G_{i-1}^T Z_ii */             \
+                    ACC[IDXS] += (s & 1) ? -sum : sum;                                                                                 \
+                }                                                                                                                      \
+            }                                                                                                                          \
         }
-        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);               // vmcnt(0): the next class' tiles have landed
+        DKT_CHAIN_COL(P, 0, s, i0, l0, NACC_P)
+        DKT_CHAIN_COL(P, NACC_P - 1, NACC_P - 1 - s, i3, l3, NACC_P)
+        DKT_CHAIN_COL(Q, 0, s, i1, l1, NACC_Q)
+        DKT_CHAIN_COL(Q, NACC_Q - 1, NACC_Q - 1 - s, i2, l2, NACC_Q)
+#undef DKT_CHAIN_COL
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00);               // vmcnt(0): the next pair's tiles have landed
         __syncthreads();
     }
     // rank-C term M_ji += sum_p (A^T_pj)^T diag(ka) A^T_pi, then the stored triangle: tile (i, j) = M_ji^T
@@ -1078,6 +1084,7 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)band_sym_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) return DKT_ERR_LAUNCH;
         if (hipFuncSetAttribute((const void*)band_sym_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) return DKT_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)band_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BAND_MAXNT * 1024) != hipSuccess) return DKT_ERR_LAUNCH;
         attr_done = true;
     }
     const int Bc = a.B < BAND_CHUNK ? a.B : BAND_CHUNK;
@@ -1089,7 +1096,7 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
         hipLaunchKernelGGL(band_init_kernel, dim3((slots + 3) / 4, bcnt), dim3(256), 0, st, t);
         hipLaunchKernelGGL(band_sym_kernel<false>, dim3(bcnt), dim3(256), lds, st, t);
         hipLaunchKernelGGL(band_class_kernel, dim3(bcnt, (a.C + 3) / 4), dim3(256), 0, st, t);
-        if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt), dim3(64 * CHAIN_WAVES), 2 * BAND_MAXNT * 1024, st, t);
+        if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt), dim3(64 * CHAIN_WAVES), 4 * BAND_MAXNT * 1024, st, t);
         hipLaunchKernelGGL(band_sym_kernel<true>, dim3(bcnt), dim3(256), lds, st, t);
         MllArgs f = a;
         f.only_failed = a.info;
