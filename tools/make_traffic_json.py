@@ -33,7 +33,7 @@ KERNEL_TABLE = {
     "gram_bwd_rows_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_big_ep_kernel": "dkt_gram_bwd_f32", "gram_small_bwd_kernel": "dkt_gram_bwd_f32",
     "gram_bwd_kernel": "dkt_gram_bwd_f32", "gram_bn_bwd_ep_kernel": "dkt_gram_bwd_f32",
     # dkt_mll_f32
-    "mll_h2e_kernel": "dkt_mll_f32", "mll_h2_kernel": "dkt_mll_f32", "mll_mfma_kernel": "dkt_mll_f32", "mll_generic_kernel": "dkt_mll_f32",
+    "mll_h2e_kernel": "dkt_mll_f32", "mll_h2_kernel": "dkt_mll_f32", "mll_mfma_kernel": "dkt_mll_f32", "mll_generic_kernel": "dkt_mll_f32", "mll_kappa_flag_kernel": "dkt_mll_f32",
     "tiled_etile_kernel": "dkt_mll_f32", "tiled_factor_kernel": "dkt_mll_f32", "tiled_invert_kernel": "dkt_mll_f32", "tiled_w_kernel": "dkt_mll_f32",
     "tiled_wres_kernel": "dkt_mll_f32", "tiled_invres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
     "big_trmv_kernel": "dkt_mll_f32", "big_finish_kernel": "dkt_mll_f32",
