@@ -14,16 +14,23 @@
 // per class matrix.
 //
 // Everything is 16 x 16 tiles of 1 KB in the MFMA accumulator layout (lane (g, c) register q <-> element [4g + q][c]), every product is D += X^T Y =
-// 4 x v_mfma_f32_16x16x4_f32 (dkt_mfma_tiles.h) -- exact fp32 throughout, no split, no range contract.  Kernels (workspace per episode in `BandGeo`):
-//   band_init_kernel      E[b] -> full tile array A (both triangles), U = [y_c - m_c] as tiles
-//   band_sym_kernel<false>  (workgroup = episode)  panels k = 0 .. NT-3: Householder QR of block column k below the band (rows over threads, one
-//                         exchange per column), T_k by the larft recurrence from V^T V, U <- H^T U, and the two-sided update A <- H^T A H as
-//                         X = A V, S = V^T X, Y = X Th^T - 0.5 V (Th S Th^T), A -= V Y^T + Y V^T with V and Y in LDS
-//   band_class_kernel     (wave = class matrix)  block LDL^T chain of B + mu_c I on the diagonal-tile sweep of dkt_mfma_tiles.h: pivots, P_j^-1, G_j = S_j P_j^-1,
-//                         forward / backward substitution for a_c, Z_jj = diagonal blocks of (B + mu_c)^-1, all scalars of the class
-//   band_chain_kernel     (wave = block columns)  Z_ji = -G_j^T Z_{j+1,i} upwards from the diagonal, accumulated over the classes in registers, + the rank-C term
-//   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same code with Th = T), a <- H_k a; then W[b] and alpha[b] are stored
-// Attempt 0 only (no jitter): an episode with a failed class is redone -- jitter ladder and all -- by the generic kernel's fix-up launch, as in the tile-array path.
+// 4 x v_mfma_f32_16x16x4_f32 (dkt_mfma_tiles.h).  The forward reduction, the class chains and the column chains are EXACT fp32 (their rounding is amplified by
+// cond(K)); only the back transform -- orthogonal similarities of M, every operand bounded a priori -- runs as scaled 2-way f16 splits (dkt_h2_tiles.h).
+// A / B / M live as the LOWER block triangle of the episode (tile (i, j), i >= j, at i (i + 1) / 2 + j).  Kernels (workspace per episode in `BandGeo`):
+//   band_init_kernel        E[b] -> the tile array, U = [y_c - m_c] as tiles
+//   band_sym_kernel<false>  (workgroup = episode, 2 per CU)  panels k = 0 .. NT-3: update block column k with the finished panel, Householder QR of it (rows over
+//                           threads, ONE exchange per column), then ONE fused pass over the stored tiles: A_ij -= V_i Y_j^T + Y_i V_j^T and the next panel's
+//                           X' = A V' from the same registers (per-wave partial accumulators for every tile column, a wave-private LDS transpose for the mirrored
+//                           contribution); T' by the larft recurrence from V'^T V', Y' = X' Th^T - 0.5 V' (Th S Th^T), U <- H'^T U
+//   band_class_kernel       (wave = class matrix)  block LDL^T chain of B + mu_c I on the diagonal-tile sweep of dkt_mfma_tiles.h: pivots, P_j^-1, G_j = S_j P_j^-1,
+//                           forward / backward substitution for a_c, Z_jj = diagonal blocks of (B + mu_c)^-1, tr Z, a.a, the a-priori condition bound
+//   band_chain_kernel       (workgroup = episode, 8 waves x 4 block columns)  Z_ji = -G_j^T Z_{j+1,i} upwards from the diagonal, two classes per step, accumulated
+//                           over the classes in registers, the classes' G tiles DMA-staged through LDS, + the rank-C term
+//   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same fused pass with Th = T, f16 splits), a <- H_k a; then W[b], alpha[b], and the quadratic
+//                           form / hyper-gradients from the residual rho = r - K alpha against the ORIGINAL E (the reduction's backward error, a few eps |E|, would
+//                           otherwise cost 3e-5 ... 9e-5 on r^T K^-1 r for class-correlated features)
+// Attempt 0 only (no jitter): an episode with a failed class -- or with a class whose a-priori bound 1 + sv trace(E) / noise exceeds BAND_KAPPA_MAX -- is redone,
+// jitter ladder and all, by the generic kernel's fix-up launch, as in the tile-array path.  Measurements and everything that was tried: docs/MEASUREMENTS.md R6.
 #include "dkt_h2_tiles.h"
 
 namespace {
