@@ -22,7 +22,7 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdkt_hip.so")
-SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_small.hip", "dkt_classkernel.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_h2.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_mll_band.hip", "dkt_predict.hip",
+SOURCES = ["dkt_gram.hip", "dkt_gram_ep.hip", "dkt_gram_big.hip", "dkt_gram_small.hip", "dkt_classkernel.hip", "dkt_mll.hip", "dkt_mll_mfma.hip", "dkt_mll_h2.hip", "dkt_mll_reg.hip", "dkt_mll_big.hip", "dkt_mll_tiled.hip", "dkt_mll_band.hip", "dkt_objective.hip", "dkt_predict.hip",
            "dkt_spectral.hip", "dkt_frontend.hip", "dkt_frontend_big.hip", "dkt_lowrank.hip"]
 # measurement-only kernels (stream ceilings, co-residency spinners): a separate test / tooling library, NOT part of the product
 DIAG_SOURCES = ["dkt_diag.hip", "dkt_mll_reg_twin.hip"]
@@ -46,6 +46,8 @@ SIGNATURES = {
     "dkt_mll_f32": (_c_i, [_c_p, _c_p, ctypes.c_long, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_i,
                            ctypes.c_uint, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                            _c_p, ctypes.c_size_t, _c_p]),
+    "dkt_objective_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
+    "dkt_hyper_grads_f32": (_c_i, [_c_p] * 8 + [_c_i, _c_i, _c_p]),
     "dkt_gram_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, ctypes.c_uint, _c_p]),
     "dkt_rbf_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_sqdist_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),

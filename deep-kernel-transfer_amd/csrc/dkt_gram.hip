@@ -19,6 +19,7 @@
 bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st);
 bool dkt_gram_sym_big_launch(const float* Z, float* E, int B, int N, int D, bool unit, hipStream_t st);
+bool dkt_gram_fewep_applies(int B, int N, int D);                                  // dkt_gram_ep.hip: fewer episodes than the episode-resident kernels take
 // wave-per-episode kernels for N <= 32 (dkt_gram_small.hip): every kind, symmetric; DKT_GRAM_SMALL=0 keeps the generic kernels
 bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st);
 bool dkt_gram_dist_ep_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st);      // dkt_frontend.hip
@@ -345,6 +346,66 @@ __global__ __launch_bounds__(256) void sqdist_bwd_kernel(const float* __restrict
     if (threadIdx.x == 0) dl[b] = -2.0f * tot / l;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// A handful of episodes (the reference's literal loop is ONE episode per step, DKT.py:117-164): every kernel above gives an episode to one to three workgroups,
+// whose K loop is then a chain of dependent memory round trips (50 steps at D = 1600: 57 us for one 105 x 1600 episode, on 3 of 256 CUs).  Here a workgroup owns
+// ONE 16 x 16 tile of the lower block triangle and its 8 waves each contract every eighth 16-feature group, straight from global memory into the MFMA operand
+// layout (lane (r, q) loads Z[16 i + r][16 s + 4 q .. + 3]: the t-th MFMA of the group contracts k = {t, 4 + t, 8 + t, 12 + t} on both operands); the partial tiles
+// meet in LDS in wave order (bitwise reproducible).  Z is re-read once per tile column from L2 -- irrelevant at this size.  Exact fp32 (v_mfma_f32_16x16x4_f32).
+// ------------------------------------------------------------------------------------------
+constexpr int FEW_WAVES = 8, FEW_UNROLL = 4;
+__global__ __launch_bounds__(64 * FEW_WAVES) void gram_sym_fewep_kernel(const float* __restrict__ Z, float* __restrict__ E, const int N, const int D) {
+    __shared__ __attribute__((aligned(16))) float part[FEW_WAVES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    int ti = 0;
+    {
+        int t = blockIdx.x;                          // tile t of the lower block triangle, row by row
+        while (t > ti) { t -= ti + 1; ++ti; }
+        // (ti, t) = (row tile, column tile)
+        const int tj = t;
+        const float* Zb = Z + (size_t)blockIdx.y * N * D;
+        const int ra = 16 * ti + r16, rb = 16 * tj + r16;
+        const float* pa = Zb + (size_t)ra * D + 4 * q;
+        const float* pb = Zb + (size_t)rb * D + 4 * q;
+        const bool oka = ra < N, okb = rb < N, diag = ti == tj;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int S = (D + 15) >> 4;
+        for (int s0 = wave; s0 < S; s0 += FEW_WAVES * FEW_UNROLL) {
+            float4 a[FEW_UNROLL], b[FEW_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FEW_UNROLL; ++u) {
+                const int s = s0 + u * FEW_WAVES, k = 16 * s + 4 * q;
+                const bool in = s < S && k < D;
+                a[u] = (in && oka) ? *reinterpret_cast<const float4*>(pa + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                b[u] = diag ? a[u] : ((in && okb) ? *reinterpret_cast<const float4*>(pb + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+#pragma unroll
+            for (int u = 0; u < FEW_UNROLL; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+            }
+        }
+        *reinterpret_cast<f32x4*>(&part[wave][lane * 4]) = acc;
+        __syncthreads();
+        if (tid < 256) {
+            // thread = element (row = tid / 16, col = tid % 16) of the tile: accumulator lane (row / 4, col), register row % 4
+            const int row = tid >> 4, col = tid & 15, at = ((row >> 2) * 16 + col) * 4 + (row & 3);
+            float v = part[0][at];
+#pragma unroll
+            for (int w = 1; w < FEW_WAVES; ++w) v += part[w][at];
+            const int gi = 16 * ti + row, gj = 16 * tj + col;
+            float* Eb = E + (size_t)blockIdx.y * N * N;
+            if (gi < N && gj < N) {
+                Eb[(size_t)gi * N + gj] = v;                             // (a diagonal tile is bitwise symmetric: both halves sum the same products in the same order)
+                if (!diag) Eb[(size_t)gj * N + gi] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dkt_sqdist_bwd_f32(const float* W, const float* U, const float* lengthscale, float* Wp,
@@ -372,6 +433,12 @@ extern "C" int dkt_gram_f32(const float* A, const float* Bm, float* E, int B, in
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (sym && kind != DKT_KERNEL_LINEAR && dkt_gram_dist_ep_launch(A, E, B, N, D, kind, lengthscale, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    // a handful of episodes: one workgroup per output tile (the kernels below would leave the chip idle behind one latency chain per episode)
+    if (sym && kind == DKT_KERNEL_LINEAR && N > 32 && dkt_gram_fewep_applies(B, N, D) && !((uintptr_t)A & 15)) {
+        const int nt = (N + 15) / 16;
+        hipLaunchKernelGGL(gram_sym_fewep_kernel, dim3(nt * (nt + 1) / 2, B), dim3(64 * FEW_WAVES), 0, st, A, E, N, D);
+        return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
+    }
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_ep_launch(A, E, B, N, D, unit, st))
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
     if (sym && kind == DKT_KERNEL_LINEAR && dkt_gram_sym_big_launch(A, E, B, N, D, unit, st))

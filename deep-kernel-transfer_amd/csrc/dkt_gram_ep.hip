@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * NT, (2 * NT + 3) / 4) void gram_bwd_ep_f16x2_k
 // Measurement / validation switches: read from the environment ONCE, at the first launch -- not per call.
 // dkt_reload_env() (below, exported for the test-suite and the A/B tools, which flip switches inside one process) re-reads them.
 struct GramEnv {
-    int ep, minb, split, ep_bk, ep_bd, unit_var, split_var, bwd_unit_var, bwd_split_var, bwd_unit_mind, bwd_split_mind;
+    int ep, fewep, minb, split, ep_bk, ep_bd, unit_var, split_var, bwd_unit_var, bwd_split_var, bwd_unit_mind, bwd_split_mind;
     static int get(const char* name, int dflt) {                 // variant switch: twins library only
         const char* v = dkt_variant_env(name);
         return v ? atoi(v) : dflt;
@@ -784,7 +784,7 @@ struct GramEnv {
         return v ? atoi(v) : dflt;
     }
     void load() {
-        ep = get("DKT_GRAM_EP", 1); minb = get_product("DKT_GRAM_EP_MINB", 64); split = get("DKT_GRAM_SPLIT", 1);
+        ep = get("DKT_GRAM_EP", 1); fewep = get("DKT_GRAM_FEWEP", 1); minb = get_product("DKT_GRAM_EP_MINB", 32); split = get("DKT_GRAM_SPLIT", 1);
         ep_bk = get("DKT_GRAM_EP_BK", 64); ep_bd = get("DKT_GRAM_EP_BD", 32);
         // Round 4 (tools/sweep_ep_variants.py + the in-step A/B of tools/r4_run12.sh, profiles/r04/v14_ep_variant_sweep.log): the forward with non-temporal Z loads
         // (22232: -1 % at D = 1600, -5 % at D = 512, -4 % at D = 64 against 2223) and, below D = 1024, the backward with ONE LDS image and prefetch depth 1
@@ -881,6 +881,17 @@ bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool 
         case 8: launch_sym<8>(Z, E, B, N, D, bk, unit, st); return true;
         default: return false;
     }
+}
+
+// Fewer episodes than the episode-resident kernels take (B < DKT_GRAM_EP_MINB = 32): gram_sym_fewep_kernel (dkt_gram.hip), one workgroup per output tile, while
+// those fit the chip at once; the backward stays with the generic tile kernel there.  The threshold is measured with the whole training step (105 x 1600) replayed
+// from a hipGraph (tools/b1_minb_probe.sh, profiles/r06/b1_probe.log): 1 episode 0.086 ms (the generic forward kernel: 0.143), 8: 0.113 against 0.158 with the
+// episode-resident pair, 16: 0.126 / 0.159, 24: 0.143 / 0.160, 32: 0.157 / 0.162.  (Until round 6 the threshold was 64 and the generic kernels served below it:
+// 16 episodes 0.209 ms, 48: 0.245 ms.)
+bool dkt_gram_fewep_applies(int B, int N, int D) {
+    if (gram_env().fewep == 0 || (D & 3) || N > 448) return false;
+    const int nt = (N + 15) / 16;
+    return B < gram_env().minb && (long)B * nt * (nt + 1) / 2 <= 1280;
 }
 
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st) {

@@ -116,7 +116,7 @@ _PRODUCT_SWITCHES = ("DKT_GRAM_EP_MINB", "DKT_MLL_H2E_MINB", "DKT_MLL_TILED_CHUN
 _VARIANT_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRAM_EP_BD", "DKT_GRAM_UNIT_VAR", "DKT_GRAM_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_VAR",
                      "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_TILED_F16", "DKT_GRAM_DIST_EP", "DKT_MLL_P2_GUARD",
                      "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA", "DKT_CLASS_BWD_V4",
-                     "DKT_MLL_TILED_WNW", "DKT_GRAM_SMALL", "DKT_BIG_NB", "DKT_GRAM_BN_F16", "DKT_LDS_STAGE_OLD", "DKT_GRAM_SMALL_WG", "DKT_CLASS_BWD_N128")
+                     "DKT_MLL_TILED_WNW", "DKT_GRAM_SMALL", "DKT_BIG_NB", "DKT_GRAM_BN_F16", "DKT_LDS_STAGE_OLD", "DKT_GRAM_SMALL_WG", "DKT_CLASS_BWD_N128", "DKT_GRAM_FEWEP")
 _ENV_SWITCHES = _PRODUCT_SWITCHES + _VARIANT_SWITCHES
 _env_seen = {}
 
@@ -531,7 +531,7 @@ class _EpisodeLossClassKernelFn(torch.autograd.Function):
         base = gram(z, None, base_kind, one if base_kind == KERNEL_SQDIST else None)
         e = class_kernel(base, cmap, power, param)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
-        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        obj = objective(out["logp"], cls_weight)
         ctx.save_for_backward(z, base, out["w"], param, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.maps = (int(cmap), int(power))
         ctx.shapes = (sv.shape, mean.shape, noise.shape, param.shape)
@@ -553,10 +553,7 @@ class _EpisodeLossClassKernelFn(torch.autograd.Function):
                 dz = gram_bwd(wp, z, gobj)
             if ng[6]:
                 gparam = (gobj.reshape(-1, 1) * dpar).sum(0).reshape(ctx.shapes[3])
-        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[2] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[3] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[4] else None
+        gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ng[2] else None, dmean if ng[3] else None, dnoise if ng[4] else None, ctx.shapes[:3])
         return dz, None, gsv, gmean, gnoise, None, gparam, None, None, None, None, None
 
 
@@ -625,7 +622,7 @@ class _MllObjectiveFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, y, sv, mean, noise, cls_weight, jitter0, max_tries):
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
-        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        obj = objective(out["logp"], cls_weight)
         ctx.save_for_backward(out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
         ctx.mark_non_differentiable(out["logp"], out["alpha"], out["info"], out["jitter"])
@@ -639,11 +636,34 @@ class _MllObjectiveFn(torch.autograd.Function):
         w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         ge = w * gobj.reshape([-1] + [1] * (w.dim() - 1)) if ctx.needs_input_grad[0] else None      # w: [B,N,N] or [B,C,N,N] (per-class E)
-        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)          # [B,C]
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ctx.needs_input_grad[2] else None, dmean if ctx.needs_input_grad[3] else None, dnoise if ctx.needs_input_grad[4] else None, ctx.shapes[:3])
         return ge, None, gsv, gmean, gnoise, None, None, None
+
+
+def objective(logp: torch.Tensor, cls_weight: Optional[torch.Tensor]) -> torch.Tensor:
+    """obj[b] = sum_c cls_weight[c] logp[b,c] (dkt_objective_f32: one launch, fixed order) -- the sum over the class models of SumMarginalLogLikelihood (DKT.py:70-71, 161)."""
+    logp = _req(logp, "logp", 2)
+    b_, c_ = logp.shape
+    cw = None if cls_weight is None else _req(cls_weight.reshape(-1), "cls_weight", 1)
+    obj = torch.empty((b_,), device=logp.device, dtype=torch.float32)
+    with _timed("dkt_objective_f32"):
+        _lib.check(_lib_now().dkt_objective_f32(_p(logp), _p(cw), _p(obj), b_, c_, _stream()), "dkt_objective_f32")
+    return obj
+
+
+def hyper_grads(gobj: torch.Tensor, cls_weight: Optional[torch.Tensor], dsv, dmean, dnoise, shapes):
+    """(g_sv, g_mean, g_noise)[c] = cls_weight[c] sum_b gobj[b] d_x[b,c] for the d_x that are not None (dkt_hyper_grads_f32: ONE launch, fixed summation order),
+    reshaped to `shapes`; None where d_x is None."""
+    gobj = _req(gobj.reshape(-1), "gobj", 1)
+    ds = [None if d is None else _req(d, "d", 2) for d in (dsv, dmean, dnoise)]
+    if all(d is None for d in ds):
+        return None, None, None
+    b_, c_ = next(d for d in ds if d is not None).shape
+    cw = None if cls_weight is None else _req(cls_weight.reshape(-1), "cls_weight", 1)
+    gs = [None if d is None else torch.empty((c_,), device=gobj.device, dtype=torch.float32) for d in ds]
+    with _timed("dkt_hyper_grads_f32"):
+        _lib.check(_lib_now().dkt_hyper_grads_f32(_p(gobj), _p(cw), _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(gs[0]), _p(gs[1]), _p(gs[2]), b_, c_, _stream()), "dkt_hyper_grads_f32")
+    return tuple(None if g is None else g.reshape(sh) for g, sh in zip(gs, shapes))
 
 
 def mll_objective(e, y, sv, mean, noise, cls_weight, jitter0: float = 1e-6, max_tries: int = 3):
@@ -660,7 +680,7 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
     def forward(ctx, z, y, sv, mean, noise, cls_weight, jitter0, max_tries, unit_rows=False):
         e = gram(z, None, KERNEL_LINEAR_UNIT if unit_rows else KERNEL_LINEAR)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
-        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        obj = objective(out["logp"], cls_weight)
         ctx.save_for_backward(z, out["w"], out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape)
         ctx.unit_rows = bool(unit_rows)
@@ -675,10 +695,7 @@ class _EpisodeLossLinearFn(torch.autograd.Function):
         z, w, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         dz = gram_bwd(w, z, gobj, unit_rows=ctx.unit_rows, w_symmetric=True) if ctx.needs_input_grad[0] else None   # W: from dkt_mll_f32
-        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ctx.needs_input_grad[2] else None, dmean if ctx.needs_input_grad[3] else None, dnoise if ctx.needs_input_grad[4] else None, ctx.shapes[:3])
         return dz, None, gsv, gmean, gnoise, None, None, None, None
 
 
@@ -806,10 +823,7 @@ class _EpisodeLossLowRankFn(torch.autograd.Function):
         z, v, t, wd, dsv, dmean, dnoise, cw = ctx.saved_tensors
         gobj = gobj.contiguous()
         dz = _lowrank_backward(z, v, t, wd, gobj) if ctx.needs_input_grad[0] else None
-        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ctx.needs_input_grad[4] else None
+        gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ctx.needs_input_grad[2] else None, dmean if ctx.needs_input_grad[3] else None, dnoise if ctx.needs_input_grad[4] else None, ctx.shapes[:3])
         return dz, None, gsv, gmean, gnoise, None, None, None, None
 
 
@@ -988,7 +1002,7 @@ class _EpisodeLossBnFn(torch.autograd.Function):
                 return o["obj"], o["logp"], o["alpha"], o["info"], o["jitter"], None, bmean, bvar, a, s, rnorm
             e = gram(zn, None, KERNEL_LINEAR_UNIT)
             out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
-            obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+            obj = objective(out["logp"], cls_weight)
             ctx.use_bn = bool(use_bn)
             ctx.save_for_backward(x, zn, out["w"], a, s, bmean, rstd, rnorm, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
             ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
@@ -1008,7 +1022,7 @@ class _EpisodeLossBnFn(torch.autograd.Function):
                 bmean = rstd = bvar = torch.zeros(0, device=x.device, dtype=torch.float32)
             e, rnorm = gram_bn(x, a, s)
         out = mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cls_weight, jitter0=jitter0, max_tries=max_tries)
-        obj = (out["logp"] * cls_weight.reshape(1, -1)).sum(1)
+        obj = objective(out["logp"], cls_weight)
         ctx.use_bn = bool(use_bn)
         ctx.save_for_backward(x, e, out["w"], a, s, bmean, rstd, rnorm, out["dsv"], out["dmean"], out["dnoise"], cls_weight)
         ctx.shapes = (sv.shape, mean.shape, noise.shape, None if gamma is None else gamma.shape, None if beta is None else beta.shape)
@@ -1029,13 +1043,10 @@ class _EpisodeLossBnFn(torch.autograd.Function):
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, bmean, rstd, gobj)
         else:
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, None, None, gobj)
-        gw = gobj.reshape(-1, 1) * cw.reshape(1, -1)
         ng = ctx.needs_input_grad
         ggamma = dg.sum(0).reshape(ctx.shapes[3]) if (dg is not None and ng[1] and ctx.shapes[3] is not None) else None
         gbeta = db.sum(0).reshape(ctx.shapes[4]) if (db is not None and ng[2] and ctx.shapes[4] is not None) else None
-        gsv = (gw * dsv).sum(0).reshape(ctx.shapes[0]) if ng[6] else None
-        gmean = (gw * dmean).sum(0).reshape(ctx.shapes[1]) if ng[7] else None
-        gnoise = (gw * dnoise).sum(0).reshape(ctx.shapes[2]) if ng[8] else None
+        gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ng[6] else None, dmean if ng[7] else None, dnoise if ng[8] else None, ctx.shapes[:3])
         return (dx if ng[0] else None), ggamma, gbeta, None, None, None, gsv, gmean, gnoise, None, None, None
 
 

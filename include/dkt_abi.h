@@ -28,12 +28,13 @@
 extern "C" {
 #endif
 
-#define DKT_ABI_VERSION 5 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
+#define DKT_ABI_VERSION 6 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
                              3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32; \
                              4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
                                           + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_lowrank_* (linear kernels in feature space, D <= 64 < N); \
                              5 (round 6): shared-E calls with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes take ONE band reduction per episode (dkt_mll_band.hip); \
-                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND; the f16-split kernels (N <= 127) are followed by a kappa-aware fix-up launch (DKT_MLL_NO_KAPPA_GUARD) */
+                                          + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND; the f16-split kernels (N <= 127) are followed by a kappa-aware fix-up launch (DKT_MLL_NO_KAPPA_GUARD); \
+                             6 (round 6): + dkt_objective_f32, dkt_hyper_grads_f32 */
 
 /* status codes */
 #define DKT_OK 0
@@ -170,6 +171,21 @@ int dkt_gram_bwd_f32(const float* W, const float* Z, float* dZ, int B, int N, in
  */
 int dkt_rbf_bwd_f32(const float* W, const float* E, const float* lengthscale, float* Wp,
                     float* dlengthscale, int B, int N, void* stream);
+
+/*
+ * dkt_objective_f32 -- the episode's training objective from its class models' log marginal likelihoods:
+ *   obj[b] = sum_c cls_weight[c] * logp[b,c]           (cls_weight NULL = 1)
+ * dkt_hyper_grads_f32 -- chain rule from dkt_mll_f32's raw per-episode, per-class gradients to the [C] parameters:
+ *   g_x[c] = cls_weight[c] * sum_b gobj[b] * d_x[b,c]      x in {sv, mean, noise}; a NULL (d_x, g_x) pair is skipped.
+ * Both in a fixed summation order (bitwise reproducible).  As tensor expressions these are seven launches per training step; the
+ * reference's loop is one episode per step (methods/DKT.py:117-164) and bound by launches.
+ * Replaces: the sum over the class models in `loss = -self.mll(output, self.model.train_targets)` (SumMarginalLogLikelihood over the
+ *   IndependentModelList, methods/DKT.py:70-71, 161) and autograd's accumulation into the C models' outputscale / mean / noise
+ *   parameters (DKT.py:163).
+ */
+int dkt_objective_f32(const float* logp, const float* cls_weight, float* obj, int B, int C, void* stream);
+int dkt_hyper_grads_f32(const float* gobj, const float* cls_weight, const float* dsv, const float* dmean, const float* dnoise,
+                        float* gsv, float* gmean, float* gnoise, int B, int C, void* stream);
 
 /*
  * dkt_sqdist_bwd_f32 -- chain rule of U = |z_i - z_j|^2 / l^2 (DKT_KERNEL_SQDIST; MaternKernel, DKT.py:358-359):

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
         assert hasattr(lib, name), "libdkt_hip.so lacks %s" % name
         assert name in dkt_amd._lib.SIGNATURES, "no ctypes signature for %s" % name
     assert sorted(dkt_amd._lib.SIGNATURES) == declared
-    assert lib.dkt_abi_version() == 5
+    assert lib.dkt_abi_version() == 6
     # pure host queries (no GPU needed)
     assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # register resident
     # N > 127: blocked path, per (episode, class) four N x N matrices + two vectors + bookkeeping
@@ -71,7 +71,7 @@ def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches()
     upath = os.path.join(os.path.dirname(dkt_amd._lib.LIB_PATH), "build", "libdkt_hip.so.resource_usage.json")       # written by the build in this checkout
     if os.path.exists(upath):
         usage = __import__("json").load(open(upath))
-        assert len(usage) <= 240 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
+        assert len(usage) <= 244 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
         assert dkt_amd._lib.check_resources(usage) == []
 
 

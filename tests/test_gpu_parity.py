@@ -32,7 +32,7 @@ def rel_l2(a, b):
 
 
 def test_loaded_native_library(cuda, lib):
-    assert lib.dkt_abi_version() == 5
+    assert lib.dkt_abi_version() == 6
     assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -62,7 +62,7 @@ def test_gram_linear_cross(cuda, b, m, n, d):
     assert np.abs(e - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-6
 
 
-# episode-resident kernels (one workgroup per episode; B >= 64, 64 < N <= 128, D % 4 == 0): every tile count NT = 5..8,
+# episode-resident kernels (one workgroup per episode; B >= 32, 64 < N <= 128, D % 4 == 0): every tile count NT = 5..8,
 # ragged last slices (D % 32 != 0, D % 64 != 0), odd stage counts, both arithmetic routes and every pipeline variant
 EP_SHAPES = [(64, 65, 36), (64, 75, 512), (70, 80, 1024), (64, 96, 100), (64, 105, 1600), (64, 105, 2916), (64, 112, 1056),
              (64, 128, 160), (96, 100, 32)]
@@ -82,10 +82,60 @@ def test_gram_episode_resident_kernels(cuda, b, n, d, split, monkeypatch):
     assert err < tol, (err, tol)
     assert torch.equal(e, e.transpose(1, 2)), "Gram must be exactly symmetric"
     assert torch.equal(e, ops.gram(z)), "deterministic"
-    # the generic tile kernel (B below the episode-kernel threshold) agrees
+    # the tile-per-workgroup kernel (B below the episode-kernel threshold) agrees
     e_gen = ops.gram(z[:2].contiguous())
     gen_err = ((e_gen.double() - ref[:2]).abs() / mag[:2]).max().item()
     assert gen_err < tol, (gen_err, tol)
+
+
+# a handful of episodes (B < 8: the reference's one-episode-per-step loop): one workgroup per 16 x 16 output tile, D over its waves (gram_sym_fewep_kernel);
+# every tile count up to the 20-way episode, ragged D (D % 16 != 0, fewer 16-feature groups than waves), rows beyond N, both linear kinds
+@pytest.mark.parametrize("b,n,d", [(1, 105, 1600), (3, 64, 20), (7, 33, 4), (1, 128, 516), (2, 130, 64), (1, 420, 512), (2, 447, 36), (5, 85, 512), (1, 105, 64)])
+def test_gram_few_episodes_tile_kernel(cuda, b, n, d):
+    g = torch.Generator(device=cuda).manual_seed(n * 11 + d + b)
+    z = torch.randn(b, n, d, generator=g, device=cuda) * torch.exp(1.5 * torch.randn(b, n, d, generator=g, device=cuda))
+    e = ops.gram(z)
+    ref = torch.einsum("bnd,bmd->bnm", z.double(), z.double())
+    mag = torch.einsum("bnd,bmd->bnm", z.double().abs(), z.double().abs())
+    tol = max(1e-6, 6.0 * np.sqrt(d) * 2.0 ** -24)
+    err = ((e.double() - ref).abs() / mag).max().item()
+    assert err < tol, (err, tol)
+    assert torch.equal(e, e.transpose(1, 2)), "Gram must be exactly symmetric"
+    assert torch.equal(e, ops.gram(z)), "deterministic"
+    zn = torch.nn.functional.normalize(z, dim=2)
+    eu = ops.gram(zn, None, ops.KERNEL_LINEAR_UNIT)
+    refu = torch.einsum("bnd,bmd->bnm", zn.double(), zn.double())
+    assert (eu.double() - refu).abs().max().item() < 1e-6
+    # the same episodes inside a batch the episode-resident / large-N kernels take
+    if n <= 128:
+        zb = z.repeat(-(-8 // b), 1, 1).contiguous()
+        eb = ops.gram(zb)
+        assert ((eb[:b].double() - ref).abs() / mag).max().item() < tol
+
+
+@pytest.mark.parametrize("b,c", [(1, 5), (1, 1), (5, 20), (300, 5), (8192, 5), (1000, 32)])
+def test_objective_and_hyper_gradient_reductions(cuda, b, c):
+    g = torch.Generator(device=cuda).manual_seed(b * 31 + c)
+    logp = torch.randn(b, c, generator=g, device=cuda) * 100.0
+    cw = torch.randn(c, generator=g, device=cuda)
+    gobj = torch.randn(b, generator=g, device=cuda)
+    dsv, dmean, dnoise = (torch.randn(b, c, generator=g, device=cuda) for _ in range(3))
+    obj = ops.objective(logp, cw)
+    ref = (logp.double() * cw.double().view(1, c)).sum(1)
+    assert ((obj.double() - ref).abs() / (logp.double().abs() * cw.double().abs().view(1, c)).sum(1)).max().item() < 1e-6
+    assert torch.equal(ops.objective(logp, None), ops.objective(logp, torch.ones(c, device=cuda)))
+    shapes = (torch.Size([c]), torch.Size([c, 1]), torch.Size([1, c]))
+    gs = ops.hyper_grads(gobj, cw, dsv, dmean, dnoise, shapes)
+    for gx, dx, sh in zip(gs, (dsv, dmean, dnoise), shapes):
+        assert gx.shape == sh
+        r = cw.double() * (gobj.double().view(b, 1) * dx.double()).sum(0)
+        mag = cw.double().abs() * (gobj.double().abs().view(b, 1) * dx.double().abs()).sum(0)
+        assert ((gx.double().reshape(-1) - r).abs() / mag).max().item() < 1e-6 * max(1.0, np.log2(b))
+    again = ops.hyper_grads(gobj, cw, dsv, dmean, dnoise, shapes)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(gs, again)), "fixed summation order"
+    only = ops.hyper_grads(gobj, cw, None, dmean, None, shapes)
+    assert only[0] is None and only[2] is None and torch.equal(only[1], gs[1])
+    assert ops.hyper_grads(gobj, cw, None, None, None, shapes) == (None, None, None)
 
 
 @pytest.mark.parametrize("var", ["11", "12", "21", "22", "611", "612"])
