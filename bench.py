@@ -480,14 +480,22 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
     return res
 
 
+GLUE_KERNELS = ("dkt_objective_f32", "dkt_hyper_grads_f32")
+
+
 def _algorithmic(cfg, n, d, c, unit_rows, lowrank=False):
     """Algorithmic bytes / flops per EPISODE, per ABI kernel of the step; `exec_f16`: the f16 MFMA flops the split Gram
     kernels actually execute (lower 16 x 16 tiles x 3 products of the scaled 2-way split; 6 for the bf16 split).
     `lowrank` (D <= 64 < N, ops.lowrank_applies): the step is dkt_lowrank_gram_f32 -> dkt_mll_f32 on the 64 x 64 models -> dkt_lowrank_finish_f32 ->
     dkt_lowrank_bwd_f32; its bytes are what those calls have to move (Z three times, dZ once, the 64 x 64 matrices A and W' once each way)."""
+    glue = {   # the two [B, C]-sized reductions around the marginal likelihood (dkt_objective.hip): launches, no bytes to speak of
+        "dkt_objective_f32": dict(bytes=4 * (c + 1), flops=2 * c, exec_f16=None),
+        "dkt_hyper_grads_f32": dict(bytes=4 * (2 * c + 1), flops=4 * c, exec_f16=None),
+    }
     if lowrank:
         dp = 64
         return {
+            **glue,
             "dkt_lowrank_gram_f32": dict(bytes=4 * (n * d + dp * dp + c * dp), flops=2 * n * d * (d + c), exec_f16=None),
             "dkt_mll_f32": dict(bytes=4 * (2 * dp * dp + 3 * c * dp), flops=c * (dp ** 3 // 3 + 2 * dp * dp + dp ** 3), exec_f16=None),
             "dkt_lowrank_finish_f32": dict(bytes=4 * (n * d + c * dp + 2 * c * n), flops=2 * n * d * c, exec_f16=None),
@@ -496,6 +504,7 @@ def _algorithmic(cfg, n, d, c, unit_rows, lowrank=False):
     nt16 = (n + 15) // 16
     nprod = 3 if unit_rows else 6
     alg = {
+        **glue,
         "dkt_gram_f32": dict(bytes=4 * (n * d + n * n), flops=2 * n * n * d,
                              exec_f16=(nt16 * (nt16 + 1) // 2) * nprod * 2 * 256 * d if (n <= 128 and cfg != "cfg0") else None),
         "dkt_mll_f32": dict(bytes=4 * (2 * n * n + 3 * c * n), flops=c * (n ** 3 // 3 + 2 * n * n + n ** 3), exec_f16=None),
@@ -506,7 +515,7 @@ def _algorithmic(cfg, n, d, c, unit_rows, lowrank=False):
     return alg
 
 
-def _measure(cfg, b, args, dev, rank, world, bucket_fn, unit_rows, min_blocks, min_total, steps):
+def _measure(cfg, b, args, dev, rank, world, bucket_fn, unit_rows, min_blocks, min_total, steps, ktime=True):
     """Warm-up, then blocks of EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (MAX over ranks), at least
     `min_blocks` blocks and `min_total` seconds; per-kernel HIP-event times from the same blocks.  Returns the measurement dict."""
     from dkt_amd import ops
@@ -530,7 +539,7 @@ def _measure(cfg, b, args, dev, rank, world, bucket_fn, unit_rows, min_blocks, m
     sync()
     blocks, total, ktimes_all = [], 0.0, {}
     while len(blocks) < min_blocks or (total < min_total and len(blocks) < 50):
-        ops.kernel_timing(True)
+        ops.kernel_timing(ktime)                 # (two HIP events per ABI call: ~ 10 us of host time each -- off for the launch-bound small-batch rows)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -863,9 +872,13 @@ def run(args):
         sweep = {}
         for bs in (1, 64, 1024):
             ss = 50 if bs <= 64 else 20
-            ms_ = _measure(args.config, bs, args, dev, rank, world, lambda st_: None, UNIT_ROWS, 3, 0.0, ss)
-            sweep[str(bs)] = {"value": round(bs * ss / ms_["dt"], 1), "ms_per_step": round(1e3 * ms_["dt"] / ss, 4),
-                              "launches_per_step": round(sum(cnt for cnt, _ in ms_["ktimes"].values()) / (ss * len(ms_["blocks"])), 2), "valid": ms_["valid"]}
+            ms_ = _measure(args.config, bs, args, dev, rank, world, lambda st_: None, UNIT_ROWS, 5, 0.0, ss, ktime=False)
+            ops.kernel_timing(True)              # the ABI calls of one step, counted apart from the timed blocks
+            ms_["step"]()
+            torch.cuda.synchronize()
+            nl = sum(cnt for cnt, _ in ops.kernel_timing_results().values())
+            ops.kernel_timing(False)
+            sweep[str(bs)] = {"value": round(bs * ss / ms_["dt"], 1), "ms_per_step": round(1e3 * ms_["dt"] / ss, 4), "launches_per_step": nl, "valid": ms_["valid"]}
             del ms_
             if bs <= 64:
                 # the same step captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed: the launch-bound small-batch step without the per-step Python / autograd
@@ -1018,7 +1031,7 @@ def _line_of(out):
                                 "dtype", "data", "config", "timing", "valid", "deterministic")}
     line["roofline"] = _compact_roof(out["roofline"])
     line["roofline_gram_build"] = _compact_roof(out["roofline_gram_build"])
-    line["kernels_ms"] = {k: v["ms"] for k, v in out["kernels"].items()}
+    line["kernels_ms"] = {k: v["ms"] for k, v in out["kernels"].items() if k not in GLUE_KERNELS}          # (the [B, C]-sized reductions: in the detail file)
     line["collective"] = {k: out["collective"][k] for k in ("bytes", "allreduce_ms", "backend", "ranks", "pack_copies_last_step")}
     if "other_configs" in out:
         line["other_configs"] = {cfg: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
@@ -1026,7 +1039,7 @@ def _line_of(out):
     for key in ("other_paths_cfg2", "other_paths_cfg4", "other_paths_cfg1"):
         if key in out:
             line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
-                                "kernels_ms": o["kernels_ms"],
+                                "kernels_ms": {k: v for k, v in o["kernels_ms"].items() if k not in GLUE_KERNELS},
                                 # per kernel: algorithmic bytes / HIP-event time / 8 TB/s (the full roofline objects are in the detail file)
                                 **({"hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}} if "roofline" in o else {}),
                                 **({"traffic_x": {k: r["traffic_over_algorithmic"] for k, r in o["roofline"].items() if "traffic_over_algorithmic" in r}}

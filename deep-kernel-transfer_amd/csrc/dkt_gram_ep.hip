@@ -889,9 +889,8 @@ bool dkt_gram_sym_ep_launch(const float* Z, float* E, int B, int N, int D, bool 
 // episode-resident pair, 16: 0.126 / 0.159, 24: 0.143 / 0.160, 32: 0.157 / 0.162.  (Until round 6 the threshold was 64 and the generic kernels served below it:
 // 16 episodes 0.209 ms, 48: 0.245 ms.)
 bool dkt_gram_fewep_applies(int B, int N, int D) {
-    if (gram_env().fewep == 0 || (D & 3) || N > 448) return false;
-    const int nt = (N + 15) / 16;
-    return B < gram_env().minb && (long)B * nt * (nt + 1) / 2 <= 1280;
+    // (N <= 128: the range of the episode-resident kernels it stands in for; larger episodes keep the 64 x 64-tile kernels of dkt_gram_big.hip at every batch)
+    return gram_env().fewep != 0 && (D & 3) == 0 && N <= 128 && B < gram_env().minb;
 }
 
 bool dkt_gram_bwd_ep_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, bool unit, hipStream_t st) {

@@ -642,6 +642,8 @@ class _MllObjectiveFn(torch.autograd.Function):
 
 def objective(logp: torch.Tensor, cls_weight: Optional[torch.Tensor]) -> torch.Tensor:
     """obj[b] = sum_c cls_weight[c] logp[b,c] (dkt_objective_f32: one launch, fixed order) -- the sum over the class models of SumMarginalLogLikelihood (DKT.py:70-71, 161)."""
+    if os.environ.get("DKT_FUSED_REDUCTIONS", "1") == "0":                 # the tensor expressions (their twin; three launches)
+        return logp.sum(1) if cls_weight is None else (logp * cls_weight.reshape(1, -1)).sum(1)
     logp = _req(logp, "logp", 2)
     b_, c_ = logp.shape
     cw = None if cls_weight is None else _req(cls_weight.reshape(-1), "cls_weight", 1)
@@ -654,6 +656,9 @@ def objective(logp: torch.Tensor, cls_weight: Optional[torch.Tensor]) -> torch.T
 def hyper_grads(gobj: torch.Tensor, cls_weight: Optional[torch.Tensor], dsv, dmean, dnoise, shapes):
     """(g_sv, g_mean, g_noise)[c] = cls_weight[c] sum_b gobj[b] d_x[b,c] for the d_x that are not None (dkt_hyper_grads_f32: ONE launch, fixed summation order),
     reshaped to `shapes`; None where d_x is None."""
+    if os.environ.get("DKT_FUSED_REDUCTIONS", "1") == "0":                 # the tensor expressions (their twin; a multiply + two launches per parameter)
+        gw = gobj.reshape(-1, 1) * (1.0 if cls_weight is None else cls_weight.reshape(1, -1))
+        return tuple(None if d is None else (gw * d).sum(0).reshape(sh) for d, sh in zip((dsv, dmean, dnoise), shapes))
     gobj = _req(gobj.reshape(-1), "gobj", 1)
     ds = [None if d is None else _req(d, "d", 2) for d in (dsv, dmean, dnoise)]
     if all(d is None for d in ds):
