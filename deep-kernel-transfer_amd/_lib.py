@@ -204,6 +204,24 @@ def _compile_link(sources, target, replace=None, verbose=False, twins: bool = Fa
     os.replace(target + ".tmp", target)
     with open(target + ".stamp", "w") as fh:
         fh.write(_stamp(sources, replace, twins))
+    if replace is None:
+        # superseded objects of these sources (a header edit re-hashes every file: the cache would otherwise grow by ~ 20 MB per edit); kept: what the three
+        # in-tree libraries were last linked from (this link's objects + whatever the other libraries' lists name)
+        keep_path = os.path.join(OBJ_DIR, os.path.basename(target) + ".objects.json")
+        with open(keep_path, "w") as fh:
+            json.dump([os.path.basename(o) for o in objs], fh)
+        keep = set()
+        for f in os.listdir(OBJ_DIR):
+            if f.endswith(".objects.json"):
+                with open(os.path.join(OBJ_DIR, f)) as fh:
+                    keep.update(json.load(fh))
+        for f in os.listdir(OBJ_DIR):
+            base = f[:-len(".res.json")] if f.endswith(".res.json") else f
+            if base.endswith(".o") and base not in keep and any(base.startswith(src + ".") for src in SOURCES + DIAG_SOURCES):
+                try:
+                    os.remove(os.path.join(OBJ_DIR, f))
+                except OSError:
+                    pass
     return target
 
 

@@ -114,7 +114,7 @@ def test_gram_few_episodes_tile_kernel(cuda, b, n, d):
 
 
 @pytest.mark.parametrize("b,c", [(1, 5), (1, 1), (5, 20), (300, 5), (8192, 5), (1000, 32)])
-def test_objective_and_hyper_gradient_reductions(cuda, b, c):
+def test_objective_and_hyper_gradient_reductions(cuda, b, c, monkeypatch):
     g = torch.Generator(device=cuda).manual_seed(b * 31 + c)
     logp = torch.randn(b, c, generator=g, device=cuda) * 100.0
     cw = torch.randn(c, generator=g, device=cuda)
@@ -136,6 +136,11 @@ def test_objective_and_hyper_gradient_reductions(cuda, b, c):
     only = ops.hyper_grads(gobj, cw, None, dmean, None, shapes)
     assert only[0] is None and only[2] is None and torch.equal(only[1], gs[1])
     assert ops.hyper_grads(gobj, cw, None, None, None, shapes) == (None, None, None)
+    monkeypatch.setenv("DKT_FUSED_REDUCTIONS", "0")                       # the tensor expressions they replace
+    tw = ops.hyper_grads(gobj, cw, dsv, dmean, dnoise, shapes)
+    for gx, tx in zip(gs, tw):
+        assert tx.shape == gx.shape and ((gx - tx).abs().max() / tx.abs().max()).item() < 1e-5
+    assert ((ops.objective(logp, cw) - obj).abs().max() / obj.abs().max()).item() < 1e-6
 
 
 @pytest.mark.parametrize("var", ["11", "12", "21", "22", "611", "612"])
