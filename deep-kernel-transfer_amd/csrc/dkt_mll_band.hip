@@ -156,20 +156,31 @@ __device__ __forceinline__ int lslot(const int i, const int j) { return (i * (i 
 #define BCLK(i) do { } while (0)
 #endif
 
-// Sums of 16 per-lane values over the 64 lanes of a wave with 17 exchanges instead of 16 full reductions: every stage halves the values a lane carries (it keeps the
-// half its lane bit selects and adds the partner's copy of that half).  On return lane l holds the total of value index 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l).
+// Sums of 16 per-lane values over the 64 lanes of a wave as a reduce-scatter: every stage halves the values a lane carries (it keeps the half its lane bit selects
+// and adds the partner's copy of that half).  On return lane l holds the total of value index 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l).  All on the VALU:
+// lane bits 5 / 4 with v_permlane32_swap / v_permlane16_swap on PAIRS of values (one swap + one add per output), bit 3 with row_ror:8, bit 2 with
+// row_half_mirror (partner l ^ 7: the same bits 3..5, and bits 0 / 1 are summed afterwards anyway), bits 1 / 0 with quad_perm.  (As __shfl_xor it was 17
+// ds_bpermute_b32 -- six dependent trips through the LDS crossbar per QR column, and six lane-address registers alive across the whole kernel.)
 __device__ __forceinline__ float wave_sum16(const float (&v)[16], const int lane) {
-    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
+    const bool h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
     float a[8], b[4], c[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = (h5 ? v[8 + i] : v[i]) + __shfl_xor(h5 ? v[i] : v[8 + i], 32, DKT_WAVE);
+    for (int i = 0; i < 8; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[8 + i]), false, false);
+        a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = (h4 ? a[4 + i] : a[i]) + __shfl_xor(h4 ? a[i] : a[4 + i], 16, DKT_WAVE);
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[4 + i]), false, false);
+        b[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#define DKT_BDPP(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false))
 #pragma unroll
-    for (int i = 0; i < 2; ++i) c[i] = (h3 ? b[2 + i] : b[i]) + __shfl_xor(h3 ? b[i] : b[2 + i], 8, DKT_WAVE);
-    float d = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, DKT_WAVE);
-    d += __shfl_xor(d, 2, DKT_WAVE);
-    d += __shfl_xor(d, 1, DKT_WAVE);
+    for (int i = 0; i < 2; ++i) c[i] = (h3 ? b[2 + i] : b[i]) + DKT_BDPP(h3 ? b[i] : b[2 + i], 0x128);     // row_ror:8 = lane ^ 8
+    float d = (h2 ? c[1] : c[0]) + DKT_BDPP(h2 ? c[0] : c[1], 0x141);                                     // row_half_mirror = lane ^ 7
+    d += DKT_BDPP(d, 0x4E);                                                                               // quad_perm [2, 3, 0, 1]
+    d += DKT_BDPP(d, 0xB1);                                                                               // quad_perm [1, 0, 3, 2]
+#undef DKT_BDPP
     return d;
 }
 
