@@ -614,155 +614,6 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
             BCLK(5);
         }
     }
-    if constexpr (BACK) {
-        // ---- W[b] row-major (both triangles from the stored one), alpha[b, c, :] = a_c / sv_c ----
-        const int b = t.b0 + bl;
-        if (t.grad) {
-            float* Wb = t.a.W + (size_t)b * N * N;
-            f32x4 hiden;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hiden[q] = (g4 + q == c16) ? 0.5f : 0.f;
-            const bool wvec = (N & 3) == 0;
-            const int ntt = NT * (NT + 1) / 2;
-            int ti = 0, tj = wave;                                                         // the wave's slots wave, wave + 4, ...: (ti, tj) walks along with the slot
-            while (tj > ti) { tj -= ti + 1; ++ti; }
-            for (int s0 = wave; s0 < ntt; s0 += 16) {                                      // four tiles in flight
-                f32x4 wv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) wv[u] = bload4(Ar, lane16, (s0 + 4 * u < ntt) ? (s0 + 4 * u) * 1024 : OOB);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (s0 + 4 * u < ntt) {
-                        const int i = ti, j = tj;
-                        f32x4 w = wv[u];
-                        if (i == j) w = xty(w, hiden, 0.5f * w);                           // a diagonal tile carries both halves: 0.5 (M_ii + M_ii^T), bitwise symmetric
-                        // tile (i, j)[4g + q][c] = W[16i + 4g + q][16j + c] and, W being symmetric, = W[16j + c][16i + 4g + q]
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int r2 = 16 * i + g4 + q, c2 = 16 * j + c16;
-                            if (r2 < N && c2 < N) Wb[(size_t)r2 * N + c2] = w[q];
-                        }
-                        if (i != j) {                                                      // the mirror: 16 bytes per lane into row 16j + c
-                            const int row = 16 * j + c16, col = 16 * i + g4;
-                            if (row < N) {
-                                if (wvec && col + 3 < N) st4(Wb + (size_t)row * N + col, w);
-                                else {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q)
-                                        if (col + q < N) Wb[(size_t)row * N + col + q] = w[q];
-                                }
-                            }
-                        }
-                        tj += 4;
-                        while (tj > ti) { tj -= ti + 1; ++ti; }
-                    }
-                }
-            }
-        }
-        BCLK(10);
-        for (int u = wave; u < NT * CP; u += 4) {
-            const int i = u / CP, p = u - i * CP;
-            const int cls = 16 * p + c16;
-            if (cls < G.C) {
-                const f32x4 a = ld4(Ut + (size_t)u * 256 + lane * 4);
-                const float rs = 1.0f / t.a.sv[cls];
-                float* al = t.a.alpha + ((size_t)b * G.C + cls) * N;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 16 * i + g4 + q;
-                    if (r < N) al[r] = a[q] * rs;
-                }
-            }
-        }
-        BCLK(11);
-        // ---- the quadratic form against the ORIGINAL matrix.  The reduction's backward error (a few eps |E|) moves the small eigenvalues of K_c by a relative
-        //      eps |E| sv / noise, which the quadratic form r^T K^-1 r feels in full (the log-determinant averages it out: measured 1e-6 against 3e-5 ... 9e-5 on
-        //      class-correlated features, tools/band_mll_model.py).  With the residual rho = r - K alpha of the computed alpha, r^T K^-1 r = (r + rho)^T alpha up to
-        //      second order: one product E a~ per episode (a~ = sv alpha, in A's tiles) restores the accuracy of a direct factorisation. ----
-        {
-            const brsrc Er = mk_rsrc(t.a.E + (size_t)b * N * N, (unsigned)((size_t)N * N * 4));
-            const bool vec_ok = (N & 3) == 0;
-            float qp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // per class column: (2r - E a~ - mu a~).a~,  a~.E a~,  a~.a~,  sum a~
-            for (int i = wave; i < NT; i += 4) {
-                f32x4 ea[2] = {ZERO4, ZERO4};
-                // tile (j, i) of E in the accumulator layout: element [4g + q][c] = E[16j + 4g + q][16i + c] = E[16i + c][16j + 4g + q]; three tiles in flight
-                auto etile = [&](const int j) {
-                    const int row = 16 * i + c16, col = 16 * j + g4;
-                    f32x4 e;
-                    if (vec_ok) {
-                        e = bload4(Er, (j < NT && row < N && col < N) ? (row * N + col) * 4 : OOB, 0);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            e[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Er, (j < NT && row < N && col + q < N) ? (row * N + col + q) * 4 : OOB, 0, 0));
-                    }
-                    return e;
-                };
-                f32x4 e0 = etile(0), e1 = etile(1), e2 = etile(2);
-                for (int j = 0; j < NT; j += 3) {
-                    const f32x4 c0 = e0, c1 = e1, c2 = e2;
-                    e0 = etile(j + 3); e1 = etile(j + 4); e2 = etile(j + 5);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        if (p < CP) {
-                            ea[p] = xty(c0, ld4(Ut + ((size_t)j * CP + p) * 256 + lane * 4), ea[p]);
-                            if (j + 1 < NT) ea[p] = xty(c1, ld4(Ut + ((size_t)(j + 1) * CP + p) * 256 + lane * 4), ea[p]);
-                            if (j + 2 < NT) ea[p] = xty(c2, ld4(Ut + ((size_t)(j + 2) * CP + p) * 256 + lane * 4), ea[p]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int cls = 16 * p + c16;
-                    if (p < CP && cls < G.C) {
-                        const f32x4 a = ld4(Ut + ((size_t)i * CP + p) * 256 + lane * 4);
-                        const float mu = t.a.noise[cls] / t.a.sv[cls], mc = t.a.mean[cls];
-                        const float* yc = t.a.Y + (size_t)b * t.a.y_bstride + (size_t)cls * N;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int r = 16 * i + g4 + q;
-                            if (r < N) {
-                                qp[p][0] += (2.0f * (yc[r] - mc) - ea[p][q] - mu * a[q]) * a[q];
-                                qp[p][1] += ea[p][q] * a[q];
-                                qp[p][2] += a[q] * a[q];
-                                qp[p][3] += a[q];
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    qp[p][v] += __shfl_xor(qp[p][v], 16, DKT_WAVE);
-                    qp[p][v] += __shfl_xor(qp[p][v], 32, DKT_WAVE);
-                }
-            __syncthreads();
-            if (lane < 16) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) L.Part[wave * 128 + v * 32 + 16 * p + lane] = qp[p][v];
-            }
-            __syncthreads();
-            if (tid < G.C) {
-                float sum[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sum[v] = L.Part[v * 32 + tid] + L.Part[128 + v * 32 + tid] + L.Part[256 + v * 32 + tid] + L.Part[384 + v * 32 + tid];
-                const size_t bc = (size_t)b * G.C + tid;
-                const float sv = t.a.sv[tid], rs = 1.0f / sv, mu = t.a.noise[tid] * rs;
-                const float quad = sum[0] * rs;
-                if (t.grad) {
-                    const float trz = t.a.dnoise[bc];                          // tr (B + mu)^-1 from the class kernel (NaN for a failed class)
-                    t.a.dsv[bc] = 0.5f * (sum[1] * rs * rs - ((float)N - mu * trz) * rs);      // tr(M E), M = 0.5 (alpha alpha^T - K^-1):  alpha^T E alpha - tr(K^-1 E)
-                    t.a.dnoise[bc] = 0.5f * (sum[2] * rs * rs - trz * rs);
-                    t.a.dmean[bc] = sum[3] * rs;
-                }
-                t.a.logp[(size_t)b * G.C + tid] -= 0.5f * quad;            // the class kernel left -0.5 log det - N/2 log 2 pi there (NaN for a failed class)
-            }
-        }
-    }
 #ifdef DKT_BAND_CLOCKS
     // measurement build (tools/band_phase_clocks.py): thread 0's accumulated s_memtime ticks per phase, reported through alpha[b, 0 / 1, 0..7] (overwriting it)
     __syncthreads();
@@ -777,6 +628,187 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
         }
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// After the back transform: W[b], alpha[b], the quadratic form and the hyper-gradients.  Kernels of their own: these are streams (705 KB of W out, 705 KB of E in
+// per 420-row episode) which, as the tail of band_sym_kernel<true>, ran at that kernel's two workgroups per CU and in 64-byte pieces (a 16 x 16 tile touches 16 rows)
+// -- 17 % of its time (profiles/r06/band_v11_phase_clocks.log).  Here a workgroup owns ONE 16-row stripe of the episode: the stripe of E comes in and the stripe of W
+// goes out as whole rows through a [16][NP + 4] image in LDS; the tiles are read from / written to the image in the accumulator layout.
+//   quadratic form against the ORIGINAL matrix: the reduction's backward error (a few eps |E|) moves the small eigenvalues of K_c by a relative eps |E| sv / noise,
+//   which r^T K^-1 r feels in full (the log-determinant averages it out: measured 1e-6 against 3e-5 ... 9e-5 on class-correlated features, tools/band_mll_model.py).
+//   With the residual rho = r - K alpha of the computed alpha, r^T K^-1 r = (r + rho)^T alpha up to second order: one product E a~ per episode (a~ = sv alpha, in A's
+//   tiles) restores the accuracy of a direct factorisation.  The stripes' partial sums meet in band_reduce_kernel in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int fin_lds_floats(const int NT) { return 16 * (16 * NT + 4) + 4 * 2 * 256; }
+
+__global__ __launch_bounds__(256, 4) void band_finish_kernel(BandArgs t) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const BandGeo& G = t.g;
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = (lane >> 2) & 12;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = G.NT, NP = 16 * NT, N = G.N, CP = G.CP, SLD = NP + 4;
+    const int i = blockIdx.x, bl = blockIdx.y, b = t.b0 + bl;
+    float* ep = t.ws + (size_t)bl * G.ep_floats;
+    const float* Ut = ep + G.oAm;
+    const brsrc Ar = mk_rsrc(ep + G.oA, (unsigned)((size_t)NT * (NT + 1) / 2 * 1024));
+    const int lane16 = lane * 16;
+    float* S = smem;                       // [16][SLD]
+    float* Red = smem + 16 * SLD;          // [4 waves][2][256]
+    const bool vec = (N & 3) == 0;
+    constexpr int MAXT = (BAND_MAXNT + 3) / 4, MAXQ = (16 * 4 * BAND_MAXNT + 255) / 256;       // tiles per wave; 16-byte pieces of the stripe per thread
+    // Every memory request of a phase is issued before the first use (a loop of load -> store pairs is one memory round trip per trip: measured, 0.64 ms per 1024
+    // episodes of 420 rows for 1.8 GB); absent pieces read an offset the descriptor rejects.
+    // ---- rows 16 i .. 16 i + 15 of E -> the image (zero beyond N); the W stripe's tiles (i, j <= i) / (j > i, i) requested alongside ----
+    f32x4 wv[MAXT];
+    {
+        const float* Eb = t.a.E + (size_t)b * N * N;
+        if (vec) {
+            const brsrc Er = mk_rsrc(Eb, (unsigned)((size_t)N * N * 4));
+            const int q4 = NP >> 2;
+            f32x4 ev[MAXQ];
+#pragma unroll
+            for (int u = 0; u < MAXQ; ++u) {
+                const int idx = tid + 256 * u, rr = idx / q4, col = 4 * (idx - rr * q4), r = 16 * i + rr;
+                ev[u] = bload4(Er, (rr < 16 && r < N && col < N) ? (r * N + col) * 4 : OOB, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                const int j = wave + 4 * u;
+                wv[u] = bload4(Ar, lane16, (t.grad && j < NT) ? (j <= i ? lslot(i, j) : lslot(j, i)) * 1024 : OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXQ; ++u) {
+                const int idx = tid + 256 * u, rr = idx / q4, col = 4 * (idx - rr * q4);
+                if (rr < 16) st4(S + rr * SLD + col, ev[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                const int j = wave + 4 * u;
+                wv[u] = bload4(Ar, lane16, (t.grad && j < NT) ? (j <= i ? lslot(i, j) : lslot(j, i)) * 1024 : OOB);
+            }
+            for (int idx = tid; idx < 16 * NP; idx += 256) {
+                const int rr = idx / NP, col = idx - rr * NP, r = 16 * i + rr;
+                S[rr * SLD + col] = (r < N && col < N) ? Eb[(size_t)r * N + col] : 0.f;
+            }
+        }
+    }
+    // ---- (E a~) for the stripe: tile (j, i) of E in the accumulator layout, element [4g + q][c] = E[16j + 4g + q][16i + c] = E[16i + c][16j + 4g + q] ----
+    {
+        const brsrc Ur = mk_rsrc(Ut, (unsigned)(NT * CP * 1024));
+        f32x4 ut[MAXT][2];
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) ut[u][p] = bload4(Ur, lane16, (wave + 4 * u < NT && p < CP) ? ((wave + 4 * u) * CP + p) * 1024 : OOB);
+        __syncthreads();
+        f32x4 ea[2] = {ZERO4, ZERO4};
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wave + 4 * u;
+            if (j < NT) {
+                const f32x4 e = ld4(S + c16 * SLD + 16 * j + g4);
+                ea[0] = xty(e, ut[u][0], ea[0]);
+                if (CP > 1) ea[1] = xty(e, ut[u][1], ea[1]);
+            }
+        }
+        st4(Red + (wave * 2 + 0) * 256 + lane * 4, ea[0]);
+        st4(Red + (wave * 2 + 1) * 256 + lane * 4, ea[1]);
+    }
+    __syncthreads();
+    if (wave < CP) {                                           // wave p: class column p of the stripe
+        const int p = wave, cls = 16 * p + c16;
+        const f32x4 eap = (ld4(Red + (0 + p) * 256 + lane * 4) + ld4(Red + (2 + p) * 256 + lane * 4)) + (ld4(Red + (4 + p) * 256 + lane * 4) + ld4(Red + (6 + p) * 256 + lane * 4));
+        float qp[4] = {0.f, 0.f, 0.f, 0.f};                   // per class: (2r - E a~ - mu a~).a~,  a~.E a~,  a~.a~,  sum a~
+        if (cls < G.C) {
+            const f32x4 a = ld4(Ut + ((size_t)i * CP + p) * 256 + lane * 4);
+            const float sv = t.a.sv[cls], rs = 1.0f / sv, mu = t.a.noise[cls] * rs, mc = t.a.mean[cls];
+            const float* yc = t.a.Y + (size_t)b * t.a.y_bstride + (size_t)cls * N;
+            float* al = t.a.alpha + ((size_t)b * G.C + cls) * N;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * i + g4 + q;
+                if (r < N) {
+                    al[r] = a[q] * rs;                         // alpha[b, c, :] = a_c / sv_c
+                    qp[0] += (2.0f * (yc[r] - mc) - eap[q] - mu * a[q]) * a[q];
+                    qp[1] += eap[q] * a[q];
+                    qp[2] += a[q] * a[q];
+                    qp[3] += a[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            qp[v] += __shfl_xor(qp[v], 16, DKT_WAVE);
+            qp[v] += __shfl_xor(qp[v], 32, DKT_WAVE);
+        }
+        if (lane < 16) {
+            float* part = ep + G.oG + (size_t)i * 128;        // (the G tiles are dead by now) [stripe][4][32]
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part[v * 32 + 16 * p + lane] = qp[v];
+        }
+    }
+    if (!t.grad) return;                                       // uniform
+    __syncthreads();
+    // ---- the stripe of W: tiles (i, j <= i) as stored, tiles (j > i, i) transposed, the diagonal tile symmetrised; then whole rows out ----
+    {
+        f32x4 hiden;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hiden[q] = (g4 + q == c16) ? 0.5f : 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int j = wave + 4 * u;
+            if (j < NT) {
+                f32x4 w = wv[u];
+                if (j == i) w = xty(w, hiden, 0.5f * w);       // a diagonal tile carries both halves: 0.5 (M_ii + M_ii^T), bitwise symmetric
+                if (j <= i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) S[(g4 + q) * SLD + 16 * j + c16] = w[q];
+                } else {
+                    st4(S + c16 * SLD + 16 * j + g4, w);      // tile (j, i)[4g + q][c] = W[16i + c][16j + 4g + q]
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        float* Wb = t.a.W + (size_t)b * N * N;
+        if (vec) {
+            const int q4 = N >> 2;
+            for (int idx = tid; idx < 16 * q4; idx += 256) {
+                const int rr = idx / q4, col = 4 * (idx - rr * q4), r = 16 * i + rr;
+                if (r < N) st4(Wb + (size_t)r * N + col, ld4(S + rr * SLD + col));
+            }
+        } else {
+            for (int idx = tid; idx < 16 * N; idx += 256) {
+                const int rr = idx / N, col = idx - rr * N, r = 16 * i + rr;
+                if (r < N) Wb[(size_t)r * N + col] = S[rr * SLD + col];
+            }
+        }
+    }
+}
+
+// the stripes' partial sums -> logp, dsv, dnoise, dmean; one wave per episode
+__global__ __launch_bounds__(64) void band_reduce_kernel(BandArgs t) {
+    const BandGeo& G = t.g;
+    const int tid = threadIdx.x, bl = blockIdx.x, b = t.b0 + bl, N = G.N;
+    if (tid >= G.C) return;
+    const float* part = t.ws + (size_t)bl * G.ep_floats + G.oG;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < G.NT; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sum[v] += part[(size_t)i * 128 + v * 32 + tid];
+    const size_t bc = (size_t)b * G.C + tid;
+    const float sv = t.a.sv[tid], rs = 1.0f / sv, mu = t.a.noise[tid] * rs;
+    const float quad = sum[0] * rs;
+    if (t.grad) {
+        const float trz = t.a.dnoise[bc];                          // tr (B + mu)^-1 from the class kernel (NaN for a failed class)
+        t.a.dsv[bc] = 0.5f * (sum[1] * rs * rs - ((float)N - mu * trz) * rs);      // tr(M E), M = 0.5 (alpha alpha^T - K^-1):  alpha^T E alpha - tr(K^-1 E)
+        t.a.dnoise[bc] = 0.5f * (sum[2] * rs * rs - trz * rs);
+        t.a.dmean[bc] = sum[3] * rs;
+    }
+    t.a.logp[bc] -= 0.5f * quad;                                   // the class kernel left -0.5 log det - N/2 log 2 pi there (NaN for a failed class)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
@@ -1116,6 +1148,10 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
         hipLaunchKernelGGL(band_class_kernel, dim3(bcnt, (a.C + 3) / 4), dim3(256), 0, st, t);
         if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt), dim3(64 * CHAIN_WAVES), 4 * BAND_MAXNT * 1024, st, t);
         hipLaunchKernelGGL(band_sym_kernel<true>, dim3(bcnt), dim3(256), lds, st, t);
+#ifndef DKT_BAND_CLOCKS                       // (the measurement build reports its phase clocks through alpha)
+        hipLaunchKernelGGL(band_finish_kernel, dim3(NT, bcnt), dim3(256), fin_lds_floats(NT) * sizeof(float), st, t);
+        hipLaunchKernelGGL(band_reduce_kernel, dim3(bcnt), dim3(64), 0, st, t);
+#endif
         MllArgs f = a;
         f.only_failed = a.info;
         dkt_mll_generic_global_launch(f, b0, bcnt, t.ws, st);
