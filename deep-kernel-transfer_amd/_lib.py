@@ -102,6 +102,7 @@ SPILL_BUDGET = {
     r"tiled_invert_kernelILi\dELb1ELb1ELi3E": 24,
     # band reduction (QR + fused pass at 256 VGPRs): lane constants parked at kernel entry; the forward kernel reloads one per QR column, both a few per panel --
     # none inside the tile loop
+    r"band_class_kernel": 8,                      # (only a -DDKT_BAND_CLASS_WAVES=6 measurement build spills: 4; the default, 5 waves per SIMD, has none)
     r"band_sym_kernelILb0E": 32,
     r"band_sym_kernelILb1E": 16,
 }

@@ -32,6 +32,7 @@
 // Attempt 0 only (no jitter): an episode with a failed class -- or with a class whose a-priori bound 1 + sv trace(E) / noise exceeds BAND_KAPPA_MAX -- is redone,
 // jitter ladder and all, by the generic kernel's fix-up launch, as in the tile-array path.  Measurements and everything that was tried: docs/MEASUREMENTS.md R6.
 #include "dkt_h2_tiles.h"
+#include <type_traits>
 
 namespace {
 
@@ -472,27 +473,35 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                     for (int j = 0; j < BAND_MAXNT; ++j) part[j] *= un;
                 }
             }
-            // ---- the waves' partials meet in LDS in a fixed order: X' (over the dead Y), V'^T V', V'^T U ----
+            // ---- the waves' partials meet in LDS in a fixed order: X' (over the dead Y), V'^T V', V'^T U.  Four rounds; in round r wave w brings its partials of the
+            //      tile columns j = (w + r) mod 4 (+ 4, 8, ...): all four waves work in every round, on disjoint columns, and a column sees the waves in the fixed
+            //      order j mod 4, j mod 4 - 1, ...  (One wave per round with all its columns -- the other three waiting at the barrier -- was 7 % of the kernel.) ----
             for (int r = 0; r < 4; ++r) {
-                if (wave == r) {
-                    if (want_m) {
-                        // straight-line code: a tile outside the range goes to the wave's scratch instead (28 uniform branches around out-of-line bodies cost
-                        // more than the 28 LDS round trips: measured 4 k cycles per round)
-                        float* const sink = L.Tsc + lane * 4;
+                if (want_m) {
+                    // straight-line code: a tile outside the range goes to the wave's scratch instead (uniform branches around out-of-line bodies cost more than
+                    // the LDS round trips: measured 4 k cycles per round)
+                    float* const sink = L.Tsc + lane * 4;
+                    auto meet = [&](auto sel_c) {
+                        constexpr int SEL = decltype(sel_c)::value, CNT = (BAND_MAXNT - SEL + 3) / 4;
+                        f32x4 old[CNT];
+                        float* xp[CNT];
 #pragma unroll
-                        for (int j0 = 0; j0 < BAND_MAXNT; j0 += 9) {
-                            f32x4 old[9];
-                            float* xp[9];
-#pragma unroll
-                            for (int u = 0; u < 9; ++u) {
-                                const int j = j0 + u;
-                                xp[u] = (j >= jlo && j < NT) ? L.Ys + (16 * j + c16) * LDP + g4 : sink;
-                                old[u] = ld4(xp[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 9; ++u) st4(xp[u], r == 0 ? part[j0 + u] : part[j0 + u] + old[u]);
+                        for (int u = 0; u < CNT; ++u) {
+                            const int j = 4 * u + SEL;
+                            xp[u] = (j >= jlo && j < NT) ? L.Ys + (16 * j + c16) * LDP + g4 : sink;
+                            old[u] = ld4(xp[u]);
                         }
+#pragma unroll
+                        for (int u = 0; u < CNT; ++u) st4(xp[u], r == 0 ? part[4 * u + SEL] : part[4 * u + SEL] + old[u]);
+                    };
+                    switch ((wave + r) & 3) {
+                        case 0: meet(std::integral_constant<int, 0>{}); break;
+                        case 1: meet(std::integral_constant<int, 1>{}); break;
+                        case 2: meet(std::integral_constant<int, 2>{}); break;
+                        default: meet(std::integral_constant<int, 3>{}); break;
                     }
+                }
+                if (wave == r) {
                     if constexpr (!BACK) st4(L.Gs + lane * 4, r == 0 ? gp : gp + ld4(L.Gs + lane * 4));
                     st4(L.Wus + lane * 4, r == 0 ? wu[0] : wu[0] + ld4(L.Wus + lane * 4));
                     st4(L.Wus + 256 + lane * 4, r == 0 ? wu[1] : wu[1] + ld4(L.Wus + 256 + lane * 4));
@@ -814,7 +823,10 @@ __global__ __launch_bounds__(64) void band_reduce_kernel(BandArgs t) {
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 // Per class: the block LDL^T chain of B + mu I, one wave per class matrix
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void band_class_kernel(BandArgs t) {
+#ifndef DKT_BAND_CLASS_WAVES
+#define DKT_BAND_CLASS_WAVES 4          // (5 and 6 waves per SIMD measured equal: 9.69 / 9.69 / 9.68-9.78 ms per 1024 episodes of 420 rows -- the chain is not waiting for occupancy)
+#endif
+__global__ __launch_bounds__(256, DKT_BAND_CLASS_WAVES) void band_class_kernel(BandArgs t) {
     const BandGeo& G = t.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
