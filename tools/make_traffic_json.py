@@ -26,7 +26,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
 KERNEL_TABLE = {
     # dkt_gram_f32
     "gram_sym_ep_split_kernel": "dkt_gram_f32", "gram_sym_ep_kernel": "dkt_gram_f32", "gram_sym_tiles_split_kernel": "dkt_gram_f32",
-    "gram_sym_bigep_f16x2_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
+    "gram_sym_bigep_f16x2_kernel": "dkt_gram_f32", "gram_small_kernel": "dkt_gram_f32", "gram_nt_kernel": "dkt_gram_f32", "gram_sym_fewep_kernel": "dkt_gram_f32", "gram_bn_sym_ep_kernel": "dkt_gram_f32",
     "gram_bn_train_f16_kernel": "dkt_gram_bn_train_f32",
     # dkt_gram_bwd_f32
     "gram_bwd_ep_f16x2_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_bf16x3_kernel": "dkt_gram_bwd_f32", "gram_bwd_ep_kernel": "dkt_gram_bwd_f32",
@@ -38,6 +38,9 @@ KERNEL_TABLE = {
     "tiled_wres_kernel": "dkt_mll_f32", "tiled_invres_kernel": "dkt_mll_f32", "big_form_kernel": "dkt_mll_f32", "bgemm_kernel": "dkt_mll_f32", "chol_inv_block_kernel": "dkt_mll_f32",
     "big_trmv_kernel": "dkt_mll_f32", "big_finish_kernel": "dkt_mll_f32",
     "band_init_kernel": "dkt_mll_f32", "band_sym_kernel": "dkt_mll_f32", "band_class_kernel": "dkt_mll_f32", "band_chain_kernel": "dkt_mll_f32",
+    "band_finish_kernel": "dkt_mll_f32", "band_reduce_kernel": "dkt_mll_f32",
+    # the [B, C]-sized reductions around it (round 6)
+    "objective_kernel": "dkt_objective_f32", "hyper_grads_kernel": "dkt_hyper_grads_f32",
     # the element-wise chain rules
     "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",
     "class_kernel_fwd": "dkt_class_kernel_f32", "class_kernel_bwd": "dkt_class_kernel_bwd_f32",
@@ -46,7 +49,7 @@ KERNEL_TABLE = {
     "lowrank_gram_kernel": "dkt_lowrank_gram_f32", "lowrank_finish_kernel": "dkt_lowrank_finish_f32", "lowrank_bwd_kernel": "dkt_lowrank_bwd_f32",
     "lowrank_noise_floor_kernel": "dkt_lowrank_noise_floor_f32",
 }
-OURS = re.compile(r"gram|mll_|tiled_|band_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank")
+OURS = re.compile(r"gram|mll_|tiled_|band_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank|objective_kernel|hyper_grads")
 
 
 def short_name(kernel: str) -> str:

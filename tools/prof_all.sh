@@ -42,7 +42,7 @@ with open("%s/%s_summary.txt" % (out, cfg), "w") as f:
                 agg[k][1] += float(r.get("Counter_Value", 0) or 0)
             f.write("== counters (--pmc pass %s, --steps 5 --warmup 2)\n" % os.path.basename(d)[4:])
             for (kn, cn), (n, v) in sorted(agg.items()):
-                if any(t in kn for t in ("dkt", "gram", "mll", "tiled", "band", "bgemm", "chol", "rbf", "sqdist", "big_", "lowrank")):
+                if any(t in kn for t in ("dkt", "gram", "mll", "tiled", "band", "bgemm", "chol", "rbf", "sqdist", "big_", "lowrank", "objective_kernel", "hyper_grads")):
                     f.write("%-90s %-28s dispatches %4d  mean %.6g\n" % (kn, cn, n, v / max(n, 1)))
 print(open("%s/%s_summary.txt" % (out, cfg)).read()[:3000])
 PY
