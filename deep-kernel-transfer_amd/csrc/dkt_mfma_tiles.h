@@ -28,6 +28,17 @@ __device__ __forceinline__ void bstore4(brsrc r, f32x4 x, int voff, int soff) {
 __device__ __forceinline__ void bstore1(brsrc r, float x, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
 }
+// the same with the non-temporal hint (cache policy bit 1 = nt): a stream that is touched once per pass should not push the pass' reused operands out of L2
+template <int AUX>
+__device__ __forceinline__ f32x4 bload4_pol(brsrc r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+template <int AUX>
+__device__ __forceinline__ void bstore4_pol(brsrc r, f32x4 x, int voff, int soff) {
+    const u32x4 v = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)((unsigned)voff + (unsigned)soff), 0, AUX);
+}
 constexpr int OOB = 0x7ffffff0;      // an offset every descriptor rejects: the load returns 0, the store is dropped
 
 // D = C + X^T Y on accumulator-layout tiles

@@ -198,6 +198,14 @@ struct SymLds {
     float* Tsc;      // [4][16][17]     wave-private transposition scratch
 };
 constexpr int TSC_LD = 17;
+// cache policy of the BACK pass' tile stream (each stored tile is read once and written once per panel; 2 = non-temporal, 0 = default).  The forward kernel keeps the
+// default: there the tiles a pass writes are read again right away (column update, panel load), and the hint cost 0.3 ms per 1024 episodes (measured)
+#ifndef DKT_BAND_BACK_LD_POL
+#define DKT_BAND_BACK_LD_POL 2
+#endif
+#ifndef DKT_BAND_BACK_ST_POL
+#define DKT_BAND_BACK_ST_POL 2
+#endif
 
 __host__ __device__ inline int sym_lds_floats(const int NT) {
     const int NP = 16 * NT;
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                 constexpr int PF = BACK ? 4 : 1, VPF = BACK ? 2 : 1;      // (forward: more tiles in flight cost registers -- spills in the QR -- and bought nothing: measured)
                 f32x4 ring[PF], vring[VPF];
 #pragma unroll
-                for (int u = 0; u < PF; ++u) ring[u] = bload4(Ar, lane16, (u >= jlo && u <= i) ? (rowbase + u) * 1024 : OOB);
+                for (int u = 0; u < PF; ++u) ring[u] = bload4_pol<BACK ? DKT_BAND_BACK_LD_POL : 0>(Ar, lane16, (u >= jlo && u <= i) ? (rowbase + u) * 1024 : OOB);
 #pragma unroll
                 for (int u = 0; u < VPF; ++u) {
                     const bool vok = have_next && u >= r_next && u < i;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                     const bool in = j >= jlo && j <= i;                                     // uniform
                     f32x4 a = ring[j % PF];
                     const f32x4 vnj = vring[j % VPF];
-                    ring[j % PF] = bload4(Ar, lane16, (j + PF >= jlo && j + PF <= i) ? (rowbase + j + PF) * 1024 : OOB);
+                    ring[j % PF] = bload4_pol<BACK ? DKT_BAND_BACK_LD_POL : 0>(Ar, lane16, (j + PF >= jlo && j + PF <= i) ? (rowbase + j + PF) * 1024 : OOB);
                     {
                         const bool vok = have_next && j + VPF >= r_next && j + VPF < i;
                         vring[j % VPF] = BACK ? bload4(Vsr, lane16, vok ? (j + VPF - r_next) * 1024 : OOB) : bload4(Vr, lane16, vok ? (vb_next + j + VPF - r_next) * 1024 : OOB);
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void band_sym_kernel(BandArgs t) {
                         }
                         if (j == i) part[j] += xo;
                     }
-                    bstore4(Ar, a, lane16, (in && upd) ? (rowbase + j) * 1024 : OOB);
+                    bstore4_pol<BACK ? DKT_BAND_BACK_ST_POL : 0>(Ar, a, lane16, (in && upd) ? (rowbase + j) * 1024 : OOB);
                 }
             }
         }
