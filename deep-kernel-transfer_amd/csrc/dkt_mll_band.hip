@@ -26,9 +26,11 @@
 //                           forward / backward substitution for a_c, Z_jj = diagonal blocks of (B + mu_c)^-1, tr Z, a.a, the a-priori condition bound
 //   band_chain_kernel       (workgroup = episode, 8 waves x 4 block columns)  Z_ji = -G_j^T Z_{j+1,i} upwards from the diagonal, two classes per step, accumulated
 //                           over the classes in registers, the classes' G tiles DMA-staged through LDS, + the rank-C term
-//   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same fused pass with Th = T, f16 splits), a <- H_k a; then W[b], alpha[b], and the quadratic
-//                           form / hyper-gradients from the residual rho = r - K alpha against the ORIGINAL E (the reduction's backward error, a few eps |E|, would
-//                           otherwise cost 3e-5 ... 9e-5 on r^T K^-1 r for class-correlated features)
+//   band_sym_kernel<true>   M <- H_k M H_k^T for k = NT-3 .. 0 (the same fused pass with Th = T, f16 splits; its tile stream carries the non-temporal hint: at 17 GB per
+//                           1024 episodes of 420 rows this kernel runs at the memory system's rate), a <- H_k a
+//   band_finish_kernel      (workgroup = 16-row stripe of an episode)  W[b], alpha[b], and the quadratic form / hyper-gradients from the residual rho = r - K alpha against
+//                           the ORIGINAL E (the reduction's backward error, a few eps |E|, would otherwise cost 3e-5 ... 9e-5 on r^T K^-1 r for class-correlated features);
+//                           band_reduce_kernel sums the stripes in a fixed order
 // Attempt 0 only (no jitter): an episode with a failed class -- or with a class whose a-priori bound 1 + sv trace(E) / noise exceeds BAND_KAPPA_MAX -- is redone,
 // jitter ladder and all, by the generic kernel's fix-up launch, as in the tile-array path.  Measurements and everything that was tried: docs/MEASUREMENTS.md R6.
 #include "dkt_h2_tiles.h"
@@ -985,8 +987,9 @@ __global__ __launch_bounds__(256, DKT_BAND_CLASS_WAVES) void band_class_kernel(B
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 // M = sum_c 0.5 cw_c (a_c a_c^T / sv_c - Z^c), Z^c = (B + mu_c)^-1: block column i of Z^c follows from its diagonal block upwards, Z_ji = -G_j^T Z_{j+1,i}.
-// Workgroup = episode, 16 waves; wave w owns the block columns NT-1-w and NT-32+w (23 .. 27 tiles together) and keeps their tiles as accumulators over the
-// classes; the G tiles of a class are staged once through LDS (double buffered, one barrier per class), the diagonal blocks come straight from memory.
+// Workgroup = episode, 8 waves; a wave owns FOUR block columns -- by distance e from the last one: e = w and 31 - w (accumulator array P, filled from both ends) and
+// e = 15 - w and 16 + w (array Q): 46 .. 50 tiles per wave -- and keeps their tiles as accumulators over the classes; the G tiles of TWO classes per step are staged
+// through LDS (global_load_lds, double buffered, one barrier per pair), the diagonal blocks come straight from memory.
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int CHAIN_WAVES = 8;
 constexpr int NACC_P = BAND_MAXNT, NACC_Q = 2 * BAND_MAXNT - 31 + 1;
