@@ -48,6 +48,8 @@ SIGNATURES = {
                            _c_p, ctypes.c_size_t, _c_p]),
     "dkt_objective_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_hyper_grads_f32": (_c_i, [_c_p] * 8 + [_c_i, _c_i, _c_p]),
+    "dkt_bn_param_grads_workspace_bytes": (ctypes.c_size_t, [_c_i, _c_i]),
+    "dkt_bn_param_grads_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p, ctypes.c_size_t, _c_p]),
     "dkt_gram_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, ctypes.c_uint, _c_p]),
     "dkt_rbf_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "dkt_sqdist_bwd_f32": (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_p]),

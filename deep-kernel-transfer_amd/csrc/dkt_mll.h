@@ -28,6 +28,8 @@ struct MllArgs {
     int max_tries;
     unsigned flags;
     int p2_guard;                 // wave-per-episode kernel: binades of head room of the f16 scale of M over the diagonal tiles (DKT_MLL_P2_GUARD, default 1)
+    float kappa_max = 0.f;        // f16-split kernels (dkt_mll_h2.hip): > 0 = a class whose a-priori bound 1 + sv trace(E) / noise exceeds it (and whose factorisation succeeded)
+                                  // leaves with info = -1 for the generic kernel's fix-up launch (dkt_mll.hip, mll_kappa_fixup); 0 = no test
 };
 
 constexpr float DKT_HALF_LOG_2PI = 0.91893853320467274178f;

@@ -212,33 +212,17 @@ void dkt_mll_generic_global_launch(MllArgs a, int b0, int count, float* ws, hipS
 // kappa-aware dispatch of the f16-split kernels (N + 1 <= 128): their 22-bit tile products hold the tolerances up to cond(K) of a few
 // thousand (the reference's unit-norm rows and frozen noise 0.1: <= 730) and 2 - 3 x the tolerances at 1.6e4 (test_mll_large_and_small_magnitude_base_matrices).  After
 // the split launch the generic kernel -- exact fp32 on the matrix itself, jitter ladder included, LDS-resident at these sizes -- redoes every unit (episode, or matrix
-// with DKT_MLL_E_PER_CLASS) whose a-priori bound 1 + sv trace(E) / noise exceeds MLL_H2_KAPPA_MAX, decided on the device (a launch of B workgroups that read N diagonal
-// elements per unit, then the generic kernel whose workgroups read their flags and leave).  DKT_MLL_NO_KAPPA_GUARD = the raw split kernels (tests, A/B tools).
+// with DKT_MLL_E_PER_CLASS) whose a-priori bound 1 + sv trace(E) / noise exceeds MLL_H2_KAPPA_MAX, decided on the device: the split kernels take the trace off the
+// diagonal tiles they hold anyway and leave such a class with info = -1 (MllArgs::kappa_max; a launch of its own until ABI 7), then the generic kernel whose workgroups
+// read their flags and leave.  DKT_MLL_NO_KAPPA_GUARD = the raw split kernels (tests, A/B tools).
 constexpr float MLL_H2_KAPPA_MAX = 5.0e3f;
 
-// one wave per unit (episode, or class matrix with DKT_MLL_E_PER_CLASS): trace(E) from the N diagonal elements, then info[b, c] = -1 for every class of the unit
-// whose bound exceeds kappa_max and whose split factorisation had succeeded (a failed one is flagged already)
-__global__ __launch_bounds__(256) void mll_kappa_flag_kernel(MllArgs a, const float kappa_max) {
-    const int lane = threadIdx.x & 63;
-    const bool epc = (a.flags & DKT_MLL_E_PER_CLASS) != 0;
-    const size_t unit = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), units = epc ? (size_t)a.B * a.C : (size_t)a.B;
-    if (unit >= units) return;
-    const int N = a.N, C = a.C;
-    const float* Eb = a.E + unit * N * N;
-    float tr = 0.f;
-    for (int i = lane; i < N; i += 64) tr += Eb[(size_t)i * N + i];
-    tr = wave_allsum(tr);
-    const int c0 = epc ? (int)(unit % (size_t)C) : 0, c1 = epc ? c0 + 1 : C;
-    const size_t b = epc ? unit / (size_t)C : unit;
-    for (int c = c0 + lane; c < c1; c += 64)
-        if (!(1.0f + a.sv[c] * tr / a.noise[c] <= kappa_max) && a.info[b * C + c] == 0) a.info[b * C + c] = -1;
-}
+static bool mll_kappa_guarded(const MllArgs& a) { return !(a.flags & DKT_MLL_NO_KAPPA_GUARD) && mll_fits_lds(a.N); }
 
 static void mll_kappa_fixup(MllArgs a, hipStream_t st) {
-    if ((a.flags & DKT_MLL_NO_KAPPA_GUARD) || !mll_fits_lds(a.N)) return;
+    if (!mll_kappa_guarded(a)) return;
     const int upe = (a.flags & DKT_MLL_E_PER_CLASS) ? a.C : 1;
     const size_t units = (size_t)a.B * upe;
-    hipLaunchKernelGGL(mll_kappa_flag_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a, MLL_H2_KAPPA_MAX);
     a.only_failed = a.info;                                    // the generic kernel leaves at once (one flag read per class, no barrier) unless the unit is flagged
     a.b0 = 0; a.LD = mll_ld(a.N);
     const size_t lds = (mll_vec_floats(a.N) + mll_mat_floats(a.N)) * sizeof(float);
@@ -316,12 +300,14 @@ extern "C" int dkt_mll_f32(const float* E, const float* Y, long y_bstride, const
                 return dkt_mll_tiled_launch(a, workspace, workspace_bytes, st);
             }
             if (N + 1 <= 128) {
+                a.kappa_max = mll_kappa_guarded(a) ? MLL_H2_KAPPA_MAX : 0.f;
                 if (!dkt_mll_h2_launch(a, st)) return DKT_ERR_BAD_ARG;
                 mll_kappa_fixup(a, st);
                 return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
             }
         }
     }
+    a.kappa_max = (N + 1 <= 128 && mll_kappa_guarded(a)) ? MLL_H2_KAPPA_MAX : 0.f;
     if (!(flags & (DKT_MLL_FORCE_GENERIC | DKT_MLL_FORCE_REG | DKT_MLL_FORCE_F32MFMA)) && dkt_mll_h2_launch(a, st)) {
         mll_kappa_fixup(a, st);
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

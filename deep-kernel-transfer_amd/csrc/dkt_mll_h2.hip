@@ -381,14 +381,19 @@ void mll_h2_kernel(MllArgs a, const int wpg) {
             f.pN = pN; f.c16 = c16; f.g4 = g4; f.lane = lane; f.mc = mc;
             // kappa = 4^m >= max_i K_ii (exact in fp32): every pivot of K / kappa is <= 1, every entry of K / kappa, of its Schur
             // complements and of R is bounded by 1.
-            float emax = 0.f;
+            float emax = 0.f, etr = 0.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const f32x4 e = stage[tidx(j, j) * 64 + lane];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) emax = fmaxf(emax, (g4 + q == c16) ? e[q] : 0.f);
+                for (int q = 0; q < 4; ++q) {
+                    emax = fmaxf(emax, (g4 + q == c16) ? e[q] : 0.f);
+                    etr += (g4 + q == c16) ? e[q] : 0.f;
+                }
             }
             emax = wave_reduce_dpp<true>(emax);
+            // kappa-aware dispatch (dkt_mll.hip, mll_kappa_fixup): the a-priori condition bound 1 + sv trace(E) / noise from the diagonal that is in registers anyway
+            const bool kappa_high = a.kappa_max > 0.f && !(1.0f + svc * wave_reduce_dpp<false>(etr) / nzc <= a.kappa_max);
             r2 = wave_reduce_dpp<false>(r2);
             int fail_at = 0;
             float jit = 0.f, lsum = 0.f, quad = 0.f, aug_unscale = 1.f;
@@ -587,7 +592,7 @@ void mll_h2_kernel(MllArgs a, const int wpg) {
                 const bool ok = fail_at == 0;
                 a.logp[bc] = ok ? (-0.5f * quad - 0.34657359027997264f * lsum - (float)N * DKT_HALF_LOG_2PI) : qnan;
                 a.jitter_used[bc] = jit;
-                a.info[bc] = fail_at;
+                a.info[bc] = (ok && kappa_high) ? -1 : fail_at;
                 if constexpr (GRAD) {
                     const float nz_eff = a.noise[c] + jit;
                     const float trpp = trk - aa;                                    // tr (K^-1 - alpha alpha^T)
@@ -818,6 +823,7 @@ void mll_h2e_kernel(MllArgs a) {
         f.pN = pN; f.c16 = c16; f.g4 = g4; f.lane = lane; f.mc = mc;
         Tiles<NT> T;
         int fail_at = 0;
+        bool kappa_high = false;
         float jit = 0.f, lsum = 0.f, quad = 0.f, aug_unscale = 1.f;
         int msc = 0;
         const brsrc Er = mk_rsrc(a.E + mat * N * N, (unsigned)(N * N * 4));
@@ -828,13 +834,18 @@ void mll_h2e_kernel(MllArgs a) {
             }
             // ---- E[b] -> the tile registers (diagonal tiles first: kappa needs max E_ii) ----
             load_all_e<NT>(T, Er, N, pN, c16, g4);
-            float emax = 0.f;
+            float emax = 0.f, etr = 0.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) emax = fmaxf(emax, (g4 + q == c16) ? T.t[j][j][q] : 0.f);
+                for (int q = 0; q < 4; ++q) {
+                    emax = fmaxf(emax, (g4 + q == c16) ? T.t[j][j][q] : 0.f);
+                    etr += (g4 + q == c16) ? T.t[j][j][q] : 0.f;
+                }
             }
             emax = wave_reduce_dpp<true>(emax);
+            // kappa-aware dispatch (dkt_mll.hip, mll_kappa_fixup): the a-priori condition bound 1 + sv trace(E) / noise from the diagonal that is in registers anyway
+            kappa_high = a.kappa_max > 0.f && !(1.0f + svc * wave_reduce_dpp<false>(etr) / nzc <= a.kappa_max);
             int ex;
             (void)frexpf(fmaf(svc, emax, nzc + jit), &ex);                 // max K_ii = f 2^ex, 0.5 <= f < 1
             msc = max(0, (ex + 1) >> 1);
@@ -1212,7 +1223,7 @@ void mll_h2e_kernel(MllArgs a) {
             const bool ok = fail_at == 0;
             a.logp[bc] = ok ? (-0.5f * quad - 0.34657359027997264f * lsum - (float)N * DKT_HALF_LOG_2PI) : qnan;
             a.jitter_used[bc] = jit;
-            a.info[bc] = fail_at;
+            a.info[bc] = (ok && kappa_high) ? -1 : fail_at;
             if (want_grad) {
                 const float nz_eff = nzc + jit;
                 a.dmean[bc] = ok ? asum : qnan;

@@ -929,6 +929,29 @@ def gram_bn_bwd(w, e, x, a, s, rnorm, mean=None, rstd=None, ep_scale=None):
     return dx, dg, db
 
 
+def bn_param_grads(dg: torch.Tensor, db: torch.Tensor):
+    """(dgamma [D], dbeta [D]) = the sums over the episodes of the per-episode parts [B,D] gram_bn_bwd / normalize_bn_bwd return (dkt_bn_param_grads_f32: fixed
+    order; one launch up to 256 episodes, two beyond -- as two tensor reductions: two launches + four buffer fills).  One episode: the parts ARE the sums."""
+    dg = _req(dg, "dgamma_part", 2)
+    db = _req(db, "dbeta_part", 2)
+    b_, d = dg.shape
+    if db.shape != dg.shape:
+        raise RuntimeError("bn_param_grads: the two parts must have the same shape")
+    if b_ == 1:
+        return dg.reshape(d), db.reshape(d)
+    if os.environ.get("DKT_FUSED_REDUCTIONS", "1") == "0":                 # the tensor expressions (their twin)
+        return dg.sum(0), db.sum(0)
+    lib = _lib_now()
+    og = torch.empty((d,), device=dg.device, dtype=torch.float32)
+    ob = torch.empty((d,), device=dg.device, dtype=torch.float32)
+    ws_bytes = int(lib.dkt_bn_param_grads_workspace_bytes(b_, d))
+    ws = torch.empty((ws_bytes + 3) // 4, device=dg.device, dtype=torch.float32) if ws_bytes else None
+    with _timed("dkt_bn_param_grads_f32"):
+        st = lib.dkt_bn_param_grads_f32(_p(dg), _p(db), _p(og), _p(ob), b_, d, _p(ws), ws_bytes, _stream())
+    _lib.check(st, "dkt_bn_param_grads_f32")
+    return og, ob
+
+
 def affine_normalize(x: torch.Tensor, a: torch.Tensor, s: torch.Tensor):
     """Zn = y / max(|y|_2, 1e-12), y = a x + s, row by row; a, s: [D] or [B,D].  Returns (Zn [B,N,D], rnorm [B,N]) (dkt_affine_normalize_f32: the front end of
     episodes with more than 128 rows, whose Gram kernels take unit rows as input)."""
@@ -1049,8 +1072,11 @@ class _EpisodeLossBnFn(torch.autograd.Function):
         else:
             dx, dg, db = gram_bn_bwd(w, e, x, a, s, rnorm, None, None, gobj)
         ng = ctx.needs_input_grad
-        ggamma = dg.sum(0).reshape(ctx.shapes[3]) if (dg is not None and ng[1] and ctx.shapes[3] is not None) else None
-        gbeta = db.sum(0).reshape(ctx.shapes[4]) if (db is not None and ng[2] and ctx.shapes[4] is not None) else None
+        ggamma = gbeta = None
+        if dg is not None and ((ng[1] and ctx.shapes[3] is not None) or (ng[2] and ctx.shapes[4] is not None)):
+            sg, sb = bn_param_grads(dg, db)
+            ggamma = sg.reshape(ctx.shapes[3]) if (ng[1] and ctx.shapes[3] is not None) else None
+            gbeta = sb.reshape(ctx.shapes[4]) if (ng[2] and ctx.shapes[4] is not None) else None
         gsv, gmean, gnoise = hyper_grads(gobj, cw, dsv if ng[6] else None, dmean if ng[7] else None, dnoise if ng[8] else None, ctx.shapes[:3])
         return (dx if ng[0] else None), ggamma, gbeta, None, None, None, gsv, gmean, gnoise, None, None, None
 

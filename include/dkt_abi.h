@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define DKT_ABI_VERSION 6 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
+#define DKT_ABI_VERSION 7 /* 2 (round 3): + dkt_gram_bn_train_f32, dkt_class_kernel_*, DKT_MLL_E_PER_CLASS (W layout [B,C,N,N]), DKT_MLL_FORCE_F32MFMA; \
                              3 (round 4): DKT_MLL_E_PER_CLASS up to N = 447, DKT_MLL_FORCE_REG retired (DKT_ERR_BAD_ARG), + dkt_affine_normalize_f32, dkt_normalize_bn_bwd_f32; \
                              4 (round 5): DKT_MLL_E_PER_CLASS for every N with the jitter ladder on every path (+ DKT_MLL_FORCE_GENERIC as its twin), \
                                           + dkt_predict_per_class_f32, dkt_reload_env declared, + dkt_lowrank_* (linear kernels in feature space, D <= 64 < N); \
                              5 (round 6): shared-E calls with 12 <= C <= 32 classes, 128 <= N <= 432 and >= 192 episodes take ONE band reduction per episode (dkt_mll_band.hip); \
                                           + DKT_MLL_FORCE_TILED (the tile-array kernels as its twin), DKT_MLL_FORCE_BAND; the f16-split kernels (N <= 127) are followed by a kappa-aware fix-up launch (DKT_MLL_NO_KAPPA_GUARD); \
-                             6 (round 6): + dkt_objective_f32, dkt_hyper_grads_f32 */
+                             6 (round 6): + dkt_objective_f32, dkt_hyper_grads_f32; \
+                             7 (round 6): + dkt_bn_param_grads_f32 (+ its workspace query); the kappa test of the f16-split kernels moved into those kernels (one launch less per call) */
 
 /* status codes */
 #define DKT_OK 0
@@ -308,6 +309,18 @@ int dkt_gram_bn_train_f32(const float* X, const float* gamma, const float* beta,
 int dkt_gram_bn_bwd_f32(const float* W, const float* E, const float* X, const float* a, const float* s, long ab_bstride,
                         const float* mean, const float* rstd, const float* rnorm, const float* ep_scale, float* dX,
                         float* dgamma_part, float* dbeta_part, int B, int N, int D, void* stream);
+
+/*
+ * dkt_bn_param_grads_f32 -- the sum over the episodes of a call that dkt_gram_bn_bwd_f32 / dkt_normalize_bn_bwd_f32 leave to the caller:
+ *   dgamma[d] = sum_b dgamma_part[b,d],  dbeta[d] = sum_b dbeta_part[b,d]      (parts [B,D], D % 4 == 0, 16-byte aligned)
+ *   in a fixed summation order (row lanes of 256-row chunks in a tree, then the chunks in order: bitwise reproducible), one launch up to 256 episodes, two
+ *   beyond (workspace: dkt_bn_param_grads_workspace_bytes(B, D) bytes, 0 up to 256 episodes).  As two tensor reductions this is two launches plus, on ROCm,
+ *   four buffer fills for their cross-block semaphores -- 40 us of a 1.3-ms step of 2048 episodes.
+ * Replaces autograd's accumulation into bn_out.weight / bn_out.bias (loss.backward(), methods/DKT.py:48, 163) for a batch of episodes.
+ */
+size_t dkt_bn_param_grads_workspace_bytes(int B, int D);
+int dkt_bn_param_grads_f32(const float* dgamma_part, const float* dbeta_part, float* dgamma, float* dbeta, int B, int D,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * ---- the same front end for episodes of MORE than 128 rows (round 4; the 20-way shapes of train.py:132-133) -----------------------

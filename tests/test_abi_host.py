@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_header_symbols(lib):
         assert hasattr(lib, name), "libdkt_hip.so lacks %s" % name
         assert name in dkt_amd._lib.SIGNATURES, "no ctypes signature for %s" % name
     assert sorted(dkt_amd._lib.SIGNATURES) == declared
-    assert lib.dkt_abi_version() == 6
+    assert lib.dkt_abi_version() == 7
     # pure host queries (no GPU needed)
     assert lib.dkt_mll_workspace_bytes(8, 5, 105) == 0                 # register resident
     # N > 127: blocked path, per (episode, class) four N x N matrices + two vectors + bookkeeping

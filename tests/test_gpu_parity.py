@@ -32,7 +32,7 @@ def rel_l2(a, b):
 
 
 def test_loaded_native_library(cuda, lib):
-    assert lib.dkt_abi_version() == 6
+    assert lib.dkt_abi_version() == 7
     assert lib.dkt_device_cu_count() == 256, "expected an MI355X (256 CUs)"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -141,6 +141,33 @@ def test_objective_and_hyper_gradient_reductions(cuda, b, c, monkeypatch):
     for gx, tx in zip(gs, tw):
         assert tx.shape == gx.shape and ((gx - tx).abs().max() / tx.abs().max()).item() < 1e-5
     assert ((ops.objective(logp, cw) - obj).abs().max() / obj.abs().max()).item() < 1e-6
+
+
+@pytest.mark.parametrize("b,d", [(1, 64), (5, 1600), (256, 36), (257, 1600), (2048, 1600), (3000, 512)])
+def test_bn_param_gradient_sums(cuda, b, d, monkeypatch):
+    """dkt_bn_param_grads_f32: the sums over the episodes of the per-episode dgamma / dbeta parts of the fused backward (one launch up to 256 episodes, row chunks +
+    a fold beyond) against float64, bitwise repeatable, and against the tensor reductions it replaces; at the C ABI: a missing / short workspace is refused."""
+    g = torch.Generator(device=cuda).manual_seed(b * 7 + d)
+    dg = torch.randn(b, d, generator=g, device=cuda) * 3.0
+    db = torch.randn(b, d, generator=g, device=cuda) + 0.5
+    og, ob = ops.bn_param_grads(dg, db)
+    for o, p_ in ((og, dg), (ob, db)):
+        assert o.shape == (d,)
+        err = (o.double() - p_.double().sum(0)).abs() / p_.double().abs().sum(0)
+        assert err.max().item() < 1e-6 * max(1.0, np.log2(b))
+    og2, ob2 = ops.bn_param_grads(dg, db)
+    assert torch.equal(og, og2) and torch.equal(ob, ob2), "fixed summation order"
+    monkeypatch.setenv("DKT_FUSED_REDUCTIONS", "0")
+    tg, tb = ops.bn_param_grads(dg, db)
+    assert ((tg - og).abs().max() / tg.abs().max()).item() < 1e-5 and ((tb - ob).abs().max() / tb.abs().max()).item() < 1e-5
+    monkeypatch.delenv("DKT_FUSED_REDUCTIONS")
+    lib = dkt_amd._lib.load()
+    need = int(lib.dkt_bn_param_grads_workspace_bytes(b, d))
+    assert (need == 0) == (b <= 256)
+    if need:
+        st = lib.dkt_bn_param_grads_f32(dg.data_ptr(), db.data_ptr(), og.data_ptr(), ob.data_ptr(), b, d, None, 0, None)
+        assert st == -3                                                   # DKT_ERR_WORKSPACE
+    assert lib.dkt_bn_param_grads_f32(dg.data_ptr(), db.data_ptr(), og.data_ptr(), ob.data_ptr(), b, d + 2, None, 0, None) == -1      # D % 4
 
 
 @pytest.mark.parametrize("var", ["11", "12", "21", "22", "611", "612"])

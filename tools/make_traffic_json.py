@@ -41,6 +41,7 @@ KERNEL_TABLE = {
     "band_finish_kernel": "dkt_mll_f32", "band_reduce_kernel": "dkt_mll_f32",
     # the [B, C]-sized reductions around it (round 6)
     "objective_kernel": "dkt_objective_f32", "hyper_grads_kernel": "dkt_hyper_grads_f32",
+    "bn_param_grads_kernel": "dkt_bn_param_grads_f32", "bn_param_grads_fold_kernel": "dkt_bn_param_grads_f32",
     # the element-wise chain rules
     "rbf_bwd_kernel": "dkt_rbf_bwd_f32", "sqdist_bwd_kernel": "dkt_sqdist_bwd_f32",
     "class_kernel_fwd": "dkt_class_kernel_f32", "class_kernel_bwd": "dkt_class_kernel_bwd_f32",
@@ -49,7 +50,7 @@ KERNEL_TABLE = {
     "lowrank_gram_kernel": "dkt_lowrank_gram_f32", "lowrank_finish_kernel": "dkt_lowrank_finish_f32", "lowrank_bwd_kernel": "dkt_lowrank_bwd_f32",
     "lowrank_noise_floor_kernel": "dkt_lowrank_noise_floor_f32",
 }
-OURS = re.compile(r"gram|mll_|tiled_|band_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank|objective_kernel|hyper_grads")
+OURS = re.compile(r"gram|mll_|tiled_|band_|bgemm|chol_inv|big_|rbf_bwd|sqdist|class_kernel|predict|smk_|bn_stats|lowrank|objective_kernel|hyper_grads|bn_param_grads")
 
 
 def short_name(kernel: str) -> str:
