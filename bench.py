@@ -480,7 +480,7 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
     return res
 
 
-GLUE_KERNELS = ("dkt_objective_f32", "dkt_hyper_grads_f32")
+GLUE_KERNELS = ("dkt_objective_f32", "dkt_hyper_grads_f32", "dkt_bn_param_grads_f32")
 
 
 def _algorithmic(cfg, n, d, c, unit_rows, lowrank=False):

@@ -34,28 +34,48 @@ __device__ __forceinline__ void fe_store4(brsrc_t r, int voff, float a0, float a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Batch statistics: grid (ceil(D/4 / 256), B); a thread owns 4 adjacent features and walks the N rows of its episode
-// (float4 loads, 4 KB contiguous per wave and row).  Sums are taken about the first row (shifted data): no
-// catastrophic cancellation in  E[x^2] - E[x]^2  for features with a large common offset (ReLU outputs).
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, float* __restrict__ mean,
-                                                       float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ s,
-                                                       float* __restrict__ var_unbiased, int N, int D) {
+// Batch statistics: grid (ceil(D / 256), B), 1024 threads = 64 feature quads x 16 row lanes; a row lane walks the rows rl, rl + 16, ... of its quad
+// (float4 loads, 1 KB contiguous per wave and row, 8 rows in flight), the 16 lanes of a quad meet in a fixed tree in LDS (bitwise reproducible).  Sums are
+// taken about the first row (shifted data): no catastrophic cancellation in  E[x^2] - E[x]^2  for features with a large common offset (ReLU outputs).
+// (Until round 6 a thread walked all N rows of its quad: 128 busy threads per 420 x 512 episode, 0.25 of the HBM roofline at the 20-way shape.)
+__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ s,
+                                                        float* __restrict__ var_unbiased, int N, int D) {
+    __shared__ __attribute__((aligned(16))) float red[16][64][8];
     const int b = blockIdx.y;
-    const int d = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (d >= D) return;
-    const float* Xb = X + (size_t)b * N * D + d;
+    const int qd = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int d = 256 * blockIdx.x + 4 * qd;
+    const bool dok = d < D;                                     // (D % 4 == 0: a quad is inside the row or wholly beyond it)
+    const float* Xb = X + (size_t)b * N * D + (dok ? d : 0);
     const float4 x0 = *reinterpret_cast<const float4*>(Xb);
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 1; i < N; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(Xb + (size_t)i * D);
-        const float e[4] = {v.x - x0.x, v.y - x0.y, v.z - x0.z, v.w - x0.w};
+    if (dok) {
+#pragma unroll 8
+        for (int i = rl; i < N; i += 16) {                      // (row 0 contributes exact zeros)
+            const float4 v = *reinterpret_cast<const float4*>(Xb + (size_t)i * D);
+            const float e[4] = {v.x - x0.x, v.y - x0.y, v.z - x0.z, v.w - x0.w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s1[t] += e[t];
-            s2[t] = __builtin_fmaf(e[t], e[t], s2[t]);
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += e[t];
+                s2[t] = __builtin_fmaf(e[t], e[t], s2[t]);
+            }
         }
     }
+    *reinterpret_cast<float4*>(&red[rl][qd][0]) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(&red[rl][qd][4]) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    __syncthreads();
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) {
+        if (rl < w) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rl][qd][e] += red[rl + w][qd][e];
+        }
+        __syncthreads();
+    }
+    if (rl != 0 || !dok) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s1[t] = red[0][qd][t]; s2[t] = red[0][qd][4 + t]; }
     const float inv_n = 1.0f / (float)N;
     const float x0v[4] = {x0.x, x0.y, x0.z, x0.w};
     float mu[4], rs[4], av[4], sv[4], vu[4];
@@ -1055,8 +1075,8 @@ extern "C" int dkt_bn_stats_f32(const float* X, const float* gamma, const float*
     if (!X || !mean || !rstd || !a || !s || B <= 0 || N <= 0 || D <= 0) return DKT_ERR_BAD_ARG;
     if ((D & 3) || ((uintptr_t)X & 15)) return DKT_ERR_BAD_ARG;
     if (B > 65535) return DKT_ERR_TOO_LARGE;
-    dim3 grid((D / 4 + 255) / 256, B);
-    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, gamma, beta, eps, mean, rstd, a, s, var_unbiased, N, D);
+    dim3 grid((D + 255) / 256, B);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(1024), 0, (hipStream_t)stream, X, gamma, beta, eps, mean, rstd, a, s, var_unbiased, N, D);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 

@@ -15,7 +15,8 @@
 
 namespace {
 
-// one wave per row
+// one wave per row; up to D = 2048 the row's y = a x + s stays in the wave's registers between the norm and the store (X is read once), beyond that the row is
+// read a second time (an L1 / L2 hit)
 __global__ __launch_bounds__(256) void affine_normalize_kernel(const float* __restrict__ X, const float* __restrict__ A, const float* __restrict__ S, long ab_bstride,
                                                                float* __restrict__ Zn, float* __restrict__ rnorm, long rows, int N, int D) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -28,6 +29,32 @@ __global__ __launch_bounds__(256) void affine_normalize_kernel(const float* __re
     float4* z = reinterpret_cast<float4*>(Zn + row * D);
     const int nv = D >> 2;
     float ss = 0.f;
+    if (nv <= 512) {
+        float4 y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = lane + 64 * k;
+            y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < nv) {
+                const float4 xv = x[v], av = a[v], sv = s[v];
+                y[k] = make_float4(__builtin_fmaf(av.x, xv.x, sv.x), __builtin_fmaf(av.y, xv.y, sv.y), __builtin_fmaf(av.z, xv.z, sv.z), __builtin_fmaf(av.w, xv.w, sv.w));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {      // (same order of the squares as the streaming form below: lane-wise v = lane, lane + 64, ...)
+            ss = __builtin_fmaf(y[k].x, y[k].x, ss); ss = __builtin_fmaf(y[k].y, y[k].y, ss); ss = __builtin_fmaf(y[k].z, y[k].z, ss); ss = __builtin_fmaf(y[k].w, y[k].w, ss);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, DKT_WAVE);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize: x / max(|x|_2, eps)
+        if (lane == 0) rnorm[row] = rn;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = lane + 64 * k;
+            if (v < nv) z[v] = make_float4(y[k].x * rn, y[k].y * rn, y[k].z * rn, y[k].w * rn);
+        }
+        return;
+    }
     for (int v = lane; v < nv; v += 64) {
         const float4 xv = x[v], av = a[v], sv = s[v];
         const float y0 = __builtin_fmaf(av.x, xv.x, sv.x), y1 = __builtin_fmaf(av.y, xv.y, sv.y), y2 = __builtin_fmaf(av.z, xv.z, sv.z), y3 = __builtin_fmaf(av.w, xv.w, sv.w);
@@ -35,9 +62,9 @@ __global__ __launch_bounds__(256) void affine_normalize_kernel(const float* __re
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, DKT_WAVE);
-    const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize: x / max(|x|_2, eps)
+    const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
     if (lane == 0) rnorm[row] = rn;
-    for (int v = lane; v < nv; v += 64) {                     // (the row is 2 KB at D = 512: the second read is an L1 / L2 hit)
+    for (int v = lane; v < nv; v += 64) {                     // (the second read of the row is an L1 / L2 hit)
         const float4 xv = x[v], av = a[v], sv = s[v];
         z[v] = make_float4(__builtin_fmaf(av.x, xv.x, sv.x) * rn, __builtin_fmaf(av.y, xv.y, sv.y) * rn, __builtin_fmaf(av.z, xv.z, sv.z) * rn,
                            __builtin_fmaf(av.w, xv.w, sv.w) * rn);
@@ -82,23 +109,43 @@ __global__ __launch_bounds__(256) void normalize_bn_bwd_cols_kernel(const float*
         rs = *reinterpret_cast<const float4*>(rstd + (size_t)b * D + d);
     }
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;                   // column sums of dY and dY xhat over this thread's rows
-    for (int i = r; i < N; i += 32) {
-        float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dok) {
+    // four rows per trip, every load of the trip issued before the first use (round 6: one row per trip left each of the 16 waves of a CU waiting for its own
+    // three loads, trip after trip -- 0.40 of the HBM roofline at the 20-way shape); rows past N are clamped to the last row and weighted out
+    for (int i0 = r; i0 < N; i0 += 128) {
+        float4 g[4], z[4], x[4];
+        float ti[4], rn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + 32 * u, N - 1);
             const size_t o = base + (size_t)i * D;
-            const float4 g = *reinterpret_cast<const float4*>(dZn + o), z = *reinterpret_cast<const float4*>(Zn + o);
-            const float ti = t[(size_t)b * N + i], rn = rnorm[(size_t)b * N + i];
-            dy = make_float4(rn * __builtin_fmaf(-z.x, ti, g.x), rn * __builtin_fmaf(-z.y, ti, g.y), rn * __builtin_fmaf(-z.z, ti, g.z), rn * __builtin_fmaf(-z.w, ti, g.w));
-            if (TRAIN) {
-                const float4 x = *reinterpret_cast<const float4*>(X + o);
-                sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
-                sg.x = __builtin_fmaf(dy.x, (x.x - mu.x) * rs.x, sg.x); sg.y = __builtin_fmaf(dy.y, (x.y - mu.y) * rs.y, sg.y);
-                sg.z = __builtin_fmaf(dy.z, (x.z - mu.z) * rs.z, sg.z); sg.w = __builtin_fmaf(dy.w, (x.w - mu.w) * rs.w, sg.w);
-            } else {
-                *reinterpret_cast<float4*>(dX + o) = make_float4(av.x * dy.x, av.y * dy.y, av.z * dy.z, av.w * dy.w);
+            g[u] = z[u] = x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dok) {
+                g[u] = *reinterpret_cast<const float4*>(dZn + o);
+                z[u] = *reinterpret_cast<const float4*>(Zn + o);
+                if (TRAIN) x[u] = *reinterpret_cast<const float4*>(X + o);
+            }
+            ti[u] = t[(size_t)b * N + i];
+            rn[u] = rnorm[(size_t)b * N + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 32 * u;
+            if (i < N) {
+                float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dok) {
+                    dy = make_float4(rn[u] * __builtin_fmaf(-z[u].x, ti[u], g[u].x), rn[u] * __builtin_fmaf(-z[u].y, ti[u], g[u].y),
+                                     rn[u] * __builtin_fmaf(-z[u].z, ti[u], g[u].z), rn[u] * __builtin_fmaf(-z[u].w, ti[u], g[u].w));
+                    if (TRAIN) {
+                        sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
+                        sg.x = __builtin_fmaf(dy.x, (x[u].x - mu.x) * rs.x, sg.x); sg.y = __builtin_fmaf(dy.y, (x[u].y - mu.y) * rs.y, sg.y);
+                        sg.z = __builtin_fmaf(dy.z, (x[u].z - mu.z) * rs.z, sg.z); sg.w = __builtin_fmaf(dy.w, (x[u].w - mu.w) * rs.w, sg.w);
+                    } else {
+                        *reinterpret_cast<float4*>(dX + base + (size_t)i * D) = make_float4(av.x * dy.x, av.y * dy.y, av.z * dy.z, av.w * dy.w);
+                    }
+                }
+                if (TRAIN) *reinterpret_cast<float4*>(dy_s + (size_t)i * 32 + 4 * c4) = dy;
             }
         }
-        if (TRAIN) *reinterpret_cast<float4*>(dy_s + (size_t)i * 32 + 4 * c4) = dy;
     }
     if (!TRAIN) return;
     // the 32 row-threads of a feature quad: fixed-order tree over r in LDS (deterministic)
@@ -122,15 +169,23 @@ __global__ __launch_bounds__(256) void normalize_bn_bwd_cols_kernel(const float*
     }
     if (!dok) return;
     const float inv_n = 1.0f / (float)N;
-    for (int i = r; i < N; i += 32) {
-        const size_t o = base + (size_t)i * D;
-        const float4 dy = *reinterpret_cast<const float4*>(dy_s + (size_t)i * 32 + 4 * c4), x = *reinterpret_cast<const float4*>(X + o);
-        float4 out;
-        out.x = av.x * (dy.x - inv_n * (tb.x + (x.x - mu.x) * rs.x * tg.x));
-        out.y = av.y * (dy.y - inv_n * (tb.y + (x.y - mu.y) * rs.y * tg.y));
-        out.z = av.z * (dy.z - inv_n * (tb.z + (x.z - mu.z) * rs.z * tg.z));
-        out.w = av.w * (dy.w - inv_n * (tb.w + (x.w - mu.w) * rs.w * tg.w));
-        *reinterpret_cast<float4*>(dX + o) = out;
+    for (int i0 = r; i0 < N; i0 += 128) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(X + base + (size_t)min(i0 + 32 * u, N - 1) * D);     // (second read of the slab: an L2 / MALL hit)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 32 * u;
+            if (i < N) {
+                const float4 dy = *reinterpret_cast<const float4*>(dy_s + (size_t)i * 32 + 4 * c4);
+                float4 out;
+                out.x = av.x * (dy.x - inv_n * (tb.x + (x[u].x - mu.x) * rs.x * tg.x));
+                out.y = av.y * (dy.y - inv_n * (tb.y + (x[u].y - mu.y) * rs.y * tg.y));
+                out.z = av.z * (dy.z - inv_n * (tb.z + (x[u].z - mu.z) * rs.z * tg.z));
+                out.w = av.w * (dy.w - inv_n * (tb.w + (x[u].w - mu.w) * rs.w * tg.w));
+                *reinterpret_cast<float4*>(dX + base + (size_t)i * D) = out;
+            }
+        }
     }
 }
 

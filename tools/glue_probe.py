@@ -75,3 +75,8 @@ if what in ("cfg1", "all"):
         print("%s, %d episodes: %.4f / %.4f ms per step without events, %.4f with; kernels %s (sum %.4f)" % (cfg, b, a, a2, e, kt, sum(kt.values())), flush=True)
         del step
         torch.cuda.empty_cache()
+
+if what in ("cfg4",):
+    r = bench._aux_paths(dev, "cfg4", 512, 64)["from_trunk_features"]
+    print("cfg4 from trunk features, 512 episodes: %.4f ms per step; kernels %s" % (r["ms_per_step"], r["kernels_ms"]), flush=True)
+    print("   hbm_frac %s" % {k: v["frac"] for k, v in r["roofline"].items()}, flush=True)
