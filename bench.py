@@ -403,7 +403,7 @@ def _workload(cfg, b, dev, rank, unit_rows):
                       n_backbone=n_backbone, kernel="bncossim")
 
 
-def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
+def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=10, only=None):
     """The two other entries into the same hot path, driver-timed next to the graded one, at the headline shape (cfg2: N = 105, D = 1600, C = 5) and at the
     20-way shape (cfg4: N = 420, D = 512, C = 20):
     `from_trunk_features` = what DKT.train_loop runs for bncossim -- N <= 128: bn_out in train mode + F.normalize folded into the Gram kernels
@@ -446,15 +446,22 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=5):
 
     res = {}
     for name, fn, nb in (("from_trunk_features", trunk, b), ("rbf_per_class_lengthscales", rbf, b_rbf)):
+        if only is not None and name != only:
+            continue
         for _ in range(2):
             info = fn()
         torch.cuda.synchronize()
-        ops.kernel_timing(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             info = fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        # the per-kernel HIP events in a pass of their own (they are required inside the timed region of the graded step only; here each pair costs the
+        # 1.3-ms step of 2048 episodes ~ 0.03 ms: tools/glue_probe.py)
+        ops.kernel_timing(True)
+        for _ in range(steps):
+            info = fn()
+        torch.cuda.synchronize()
         kt = {k: round(v[1], 4) for k, v in ops.kernel_timing_results().items()}
         ops.kernel_timing(False)
         # algorithmic bytes per episode of the calls of these paths (include/dkt_abi.h contracts: every operand once) -> HBM roofline per kernel
@@ -824,13 +831,12 @@ def run(args):
         kernels, roofline_all = _kernel_report(args.config, m, UNIT_ROWS, traffic)
         dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
         roofline = roofline_all.get(dom)
-        mll_arith = ("the factorisations, the triangular inverses and the K^-1 products as scaled 2-way f16 splits too (v_mfma_f32_16x16x16_f16, "
-                     "fp32 accumulate; diagonal-tile sweeps in fp32 on the VALU)" if n + 1 <= 128 else
-                     "the tile-array factorisations, triangular inverses and K^-1 products on scaled 2-way f16-split tiles too (v_mfma_f32_16x16x16_f16 / "
-                     "16x16x32_f16, fp32 accumulate; diagonal tiles and the alpha column in fp32)")
-        arith = ("f32 (results fp32-faithful; the two Gram contractions run as a scaled 2-way f16 split of every fp32 operand -- "
-                 "22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16 products, fp32 accumulate; " + mll_arith + ")" if UNIT_ROWS else
-                 "f32 (the two Gram contractions as an exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate; " + mll_arith + ")")
+        mll_arith = ("factorisations / triangular inverses / K^-1 products as scaled 2-way f16 splits too (16x16x16_f16; diagonal-tile sweeps fp32 on the VALU)"
+                     if n + 1 <= 128 else
+                     "tile-array / band factorisations on f16-split or fp32 MFMA tiles (DESIGN 4.2b-c; diagonal tiles and the alpha column fp32)")
+        arith = ("f32, results fp32-faithful: Gram contractions as a scaled 2-way f16 split of every operand (22 of 24 significand bits, 3 v_mfma_f32_16x16x32_f16, "
+                 "fp32 accumulate); " + mll_arith if UNIT_ROWS else
+                 "f32: Gram contractions as an exact 3-way bf16 split (6 v_mfma_f32_16x16x32_bf16, fp32 accumulate); " + mll_arith)
         out = {
             "metric": "episodes/sec", "value": round(eps, 1), "unit": "episodes/s", "n_gpus": distributed.world_size(),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -893,6 +899,9 @@ def run(args):
         # library reads its switches once)
         out["exact_fp32"] = _exact_fp32_run(args)
         out["other_paths_cfg2"] = _aux_paths(dev)
+        torch.cuda.empty_cache()
+        # the drop-in class' step at the headline's batch (the fused front-end kernels with their rooflines at 8192 episodes)
+        out["other_paths_cfg2"]["from_trunk_features_8192"] = _aux_paths(dev, "cfg2", 8192, steps=5, only="from_trunk_features")["from_trunk_features"]
         torch.cuda.empty_cache()
         out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 3)
         torch.cuda.empty_cache()
@@ -1038,12 +1047,14 @@ def _line_of(out):
                                        "dominant": _dominant(o["kernels"], o["roofline_by_kernel"])} for cfg, o in out["other_configs"].items()}
     for key in ("other_paths_cfg2", "other_paths_cfg4", "other_paths_cfg1"):
         if key in out:
-            line[key] = {name: {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
+            line[key] = {name: ({"value": o["value"], "ms_per_step": o["ms_per_step"], "valid": o["valid"], "hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}}
+                                if name.endswith("_8192") else          # (compact: kernel times and PMC traffic of this record are in the detail file)
+                                {"value": o["value"], "ms_per_step": o["ms_per_step"], "episodes_per_step": o["episodes_per_step"], "valid": o["valid"],
                                 "kernels_ms": {k: v for k, v in o["kernels_ms"].items() if k not in GLUE_KERNELS},
                                 # per kernel: algorithmic bytes / HIP-event time / 8 TB/s (the full roofline objects are in the detail file)
                                 **({"hbm_frac": {k: r["frac"] for k, r in o["roofline"].items()}} if "roofline" in o else {}),
                                 **({"traffic_x": {k: r["traffic_over_algorithmic"] for k, r in o["roofline"].items() if "traffic_over_algorithmic" in r}}
-                                   if any("traffic_over_algorithmic" in r for r in o.get("roofline", {}).values()) else {})}
+                                   if any("traffic_over_algorithmic" in r for r in o.get("roofline", {}).values()) else {})})
                          for name, o in out[key].items()}
     if "test_time_forward" in out:
         line["test_time_forward"] = {k: out["test_time_forward"][k] for k in ("value", "ms_per_step", "episodes_per_step")}
