@@ -403,7 +403,7 @@ def _workload(cfg, b, dev, rank, unit_rows):
                       n_backbone=n_backbone, kernel="bncossim")
 
 
-def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=10, only=None):
+def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=20, only=None):
     """The two other entries into the same hot path, driver-timed next to the graded one, at the headline shape (cfg2: N = 105, D = 1600, C = 5) and at the
     20-way shape (cfg4: N = 420, D = 512, C = 20):
     `from_trunk_features` = what DKT.train_loop runs for bncossim -- N <= 128: bn_out in train mode + F.normalize folded into the Gram kernels
@@ -448,7 +448,7 @@ def _aux_paths(dev, cfg="cfg2", b=2048, b_rbf=None, steps=10, only=None):
     for name, fn, nb in (("from_trunk_features", trunk, b), ("rbf_per_class_lengthscales", rbf, b_rbf)):
         if only is not None and name != only:
             continue
-        for _ in range(2):
+        for _ in range(max(2, steps // 2)):                   # (the first steps of a fresh shape run slower: allocator growth, clock ramp -- tools/glue_probe.py)
             info = fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -901,11 +901,11 @@ def run(args):
         out["other_paths_cfg2"] = _aux_paths(dev)
         torch.cuda.empty_cache()
         # the drop-in class' step at the headline's batch (the fused front-end kernels with their rooflines at 8192 episodes)
-        out["other_paths_cfg2"]["from_trunk_features_8192"] = _aux_paths(dev, "cfg2", 8192, steps=5, only="from_trunk_features")["from_trunk_features"]
+        out["other_paths_cfg2"]["from_trunk_features_8192"] = _aux_paths(dev, "cfg2", 8192, steps=10, only="from_trunk_features")["from_trunk_features"]
         torch.cuda.empty_cache()
-        out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 3)
+        out["other_paths_cfg4"] = _aux_paths(dev, "cfg4", 512, 64, 5)
         torch.cuda.empty_cache()
-        out["other_paths_cfg1"] = _aux_paths(dev, "cfg1", 8192, 2048, 5)          # the Omniglot shape from trunk features: the feature-space episode behind the streaming front end
+        out["other_paths_cfg1"] = _aux_paths(dev, "cfg1", 8192, 2048, 10)          # the Omniglot shape from trunk features: the feature-space episode behind the streaming front end
         torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_test_time and args.config != "cfg0":

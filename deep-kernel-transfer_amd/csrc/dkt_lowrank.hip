@@ -194,13 +194,23 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
         f32x4 zn[4];
         load_rows(rt + 1, zn);                                 // the next row tile's loads fly during this tile's products and stores
         float yv[NCT][4];
+        if (16 * rt + 16 <= N) {                               // (uniform) a row tile inside the episode: the lane's four targets are 16 consecutive bytes
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int n = 16 * ct + c;
+                const f32x4 y4 = bload4(Yr, (n < C) ? (n * N + 16 * rt + g4) * 4 : OOB, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 16 * ct + c, row = 16 * rt + g4 + r;
-                yv[ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, (n < C && row < N) ? (n * N + row) * 4 : OOB, 0, 0));
+                for (int r = 0; r < 4; ++r) yv[ct][r] = y4[r];
             }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * ct + c, row = 16 * rt + g4 + r;
+                    yv[ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Yr, (n < C && row < N) ? (n * N + row) * 4 : OOB, 0, 0));
+                }
+        }
         f32x4 S[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -213,24 +223,40 @@ __global__ __launch_bounds__(64) void lowrank_finish_kernel(const float* __restr
                 for (int j = 0; j < 4; ++j) sj[j] = mfma4(za[j][q], tb[ct][j][q], sj[j]);
             S[ct] = (sj[0] + sj[1]) + (sj[2] + sj[3]);
         }
-        // accumulator lane (g, c), register r: S[row 16 rt + 4 g + r][class 16 ct + c]
+        // accumulator lane (g, c), register r: S[row 16 rt + 4 g + r][class 16 ct + c] -- a lane's four registers are four CONSECUTIVE rows of one class: a row tile
+        // inside the episode leaves as one 16-byte store per lane, class tile and output (round 6; as 4-byte stores -- 64 isolated dwords per instruction, 16 instructions
+        // per row tile at 20 classes -- this kernel sat at 0.26 of HBM at the 20-way shape); the episode's last, partial tile keeps the masked 4-byte stores
+        const bool whole_tile = 16 * rt + 16 <= N;                 // uniform
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const int n = 16 * ct + c;
+            f32x4 al4, v4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * rt + g4 + r;
                 const bool ok = n < C && row < N;
-                const int off = ok ? (n * N + row) * 4 : OOB;
                 const float rr = ok ? yv[ct][r] - mc[ct] : 0.f;
                 const float s = ok ? S[ct][r] : 0.f;
                 const float al = (rr - svc[ct] * s) / nz[ct];
-                bstore1(Alr, al, off, 0);
-                bstore1(Vr, cws[ct] * (al - s), off, 0);
+                al4[r] = al;
+                v4[r] = cws[ct] * (al - s);
                 sa[ct] += al;
                 saa[ct] = fmaf(al, al, saa[ct]);
                 srr[ct] = fmaf(rr, rr, srr[ct]);
                 srs[ct] = fmaf(rr, s, srs[ct]);
+            }
+            if (whole_tile) {
+                const int off = (n < C) ? (n * N + 16 * rt + g4) * 4 : OOB;
+                bstore4(Alr, al4, off, 0);
+                bstore4(Vr, v4, off, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + g4 + r;
+                    const int off = (n < C && row < N) ? (n * N + row) * 4 : OOB;
+                    bstore1(Alr, al4[r], off, 0);
+                    bstore1(Vr, v4[r], off, 0);
+                }
             }
         }
 #pragma unroll

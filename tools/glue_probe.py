@@ -80,3 +80,13 @@ if what in ("cfg4",):
     r = bench._aux_paths(dev, "cfg4", 512, 64)["from_trunk_features"]
     print("cfg4 from trunk features, 512 episodes: %.4f ms per step; kernels %s" % (r["ms_per_step"], r["kernels_ms"]), flush=True)
     print("   hbm_frac %s" % {k: v["frac"] for k, v in r["roofline"].items()}, flush=True)
+
+if what in ("cfg1_20way", "lowrank"):
+    for cfg, b in (("cfg1", 8192), ("cfg1_20way", 2048)):
+        step, _ = bench._workload(cfg, b, dev, 0, True)
+        a, _ = timed(step, 20, False)
+        e, kt = timed(step, 20, True)
+        a2, _ = timed(step, 20, False)
+        print("%s, %d episodes: %.4f / %.4f ms per step without events, %.4f with; kernels %s (sum %.4f)" % (cfg, b, a, a2, e, kt, sum(kt.values())), flush=True)
+        del step
+        torch.cuda.empty_cache()
