@@ -308,8 +308,16 @@ class DKT(MetaTemplate):
                 # launch over all (episode, class) matrices (DKT_MLL_E_PER_CLASS), the chain rule back in two launches
                 obj, logp, alpha, info, jit, e = ops.episode_loss_class_kernel(zb, y, sv, mean, noise, cw, self.kernel_type, ls, off,
                                                                                self.jitter0, self.max_tries)
+            elif ops.mll_per_class_supported(n, 1):
+                # more than 32 classes (dkt_class_kernel_bwd_f32 takes up to 32 class maps per launch): the same one-launch path per GROUP of 32 classes --
+                # ceil(C / 32) groups instead of C single-model calls; the class weights already carry 1 / (C N), so the groups' objectives add up
+                parts = [ops.episode_loss_class_kernel(zb, y[..., k:k + 32, :].contiguous(), sv[k:k + 32], mean[k:k + 32], noise[k:k + 32], cw[k:k + 32],
+                                                       self.kernel_type, None if ls is None else ls[k:k + 32], None if off is None else off[k:k + 32],
+                                                       self.jitter0, self.max_tries) for k in range(0, c, 32)]
+                obj = torch.stack([pt[0] for pt in parts], 0).sum(0)
+                logp, alpha, info, jit, e = (torch.cat([pt[i] for pt in parts], 1) for i in range(1, 6))
             else:
-                # N > 447 or more than 32 classes: one Gram + one single-model launch per class
+                # N > 447: one Gram + one single-model launch per class (the blocked path serves those sizes)
                 objs, logps, alphas, infos, jits = [], [], [], [], []
                 for k in range(c):
                     e = ops.base_matrix(zb, self.kernel_type, None if ls is None else ls[k:k + 1], None if off is None else off[k:k + 1])
@@ -345,12 +353,21 @@ class DKT(MetaTemplate):
             mu, labels = ops.predict(ex_c, out["alpha"], sv, mean)                               # dkt_predict_per_class_f32
             return mu[0], labels[0], {key: out[key] for key in ("logp", "alpha", "jitter", "info")}
         mus, outs = [], []
-        for k in range(y.shape[-2]):
-            lk, ok = (None if ls is None else ls[k:k + 1]), (None if off is None else off[k:k + 1])
-            o = ops.mll(ops.kernel_matrix(zc, None, self.kernel_type, lk, ok), y[..., k:k + 1, :].contiguous(), sv[k:k + 1], mean[k:k + 1],
-                        noise[k:k + 1], jitter0=self.jitter0, max_tries=self.max_tries)
-            m, _ = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type, lk, ok), o["alpha"], sv[k:k + 1], mean[k:k + 1], want_labels=False)
-            mus.append(m); outs.append(o)
+        if ops.mll_per_class_supported(zc.shape[1], 1):
+            # more than 32 classes: the one-launch path per group of 32 classes
+            for k in range(0, y.shape[-2], 32):
+                lk, ok = (None if ls is None else ls[k:k + 32]), (None if off is None else off[k:k + 32])
+                o = ops.mll(ops.kernel_matrix_per_class(zc, None, self.kernel_type, lk, ok), y[..., k:k + 32, :].contiguous(), sv[k:k + 32], mean[k:k + 32],
+                            noise[k:k + 32], jitter0=self.jitter0, max_tries=self.max_tries)
+                m, _ = ops.predict(ops.kernel_matrix_per_class(zs, zc, self.kernel_type, lk, ok), o["alpha"], sv[k:k + 32], mean[k:k + 32], want_labels=False)
+                mus.append(m); outs.append(o)
+        else:
+            for k in range(y.shape[-2]):                     # N > 447: one single-model call per class
+                lk, ok = (None if ls is None else ls[k:k + 1]), (None if off is None else off[k:k + 1])
+                o = ops.mll(ops.kernel_matrix(zc, None, self.kernel_type, lk, ok), y[..., k:k + 1, :].contiguous(), sv[k:k + 1], mean[k:k + 1],
+                            noise[k:k + 1], jitter0=self.jitter0, max_tries=self.max_tries)
+                m, _ = ops.predict(ops.kernel_matrix(zs, zc, self.kernel_type, lk, ok), o["alpha"], sv[k:k + 1], mean[k:k + 1], want_labels=False)
+                mus.append(m); outs.append(o)
         mu = torch.cat(mus, 1)
         out = {key: torch.cat([o[key] for o in outs], 1) for key in ("logp", "alpha", "jitter", "info")}
         # first maximum wins, as np.argmax (torch.argmax does not promise which of several equal maxima it returns on the GPU)

@@ -2602,6 +2602,67 @@ def _every_kernel_type_check(cuda, kernel, per, n_support):
     assert np.abs(logits.t().cpu().numpy() - mu_r.numpy()).max() < 2e-3 * max(1.0, np.abs(mu_r.numpy()).max())
 
 
+@pytest.mark.parametrize("kernel", ["rbf", "poli2"])
+def test_dkt_per_class_kernels_more_than_32_classes(cuda, kernel):
+    """40 class models with their own lengthscale / offset (methods/DKT.py:63-66, 352-365 at n_way = 40): dkt_class_kernel_bwd_f32 takes 32 class maps per launch,
+    so the host runs the one-launch path per GROUP of 32 classes (two marginal-likelihood calls for training, two for the prediction) instead of 40 single-model
+    calls.  Loss, every parameter gradient and the posterior means against the float64 restatement."""
+    import copy
+    n_way, per, n_support = 40, 3, 2
+    calls = []
+    orig = ops.mll
+
+    def spy(e, *a, **k):
+        calls.append(tuple(e.shape))
+        return orig(e, *a, **k)
+
+    torch.manual_seed(4)
+    m = dkt_amd.DKT(dkt_amd.backbone.Conv4S, n_way=n_way, n_support=n_support, kernel_type=kernel).to(cuda)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        m.model.raw_outputscale.copy_(torch.rand(n_way, generator=g) - 0.4)
+        m.model.mean_constant.copy_(0.2 * torch.rand(n_way, generator=g) - 0.1)
+        if m.model.raw_lengthscale is not None:
+            m.model.raw_lengthscale.copy_(6.5 + 3.5 * torch.rand(n_way, generator=g))
+        if m.model.raw_offset is not None:
+            m.model.raw_offset.copy_(1.2 * torch.rand(n_way, generator=g) - 0.2)
+    ref = copy.deepcopy(m).cpu().double()
+    x = torch.rand(n_way, per, 3, 28, 28, generator=torch.Generator().manual_seed(6))
+    x_all = x.view(n_way * per, 3, 28, 28)
+    ops.mll = spy
+    try:
+        m.train()
+        loss, aux = m._episode_loss(m._embed(x_all.to(cuda)), m._targets(n_way, per, cuda))
+        loss.backward()
+        m.eval()
+        m.n_query = per - n_support
+        logits = m.get_logits(x)
+    finally:
+        ops.mll = orig
+    nt, ns = n_way * per, n_way * n_support
+    assert calls == [(1, 32, nt, nt), (1, 8, nt, nt), (1, 32, ns, ns), (1, 8, ns, ns)], calls
+    assert int(aux["info"].abs().max().item()) == 0 and aux["logp"].shape == (1, n_way) and aux["alpha"].shape == (1, n_way, nt) and aux["e"].shape == (1, n_way, nt, nt)
+    ref.train()
+    extra = ref.model.lengthscale if ref.model.raw_lengthscale is not None else ref.model.offset
+    loss_r, _, _ = T.classification_loss(ref._embed(x_all.double()), n_way, ref.model.outputscale, ref.model.mean, ref.model.noise, kernel, extra)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < MLL_RTOL * abs(loss_r.item())
+    for (name, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        if pr.grad is None:
+            assert p.grad is None, name
+            continue
+        diff = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - pr.grad.numpy())
+        assert diff <= 5e-3 * np.linalg.norm(pr.grad.numpy()) + 2e-5, (name, diff)
+    ref.eval()
+    with torch.no_grad():
+        zs = ref._embed(x[:, :n_support].reshape(ns, 3, 28, 28).double())
+        zq = ref._embed(x[:, n_support:].reshape(n_way * (per - n_support), 3, 28, 28).double())
+        _, _, alpha_s = T.classification_loss(zs, n_way, ref.model.outputscale, ref.model.mean, ref.model.noise, kernel, extra)
+        mu_r = T.predict_mean(zs, zq, alpha_s, ref.model.outputscale, ref.model.mean, kernel, extra)
+    assert logits.shape == (n_way * (per - n_support), n_way)
+    assert np.abs(logits.t().cpu().numpy() - mu_r.numpy()).max() < 2e-3 * max(1.0, np.abs(mu_r.numpy()).max())
+
+
 @pytest.mark.parametrize("kernel", ["bncossim", "rbf"])
 def test_correct_with_test_time_adaptation_matches_float64_adam(cuda, kernel):
     """`correct(x, N > 0)` (methods/DKT.py:242-272): N Adam steps (lr 1e-3) on the GP hyper-parameters only, on the support set,
