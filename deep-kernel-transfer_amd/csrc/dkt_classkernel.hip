@@ -345,9 +345,9 @@ extern "C" int dkt_class_kernel_f32(const float* base, int kind, const float* pa
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((NN + 255) / 256, B), block(256);
     switch (kind) {
-        case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_RBF>, grid, block, 0, st, base, param, power, E, C, NN); break;
-        case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, base, param, power, E, C, NN); break;
-        case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_POLY>, grid, block, 0, st, base, param, power, E, C, NN); break;
+        case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_RBF>, grid, block, dkt_lds_pad("DKT_PAD_CK_FWD"), st, base, param, power, E, C, NN); break;
+        case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_MATERN25>, grid, block, dkt_lds_pad("DKT_PAD_CK_FWD"), st, base, param, power, E, C, NN); break;
+        case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_fwd<DKT_CLASSMAP_POLY>, grid, block, dkt_lds_pad("DKT_PAD_CK_FWD"), st, base, param, power, E, C, NN); break;
         default: return DKT_ERR_BAD_ARG;
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
@@ -381,9 +381,9 @@ extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int k
     // N = 25 (a row fills 25 of a wave's 128 column slots) 0.092 -> 0.128: from 65 rows.
     if (N > 64 && N <= 128 && C <= 8 && class_bwd_n128()) {
         switch (kind) {
-            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_RBF>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
-            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
-            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_POLY>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_RBF>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_MATERN25>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_n128<DKT_CLASSMAP_POLY>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
             default: return DKT_ERR_BAD_ARG;
         }
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
@@ -391,9 +391,9 @@ extern "C" int dkt_class_kernel_bwd_f32(const float* W, const float* base, int k
     // (N <= 128: a row of 4-column groups leaves more than half of a wave's lanes idle -- 0.58 vs 0.28 ms at N = 105, C = 5, 2048 episodes: the dword kernel stays for C > 8)
     if (N > 128 && N <= 512 && g_ck_v4 != 0) {
         switch (kind) {
-            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_RBF>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
-            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_MATERN25>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
-            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_POLY>, grid, block, 0, st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_RBF: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_RBF>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_MATERN25: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_MATERN25>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
+            case DKT_CLASSMAP_POLY: hipLaunchKernelGGL(class_kernel_bwd_v4<DKT_CLASSMAP_POLY>, grid, block, dkt_lds_pad("DKT_PAD_CK_BWD"), st, W, base, param, power, Wp, dparam, C, N, nsplit); break;
             default: return DKT_ERR_BAD_ARG;
         }
         return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

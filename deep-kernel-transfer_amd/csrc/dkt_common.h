@@ -57,3 +57,10 @@ __device__ __forceinline__ float4 load4_guard(const float* row, int col, int nco
     }
     return v;
 }
+
+// Twins library only: bytes of dynamic LDS a launch reserves without touching them -- caps the workgroups per CU for occupancy A/Bs of the streaming kernels
+// (tools/occupancy_pad_ab.py; the product returns 0).
+static inline unsigned dkt_lds_pad(const char* name) {
+    const char* v = dkt_variant_env(name);
+    return v ? (unsigned)atoi(v) : 0u;
+}

@@ -196,7 +196,7 @@ extern "C" int dkt_affine_normalize_f32(const float* X, const float* a, const fl
     if ((D & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Zn & 15) || ((uintptr_t)a & 15) || ((uintptr_t)s & 15) || (ab_bstride & 3) || ab_bstride < 0) return DKT_ERR_BAD_ARG;
     const long rows = (long)B * N;
     if ((rows + 3) / 4 > 0x7fffffffL) return DKT_ERR_TOO_LARGE;
-    hipLaunchKernelGGL(affine_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, a, s, ab_bstride, Zn, rnorm, rows, N, D);
+    hipLaunchKernelGGL(affine_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), dkt_lds_pad("DKT_PAD_AFFNORM"), (hipStream_t)stream, X, a, s, ab_bstride, Zn, rnorm, rows, N, D);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
@@ -213,7 +213,7 @@ extern "C" int dkt_normalize_bn_bwd_f32(const float* dZn, const float* Zn, const
     const int nslab = (D + 31) / 32;
     if ((rows + 3) / 4 > 0x7fffffffL || (long)B * nslab > 0x7fffffffL) return DKT_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, Zn, dZn, rowdot_ws, rows, D);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), dkt_lds_pad("DKT_PAD_ROWDOT"), st, Zn, dZn, rowdot_ws, rows, D);
     if (train) {
         const size_t lds = ((size_t)N * 32 + 32 * 8 * 8) * sizeof(float);
         if (lds > 48 * 1024 &&
@@ -222,7 +222,7 @@ extern "C" int dkt_normalize_bn_bwd_f32(const float* dZn, const float* Zn, const
         hipLaunchKernelGGL(normalize_bn_bwd_cols_kernel<true>, dim3((unsigned)(B * nslab)), dim3(256), lds, st, dZn, Zn, X, a, a_bstride, mean, rstd, rnorm, rowdot_ws, dX,
                            dgamma_part, dbeta_part, N, D, nslab);
     } else {
-        hipLaunchKernelGGL(normalize_bn_bwd_cols_kernel<false>, dim3((unsigned)(B * nslab)), dim3(256), 0, st, dZn, Zn, X, a, a_bstride, mean, rstd, rnorm, rowdot_ws, dX,
+        hipLaunchKernelGGL(normalize_bn_bwd_cols_kernel<false>, dim3((unsigned)(B * nslab)), dim3(256), dkt_lds_pad("DKT_PAD_NBB"), st, dZn, Zn, X, a, a_bstride, mean, rstd, rnorm, rowdot_ws, dX,
                            dgamma_part, dbeta_part, N, D, nslab);
     }
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;

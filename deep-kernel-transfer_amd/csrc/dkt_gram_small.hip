@@ -37,11 +37,11 @@ constexpr int SM_PF = 4;                 // 16-feature steps in flight
 
 // WGT (round 5): a WORKGROUP per task instead of a wave per task -- wave w takes the feature blocks w, w + 4, ... (64 features each), so that the four waves
 // of a workgroup pull 1 KB of every row at a time instead of 256 B of the rows of four different tasks; the partial Grams meet in LDS at the end.
-template <int KIND, int NB, bool WGT>    // NB = 1: N <= 16, NB = 2: N <= 32
-__global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
+template <int KIND, int NB, int WGT>     // NB = 1: N <= 16, NB = 2: N <= 32; WGT = waves of a workgroup that share a task (0: a wave per task, 4, 8)
+__global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
                                                          const float* __restrict__ lengthscale) {
     __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
-    __shared__ f32x4 part[WGT ? 3 : 1][NB * (NB + 1) / 2][64];      // WGT: the partial Grams of waves 1..3
+    __shared__ f32x4 part[WGT ? WGT - 1 : 1][NB * (NB + 1) / 2][64];      // WGT: the partial Grams of waves 1..WGT - 1
     // (wave through readfirstlane: as a plain threadIdx.x >> 6 it is a VGPR value to the compiler, and every buffer load whose scalar offset or descriptor
     // depends on it gets a readfirstlane / compare / branch "waterfall" loop around it -- round 5, found in the ISA of the workgroup-per-task kernels)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
     f32x4 acc[NB * (NB + 1) / 2];
 #pragma unroll
     for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int sfirst = WGT ? wave * SM_PF : 0, sstride = WGT ? 4 * SM_PF : SM_PF;
+    const int sfirst = WGT ? wave * SM_PF : 0, sstride = WGT ? WGT * SM_PF : SM_PF;
 #pragma unroll
     for (int p = 0; p < SM_PF; ++p) load(p, sfirst + p);
     for (int s0 = sfirst; s0 < nstep; s0 += sstride) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
         __syncthreads();
         if (wave > 0) return;
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < WGT - 1; ++w)
 #pragma unroll
             for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] += part[w][i][lane];
     }
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const float* __restrict
 }
 
 // dZ[b] = s_b (W[b] + W[b]^T) Z[b], N <= 32.  WGT: a workgroup per task, wave w takes the 64-feature chunks w, w + 4, ... (as in the forward)
-template <bool WGT>
-__global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z, float* __restrict__ dZ,
+template <int WGT>
+__global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_bwd_kernel(const float* __restrict__ W, const float* __restrict__ Z, float* __restrict__ dZ,
                                                              int B, int N, int D, const float* __restrict__ ep_scale) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int b = WGT ? blockIdx.x : blockIdx.x * 4 + wave;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __rest
             }
         }
     };
-    const int c0 = WGT ? wave : 0, cs = WGT ? 4 : 1;
+    const int c0 = WGT ? wave : 0, cs = WGT ? WGT : 1;
     load(z0, c0);
     for (int ch = c0; ch < nchunk; ch += 2 * cs) {
         load(z1, ch + cs);
@@ -235,25 +235,37 @@ __global__ __launch_bounds__(256) void gram_small_bwd_kernel(const float* __rest
 // 0.076 -> 0.053 ms at 1024 tasks, 25 x 1600 0.261 -> 0.271: from 2048 features.  Twins library: DKT_GRAM_SMALL_WG=0 / 1 forces either form.
 static int g_small_wg = -2;
 void dkt_gram_small_reload_env() { g_small_wg = -2; }
-static bool small_wgt(int D, int mind) {
+static unsigned small_lds_pad() {                    // twins library: DKT_GRAM_SMALL_LDS = bytes of (unused) dynamic LDS per workgroup (the occupancy A/B; the backward's default: 56 KB)
+    const char* v = dkt_variant_env("DKT_GRAM_SMALL_LDS");
+    return v ? (unsigned)atoi(v) : 0u;
+}
+static int small_wgt(int D, int mind) {             // waves per task: 0 (a wave per task), 4, 8 (twins library, DKT_GRAM_SMALL_WG=2: measured, not the default)
     if (g_small_wg == -2) { const char* v = dkt_variant_env("DKT_GRAM_SMALL_WG"); g_small_wg = v ? atoi(v) : -1; }
-    if (g_small_wg >= 0) return g_small_wg != 0;
-    return D >= mind;
+    if (g_small_wg >= 0) return g_small_wg == 0 ? 0 : g_small_wg == 2 ? 8 : g_small_wg == 3 ? 16 : 4;     // (2, 3: eight / sixteen waves per task, twins library only)
+    return D >= mind ? 4 : 0;
 }
 
 // Symmetric Gram of small episodes (N <= 32, D % 4 == 0, 16-byte aligned Z); returns false when it does not apply.
 bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int kind, const float* lengthscale, hipStream_t st) {
     if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
     // workgroup per task: the forward from 2048 features (16 < N <= 32, linear / RBF: the QMUL head), see small_wgt()
-    const bool wgt = small_wgt(D, 2048) && N > 16 && kind != DKT_KERNEL_SQDIST;
-    const dim3 grid(wgt ? B : (B + 3) / 4), block(256);
+    const int wgt = (N > 16 && kind != DKT_KERNEL_SQDIST) ? small_wgt(D, 2048) : 0;
+    const dim3 grid(wgt ? B : (B + 3) / 4), block(wgt > 4 ? 64 * wgt : 256);
+    const unsigned pad = small_lds_pad();
 #define DKT_SM_LAUNCH(K)                                                                                              \
     do {                                                                                                              \
-        if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1, false>), grid, block, 0, st, Z, E, B, N, D, lengthscale);   \
-        else hipLaunchKernelGGL((gram_small_kernel<K, 2, false>), grid, block, 0, st, Z, E, B, N, D, lengthscale);           \
+        if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1, 0>), grid, block, pad, st, Z, E, B, N, D, lengthscale);   \
+        else hipLaunchKernelGGL((gram_small_kernel<K, 2, 0>), grid, block, pad, st, Z, E, B, N, D, lengthscale);           \
     } while (0)
-    if (wgt && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, true>), grid, block, 0, st, Z, E, B, N, D, lengthscale);
-    else if (wgt && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, true>), grid, block, 0, st, Z, E, B, N, D, lengthscale);
+#ifdef DKT_TWINS
+    if (wgt == 8 && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 8>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    else if (wgt == 8 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 8>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    else if (wgt == 16 && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 16>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    else if (wgt == 16 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 16>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    else
+#endif
+    if (wgt && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    else if (wgt && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
     else if (kind == DKT_KERNEL_LINEAR) DKT_SM_LAUNCH(DKT_KERNEL_LINEAR);
     else if (kind == DKT_KERNEL_RBF) DKT_SM_LAUNCH(DKT_KERNEL_RBF);
     else if (kind == DKT_KERNEL_SQDIST) DKT_SM_LAUNCH(DKT_KERNEL_SQDIST);
@@ -264,7 +276,19 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
 
 bool dkt_gram_small_bwd_launch(const float* W, const float* Z, float* dZ, int B, int N, int D, const float* sc, hipStream_t st) {
     if (N > 32 || (D & 3) || ((uintptr_t)Z & 15) || ((uintptr_t)dZ & 15) || (size_t)N * D * 4 >= 0x7fffff00ull) return false;
-    if (small_wgt(D, 1024)) hipLaunchKernelGGL(gram_small_bwd_kernel<true>, dim3(B), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
-    else hipLaunchKernelGGL(gram_small_bwd_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, W, Z, dZ, B, N, D, sc);
+    const int wgt = small_wgt(D, 1024);
+    // Workgroups per CU (round 6, tools/small_occ_ab.py, profiles/r06/small_occ_ab.log): the four-wave workgroup-per-task kernel streams FASTER at one or two workgroups
+    // per CU than at the three its registers allow -- 8192 tasks of 19 x 2916: 0.880 -> 0.801 ms, 10 x 2916: 0.400 -> 0.380, 32 x 2048: 0.846 -> 0.830, 25 x 1600:
+    // 0.499 -> 0.491 (two chunks of 19 rows x 256 B in flight per wave already cover the memory latency at eight waves per CU; more tasks in flight only add streams
+    // for the DRAM pages) -- so the launch reserves 56 KB of dynamic LDS it never touches: at most two workgroups per CU.  Bitwise the same results.
+    unsigned pad = wgt == 4 ? 57344u : 0u;
+#ifdef DKT_TWINS
+    if (dkt_variant_env("DKT_GRAM_SMALL_LDS")) pad = small_lds_pad();
+    if (wgt == 8) hipLaunchKernelGGL(gram_small_bwd_kernel<8>, dim3(B), dim3(512), pad, st, W, Z, dZ, B, N, D, sc);
+    else if (wgt == 16) hipLaunchKernelGGL(gram_small_bwd_kernel<16>, dim3(B), dim3(1024), pad, st, W, Z, dZ, B, N, D, sc);
+    else
+#endif
+    if (wgt) hipLaunchKernelGGL(gram_small_bwd_kernel<4>, dim3(B), dim3(256), pad, st, W, Z, dZ, B, N, D, sc);
+    else hipLaunchKernelGGL(gram_small_bwd_kernel<0>, dim3((B + 3) / 4), dim3(256), pad, st, W, Z, dZ, B, N, D, sc);
     return true;
 }

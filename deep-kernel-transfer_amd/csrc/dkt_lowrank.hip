@@ -402,8 +402,8 @@ extern "C" int dkt_lowrank_gram_f32(const float* Z, const float* Y, long y_bstri
     if (B <= 0 || C <= 0 || N <= 0 || D <= 0 || (D & 3) != 0) return DKT_ERR_BAD_ARG;
     if (!lr_shape_ok(B, C, N, D)) return DKT_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 16) hipLaunchKernelGGL((lowrank_gram_kernel<1>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, mean, A, P, C, N, D);
-    else hipLaunchKernelGGL((lowrank_gram_kernel<2>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, mean, A, P, C, N, D);
+    if (C <= 16) hipLaunchKernelGGL((lowrank_gram_kernel<1>), dim3(B), dim3(64), dkt_lds_pad("DKT_PAD_LR_GRAM"), st, Z, Y, y_bstride, mean, A, P, C, N, D);
+    else hipLaunchKernelGGL((lowrank_gram_kernel<2>), dim3(B), dim3(64), dkt_lds_pad("DKT_PAD_LR_GRAM"), st, Z, Y, y_bstride, mean, A, P, C, N, D);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
 
@@ -425,10 +425,10 @@ extern "C" int dkt_lowrank_finish_f32(const float* Z, const float* Y, long y_bst
     if (!lr_shape_ok(B, C, N, D)) return DKT_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16)
-        hipLaunchKernelGGL((lowrank_finish_kernel<1>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
+        hipLaunchKernelGGL((lowrank_finish_kernel<1>), dim3(B), dim3(64), dkt_lds_pad("DKT_PAD_LR_FIN"), st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
                            pre_jitter, jitter_total, obj, logp, alpha, V, dsv, dmean, dnoise, C, N, D);
     else
-        hipLaunchKernelGGL((lowrank_finish_kernel<2>), dim3(B), dim3(64), 0, st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
+        hipLaunchKernelGGL((lowrank_finish_kernel<2>), dim3(B), dim3(64), dkt_lds_pad("DKT_PAD_LR_FIN"), st, Z, Y, y_bstride, sv, mean, noise, cls_weight, T, logp_d, dnoise_d, jitter_used,
                            pre_jitter, jitter_total, obj, logp, alpha, V, dsv, dmean, dnoise, C, N, D);
     return hipGetLastError() == hipSuccess ? DKT_OK : DKT_ERR_LAUNCH;
 }
@@ -440,7 +440,7 @@ extern "C" int dkt_lowrank_bwd_f32(const float* Z, const float* V, const float* 
     if (!lr_shape_ok(B, C, N, D)) return DKT_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
     const int nkc = (C + 3) / 4;
-#define DKT_LR_BWD(K) hipLaunchKernelGGL((lowrank_bwd_kernel<K>), dim3(B), dim3(64), 0, st, Z, V, T, Wd, ep_scale, dZ, C, N, D)
+#define DKT_LR_BWD(K) hipLaunchKernelGGL((lowrank_bwd_kernel<K>), dim3(B), dim3(64), dkt_lds_pad("DKT_PAD_LR_BWD"), st, Z, V, T, Wd, ep_scale, dZ, C, N, D)
     if (nkc <= 2) DKT_LR_BWD(2);
     else if (nkc <= 4) DKT_LR_BWD(4);
     else if (nkc <= 5) DKT_LR_BWD(5);
