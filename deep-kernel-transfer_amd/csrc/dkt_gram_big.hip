@@ -502,12 +502,12 @@ void launch_rows(const float* W, const float* Z, float* dZ, int B, int N, int D,
     if (gram_bwd_rows8_enabled() && (KS >= 10 || (D >= 128 && (long)B * ((N + 127) / 128) >= 256))) {
         const int nrb = (N + 127) / 128;
         const int grid = 8 * ((B + 7) / 8) * nrb;
-        hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 8>), dim3(grid), dim3(512), 0, st, W, Z, dZ, B, N, D, sc, nrb);
+        hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 8>), dim3(grid), dim3(512), dkt_lds_pad("DKT_PAD_GRAM_BIG_BWD"), st, W, Z, dZ, B, N, D, sc, nrb);
         return;
     }
     const int nrb = (N + 63) / 64;
     const int grid = 8 * ((B + 7) / 8) * nrb;
-    hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 4>), dim3(grid), dim3(256), 0, st, W, Z, dZ, B, N, D, sc, nrb);
+    hipLaunchKernelGGL((gram_bwd_rows_f16x2_kernel<KS, 4>), dim3(grid), dim3(256), dkt_lds_pad("DKT_PAD_GRAM_BIG_BWD"), st, W, Z, dZ, B, N, D, sc, nrb);
 }
 
 }  // namespace

@@ -825,7 +825,7 @@ void launch_sym(const float* Z, float* E, int B, int N, int D, int bk, bool unit
         // the product: unit rows -> scaled 2-way f16 split, 2 stage buffers, prefetch depth 2, 3 workgroups per CU, non-temporal Z loads (22232);
         // any rows -> exact 3-way bf16 split, 1 buffer, depth 1 (11)
         // (NT = 8 at TWO workgroups per CU: built for three it spills 24 registers into the slab loop, and every scratch reload is a `vmcnt(0)` that drains the prefetch)
-        if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, NT == 8 ? 2 : 3, 2>), dim3(B), dim3(256), 0, st, Z, E, N, D);
+        if (v == 22232) hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 2, 2, 32, 2, NT == 8 ? 2 : 3, 2>), dim3(B), dim3(256), dkt_lds_pad("DKT_PAD_GRAM_EP"), st, Z, E, N, D);
         else hipLaunchKernelGGL((gram_sym_ep_split_kernel<NT, 1, 1>), dim3(B), dim3(256), 0, st, Z, E, N, D);
         return;
     }
@@ -852,8 +852,8 @@ void launch_bwd(const float* W, const float* Z, float* dZ, int B, int N, int D, 
         }
 #endif
         // the product: unit rows -> f16 split, one LDS image below D = 1024 (211), two + non-temporal dZ stores from there (1222); any rows -> bf16 split (11)
-        if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
-        if (v == 211) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
+        if (v == 1222) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 2, 2, 1>), dim3(B), dim3(64 * NT), dkt_lds_pad("DKT_PAD_GRAM_EP_BWD"), st, W, Z, dZ, N, D, sc); return; }
+        if (v == 211) { hipLaunchKernelGGL((gram_bwd_ep_f16x2_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), dkt_lds_pad("DKT_PAD_GRAM_EP_BWD"), st, W, Z, dZ, N, D, sc); return; }
         if constexpr (NT <= 7) {                              // one stage buffer must also hold the N x N staging copy of W
             if (v == 11) { hipLaunchKernelGGL((gram_bwd_ep_bf16x3_kernel<NT, 1, 1>), dim3(B), dim3(64 * NT), 0, st, W, Z, dZ, N, D, sc); return; }
         }
