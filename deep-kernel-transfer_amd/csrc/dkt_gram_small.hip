@@ -33,11 +33,21 @@ __device__ __forceinline__ f32x4 sm_load4(brsrc r, int voff, int soff) {
     return (f32x4){__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
 
+// the value of lane I of the own 16-lane group (ds_swizzle, bit-mask mode: lane' = (lane & 0x10) | I inside each group of 32; the crossbar only, no LDS storage)
+template <int I>
+__device__ __forceinline__ float sm_bcast16(const float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (I << 5) | 0x10));
+}
+
 constexpr int SM_PF = 4;                 // 16-feature steps in flight
 
 // WGT (round 5): a WORKGROUP per task instead of a wave per task -- wave w takes the feature blocks w, w + 4, ... (64 features each), so that the four waves
 // of a workgroup pull 1 KB of every row at a time instead of 256 B of the rows of four different tasks; the partial Grams meet in LDS at the end.
-template <int KIND, int NB, int WGT>     // NB = 1: N <= 16, NB = 2: N <= 32; WGT = waves of a workgroup that share a task (0: a wave per task, 4, 8)
+// XR (round 6; NB = 2 and 16 < N <= 16 + XR <= 20 -- the QMUL head's 19 frames): the XR rows beyond the first sixteen fill 3 / 16 of the two tiles they add, i.e. two of
+// the three MFMAs of a step multiply padding.  With XR > 0 only tile (0, 0) runs on the matrix pipe; row 16 + i is broadcast inside every 16-lane group (ds_swizzle:
+// no LDS storage involved) and its products with the sixteen rows above and with the other extra rows are 2 x 4 fused multiply-adds per lane, summed over the four
+// feature groups of a wave at the end (fixed order) into the same accumulator layout the epilogue reads.
+template <int KIND, int NB, int WGT, int XR = 0>     // NB = 1: N <= 16, NB = 2: N <= 32; WGT = waves of a workgroup that share a task (0: a wave per task, 4, 8)
 __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
                                                          const float* __restrict__ lengthscale) {
     __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
@@ -62,6 +72,9 @@ __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(co
     f32x4 acc[NB * (NB + 1) / 2];
 #pragma unroll
     for (int i = 0; i < NB * (NB + 1) / 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float e1[XR ? XR : 1], e1x[XR ? XR : 1];                          // XR: lane (g, r): partial (row 16 + i) . (row r) and (row 16 + i) . (row 16 + r) over the features of group g
+#pragma unroll
+    for (int i = 0; i < (XR ? XR : 1); ++i) e1[i] = e1x[i] = 0.f;
     const int sfirst = WGT ? wave * SM_PF : 0, sstride = WGT ? WGT * SM_PF : SM_PF;
 #pragma unroll
     for (int p = 0; p < SM_PF; ++p) load(p, sfirst + p);
@@ -83,12 +96,35 @@ __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(co
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[0][t], xb[0][t], acc[0], 0, 0, 0);
-                if constexpr (NB == 2) {
+                if constexpr (NB == 2 && XR > 0) {
+#define DKT_SM_XROW(I)                                                                                  \
+    if constexpr (XR > I) {                                                                             \
+        const float bi = sm_bcast16<I>(xb[1][t]);                                                       \
+        e1[I] = fmaf(xb[0][t], bi, e1[I]);                                                              \
+        e1x[I] = fmaf(xb[1][t], bi, e1x[I]);                                                            \
+    }
+                    DKT_SM_XROW(0) DKT_SM_XROW(1) DKT_SM_XROW(2) DKT_SM_XROW(3)
+#undef DKT_SM_XROW
+                } else if constexpr (NB == 2) {
                     acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[1][t], xb[0][t], acc[1], 0, 0, 0);      // rows 16.., columns 0..15
                     acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[1][t], xb[1][t], acc[2], 0, 0, 0);
                 }
             }
         }
+    }
+    if constexpr (NB == 2 && XR > 0) {   // the four feature groups of the wave meet (a butterfly: every lane ends with the same sum), then into the tile layout:
+        // tile (1, 0) element [4 g + q][c] = row 16 + 4 g + q, column c: lanes g = 0, register q = e1[q]; tile (1, 1) the same with e1x (columns 16 + c)
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            float u = e1[i], v = e1x[i];
+            u += __shfl_xor(u, 16); u += __shfl_xor(u, 32);
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            t1[i] = g == 0 ? u : 0.f;
+            t2[i] = g == 0 ? v : 0.f;
+        }
+        acc[1] = t1;
+        acc[2] = t2;
     }
     if constexpr (WGT) {                 // partial Grams of waves 1..3 -> wave 0 (fixed order: bitwise reproducible)
         if (wave > 0) {
@@ -252,6 +288,12 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
     const int wgt = (N > 16 && kind != DKT_KERNEL_SQDIST) ? small_wgt(D, 2048) : 0;
     const dim3 grid(wgt ? B : (B + 3) / 4), block(wgt > 4 ? 64 * wgt : 256);
     const unsigned pad = small_lds_pad();
+    // rows beyond sixteen on the VALU: the default for RBF (tools/small_xr_ab.py, profiles/r06/small_xr_ab.log; per 8192 tasks of 19 x 2916 0.396 -> 0.394 ms, 20 x 2916
+    // 0.398 -> 0.372, 19 x 512 0.074 -> 0.071, 1024 tasks of 19 x 2916 0.049 -> 0.040); the linear kernel (no row shift on the VALU) measured 0.369 -> 0.387 and keeps
+    // its MFMA tiles.  Twins library: DKT_GRAM_SMALL_XR = 0 / 1 = neither / both kinds.
+    bool xr_on = kind == DKT_KERNEL_RBF;
+    { const char* v = dkt_variant_env("DKT_GRAM_SMALL_XR"); if (v) xr_on = atoi(v) != 0; }
+    const int xr = (xr_on && N > 16 && N <= 20 && (wgt == 0 || wgt == 4) && kind != DKT_KERNEL_SQDIST) ? (N <= 19 ? 3 : 4) : 0;
 #define DKT_SM_LAUNCH(K)                                                                                              \
     do {                                                                                                              \
         if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1, 0>), grid, block, pad, st, Z, E, B, N, D, lengthscale);   \
@@ -264,6 +306,23 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
     else if (wgt == 16 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 16>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
     else
 #endif
+    // 17 .. 20 rows (the QMUL head: 19): the rows beyond sixteen on the VALU (template parameter XR), see the kernel.  Twins library: DKT_GRAM_SMALL_XR=0 = MFMA tiles
+#ifdef DKT_TWINS
+    if (xr && wgt && kind == DKT_KERNEL_LINEAR) {
+        if (xr == 3) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4, 3>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    } else if (xr && kind == DKT_KERNEL_LINEAR) {
+        if (xr == 3) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 0, 3>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 0, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    } else
+#endif
+    if (xr && wgt && kind == DKT_KERNEL_RBF) {
+        if (xr == 3) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 3>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    } else if (xr && kind == DKT_KERNEL_RBF) {
+        if (xr == 3) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 0, 3>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+        else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 0, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
+    } else
     if (wgt && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
     else if (wgt && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
     else if (kind == DKT_KERNEL_LINEAR) DKT_SM_LAUNCH(DKT_KERNEL_LINEAR);

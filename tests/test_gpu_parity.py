@@ -2338,10 +2338,12 @@ def test_class_kernel_backward_row_kernel_twin(cuda, monkeypatch, b, c, n, cmap,
     assert rel_l2(out["1"][0].cpu().numpy(), out["0"][0].cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("b,n,d,kind", [(5, 19, 2916, "rbf"), (3, 25, 1600, "linear"), (6, 32, 2052, "linear"), (2, 17, 4096, "rbf"), (7, 10, 2916, "rbf")])
+@pytest.mark.parametrize("b,n,d,kind", [(5, 19, 2916, "rbf"), (3, 25, 1600, "linear"), (6, 32, 2052, "linear"), (2, 17, 4096, "rbf"), (7, 10, 2916, "rbf"),
+                                        (4, 20, 2916, "rbf"), (9, 18, 512, "linear"), (3, 19, 2916, "linear"), (5, 20, 64, "rbf")])
 def test_small_gram_workgroup_per_task_twin(cuda, monkeypatch, b, n, d, kind):
     """N <= 32 with long rows (round 5): a workgroup per task (DKT_GRAM_SMALL_WG=1; the default from 2048 / 1024 features) against the wave-per-task kernels
-    (=0) and float64 -- the forward sums its four partial Grams in a fixed order (equal to rounding, bitwise reproducible), the backward is bitwise equal."""
+    (=0) and float64 -- the forward sums its four partial Grams in a fixed order (equal to rounding, bitwise reproducible), the backward is bitwise equal.
+    Round 6: 17 <= N <= 20 forms the rows beyond sixteen on the VALU (the default; DKT_GRAM_SMALL_XR=0 = three MFMA tiles): both forms, both launch shapes."""
     rng = np.random.default_rng(n * 7 + d)
     z = (rng.standard_normal((b, n, d)) * 0.05).astype(np.float32)
     w = (rng.standard_normal((b, n, n)) * 0.1).astype(np.float32)
@@ -2349,24 +2351,37 @@ def test_small_gram_workgroup_per_task_twin(cuda, monkeypatch, b, n, d, kind):
     ls = torch.tensor([1.1], device=cuda)
     k = ops.KERNEL_RBF if kind == "rbf" else ops.KERNEL_LINEAR
     out = {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("DKT_GRAM_SMALL_WG", v)
+    variants = [("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")]            # (workgroup per task, extra rows on the VALU)
+    for v in variants:
+        monkeypatch.setenv("DKT_GRAM_SMALL_WG", v[0])
+        monkeypatch.setenv("DKT_GRAM_SMALL_XR", v[1])
         out[v] = (ops.gram(zd, None, k, ls if kind == "rbf" else None), ops.gram_bwd(wd, zd))
         e2 = ops.gram(zd, None, k, ls if kind == "rbf" else None)
         assert torch.equal(e2, out[v][0])
     monkeypatch.delenv("DKT_GRAM_SMALL_WG")
-    assert torch.equal(out["0"][1], out["1"][1])
+    monkeypatch.delenv("DKT_GRAM_SMALL_XR")
+    for v in variants[1:]:
+        assert torch.equal(out[variants[0]][1], out[v][1])
+    if not 16 < n <= 20:                                                   # outside 17 .. 20 rows the switch selects nothing
+        assert torch.equal(out[("0", "1")][0], out[("0", "0")][0]) and torch.equal(out[("1", "1")][0], out[("1", "0")][0])
     z64 = z.astype(np.float64)
     for i in range(b):
         g = z64[i] @ z64[i].T
         if kind == "rbf":
             d2 = np.maximum(np.diag(g)[:, None] + np.diag(g)[None, :] - 2 * g, 0.0)
             g = np.exp(-0.5 * d2 / 1.1 ** 2)
-        for v in ("0", "1"):
-            assert np.abs(out[v][0][i].cpu().numpy() - g).max() < 2e-6 * max(1.0, np.abs(g).max()), (v, i)
+        for v in variants:
+            # (4e-6: the wave-per-task kernel sums all D products of an element in ONE fp32 chain -- 2.0e-6 on the diagonal of a 19 x 2916 linear Gram)
+            assert np.abs(out[v][0][i].cpu().numpy() - g).max() < 4e-6 * max(1.0, np.abs(g).max()), (v, i)
         dz = (w[i].astype(np.float64) + w[i].astype(np.float64).T) @ z64[i]
-        assert rel_l2(out["1"][1][i].cpu().numpy(), dz) < 2e-6
-    assert torch.equal(out["1"][0], out["1"][0].transpose(1, 2))
+        assert rel_l2(out[("1", "1")][1][i].cpu().numpy(), dz) < 2e-6
+    for v in variants:
+        assert torch.equal(out[v][0], out[v][0].transpose(1, 2)), v
+    # the product library's default dispatch is one of the twins, bitwise
+    monkeypatch.setenv("DKT_TWINS", "0")
+    e_prod = ops.gram(zd, None, k, ls if kind == "rbf" else None)
+    assert any(torch.equal(e_prod, out[v][0]) for v in variants)
+    assert torch.equal(ops.gram_bwd(wd, zd), out[variants[0]][1])
 
 
 @pytest.mark.parametrize("n,d", [(105, 1600), (85, 512), (50, 96), (128, 64), (40, 2916)])
