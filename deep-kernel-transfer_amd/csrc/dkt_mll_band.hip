@@ -1153,6 +1153,8 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
     t.grad = (a.flags & DKT_MLL_WANT_GRAD) ? 1 : 0;
     const int NT = t.g.NT;
     const size_t lds = (size_t)sym_lds_floats(NT) * sizeof(float);
+    // (twins library: DKT_PAD_BAND_FWD / _BACK / _CLASS = bytes of untouched dynamic LDS on top: one workgroup per CU instead of two -- the occupancy A/B of MEASUREMENTS R6d)
+    auto band_pad = [](const size_t base, const char* name) { const size_t v = base + dkt_lds_pad(name); return v > 98304 ? (size_t)98304 : v; };
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)band_sym_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) return DKT_ERR_LAUNCH;
@@ -1167,10 +1169,10 @@ int dkt_mll_band_launch(const MllArgs& a, void* workspace, size_t ws_bytes, hipS
         t.bcnt = bcnt;
         const int slots = NT * (NT + 1) / 2 + 3 * NT * t.g.CP;
         hipLaunchKernelGGL(band_init_kernel, dim3((slots + 3) / 4, bcnt), dim3(256), 0, st, t);
-        hipLaunchKernelGGL(band_sym_kernel<false>, dim3(bcnt), dim3(256), lds, st, t);
-        hipLaunchKernelGGL(band_class_kernel, dim3(bcnt, (a.C + 3) / 4), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(band_sym_kernel<false>, dim3(bcnt), dim3(256), band_pad(lds, "DKT_PAD_BAND_FWD"), st, t);
+        hipLaunchKernelGGL(band_class_kernel, dim3(bcnt, (a.C + 3) / 4), dim3(256), dkt_lds_pad("DKT_PAD_BAND_CLASS"), st, t);
         if (t.grad) hipLaunchKernelGGL(band_chain_kernel, dim3(bcnt), dim3(64 * CHAIN_WAVES), 4 * BAND_MAXNT * 1024, st, t);
-        hipLaunchKernelGGL(band_sym_kernel<true>, dim3(bcnt), dim3(256), lds, st, t);
+        hipLaunchKernelGGL(band_sym_kernel<true>, dim3(bcnt), dim3(256), band_pad(lds, "DKT_PAD_BAND_BACK"), st, t);
 #ifndef DKT_BAND_CLOCKS                       // (the measurement build reports its phase clocks through alpha)
         hipLaunchKernelGGL(band_finish_kernel, dim3(NT, bcnt), dim3(256), fin_lds_floats(NT) * sizeof(float), st, t);
         hipLaunchKernelGGL(band_reduce_kernel, dim3(bcnt), dim3(64), 0, st, t);
