@@ -47,10 +47,7 @@ constexpr int SM_PF = 4;                 // 16-feature steps in flight
 // the three MFMAs of a step multiply padding.  With XR > 0 only tile (0, 0) runs on the matrix pipe; row 16 + i is broadcast inside every 16-lane group (ds_swizzle:
 // no LDS storage involved) and its products with the sixteen rows above and with the other extra rows are 2 x 4 fused multiply-adds per lane, summed over the four
 // feature groups of a wave at the end (fixed order) into the same accumulator layout the epilogue reads.
-// COAL (round 6): the MFMA operand layout puts sixteen DIFFERENT rows into each quarter of a wave (lane (g, r) holds row r), so a 16-byte load per lane touches sixteen
-// cache lines per quarter wave for 256 bytes.  With COAL lane (g, 4 a + c) loads row 4 a + g at the features 4 c .. 4 c + 3 instead -- a quarter wave reads four rows x
-// 64 contiguous bytes -- and the 4 x 4 transpose of (g, c) inside every group of sixteen lanes that restores the operand layout is one ds_bpermute per register.
-template <int KIND, int NB, int WGT, int XR = 0, bool COAL = false, int PF = SM_PF>     // NB = 1: N <= 16, NB = 2: N <= 32; WGT = waves of a workgroup that share a task (0: a wave per task, 4, 8)
+template <int KIND, int NB, int WGT, int XR = 0>     // NB = 1: N <= 16, NB = 2: N <= 32; WGT = waves of a workgroup that share a task (0: a wave per task, 4, 8)
 __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(const float* __restrict__ Z, float* __restrict__ E, int B, int N, int D,
                                                          const float* __restrict__ lengthscale) {
     __shared__ float dvec[4][32];        // per wave: the Gram's diagonal (squared row norms of the shifted rows)
@@ -63,18 +60,13 @@ __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(co
     const brsrc zr = sm_rsrc(Z + (size_t)b * N * D, (unsigned)((size_t)N * D * 4));
     int voff[NB];
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        if constexpr (COAL) voff[blk] = (16 * blk + (r & 12) + g < N) ? ((16 * blk + (r & 12) + g) * D + 4 * (r & 3)) * 4 : SM_OOB;
-        else voff[blk] = (16 * blk + r < N) ? ((16 * blk + r) * D + 4 * g) * 4 : SM_OOB;
-    }
-    const int tsrc = (16 * (r & 3) + (r & 12) + g) * 4;              // COAL: lane (g, 4 a + c) takes its operand from lane (c, 4 a + g) (ds_bpermute byte address)
+    for (int blk = 0; blk < NB; ++blk) voff[blk] = (16 * blk + r < N) ? ((16 * blk + r) * D + 4 * g) * 4 : SM_OOB;
     const int nstep = (D + 15) >> 4;
-    f32x4 x[PF][NB], ref[PF];
+    f32x4 x[SM_PF][NB], ref[SM_PF];
     auto load = [&](const int slot, const int s) {
         const bool in = s < nstep && 16 * s + 4 * g < D;             // D % 4 == 0: a float4 is inside the row or wholly beyond it
-        const bool inx = COAL ? (s < nstep && 16 * s + 4 * (r & 3) < D) : in;
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) x[slot][blk] = sm_load4(zr, inx ? voff[blk] : SM_OOB, s * 64);
+        for (int blk = 0; blk < NB; ++blk) x[slot][blk] = sm_load4(zr, in ? voff[blk] : SM_OOB, s * 64);
         if (KIND != DKT_KERNEL_LINEAR) ref[slot] = sm_load4(zr, in ? 16 * g : SM_OOB, s * 64);
     };
     f32x4 acc[NB * (NB + 1) / 2];
@@ -83,20 +75,16 @@ __global__ __launch_bounds__(WGT > 4 ? 64 * WGT : 256) void gram_small_kernel(co
     float e1[XR ? XR : 1], e1x[XR ? XR : 1];                          // XR: lane (g, r): partial (row 16 + i) . (row r) and (row 16 + i) . (row 16 + r) over the features of group g
 #pragma unroll
     for (int i = 0; i < (XR ? XR : 1); ++i) e1[i] = e1x[i] = 0.f;
-    const int sfirst = WGT ? wave * PF : 0, sstride = WGT ? WGT * PF : PF;
+    const int sfirst = WGT ? wave * SM_PF : 0, sstride = WGT ? WGT * SM_PF : SM_PF;
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load(p, sfirst + p);
+    for (int p = 0; p < SM_PF; ++p) load(p, sfirst + p);
     for (int s0 = sfirst; s0 < nstep; s0 += sstride) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
+        for (int p = 0; p < SM_PF; ++p) {
             f32x4 xb[NB];
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk) {
                 xb[blk] = x[p][blk];
-                if constexpr (COAL) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) xb[blk][t] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(xb[blk][t])));
-                }
                 if (KIND != DKT_KERNEL_LINEAR) {
                     // rows beyond N loaded as 0 and must stay 0 (not -ref): the mask rides on the row test
                     const bool row_ok = 16 * blk + r < N;
@@ -299,17 +287,16 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
     // workgroup per task: the forward from 2048 features (16 < N <= 32, linear / RBF: the QMUL head), see small_wgt()
     const int wgt = (N > 16 && kind != DKT_KERNEL_SQDIST) ? small_wgt(D, 2048) : 0;
     const dim3 grid(wgt ? B : (B + 3) / 4), block(wgt > 4 ? 64 * wgt : 256);
-    const unsigned pad = small_lds_pad();
+    unsigned pad = small_lds_pad();
     // rows beyond sixteen on the VALU: the default for RBF (tools/small_xr_ab.py, profiles/r06/small_xr_ab.log; per 8192 tasks of 19 x 2916 0.396 -> 0.394 ms, 20 x 2916
     // 0.398 -> 0.372, 19 x 512 0.074 -> 0.071, 1024 tasks of 19 x 2916 0.049 -> 0.040); the linear kernel (no row shift on the VALU) measured 0.369 -> 0.387 and keeps
     // its MFMA tiles.  Twins library: DKT_GRAM_SMALL_XR = 0 / 1 = neither / both kinds.
     bool xr_on = kind == DKT_KERNEL_RBF;
     { const char* v = dkt_variant_env("DKT_GRAM_SMALL_XR"); if (v) xr_on = atoi(v) != 0; }
     const int xr = (xr_on && N > 16 && N <= 20 && (wgt == 0 || wgt == 4) && kind != DKT_KERNEL_SQDIST) ? (N <= 19 ? 3 : 4) : 0;
-    bool coal = false;
-    { const char* v = dkt_variant_env("DKT_GRAM_SMALL_COAL"); if (v) coal = atoi(v) != 0; }
-    bool pf8 = false;
-    { const char* v = dkt_variant_env("DKT_GRAM_SMALL_PF"); if (v) pf8 = atoi(v) == 8; }
+    // the XR instance of the four-wave kernel (91 registers: five workgroups per CU) streams best at THREE per CU once every CU has a queue of tasks (tools/small_pf_ab.py,
+    // profiles/r06/small_pf_ab.log: 8192 tasks of 19 x 2916 0.381 -> 0.357 ms, 0.386 at two; 1024 tasks: 0.039 -> 0.043, no cap there): 40 KB of untouched dynamic LDS
+    if (xr && wgt == 4 && B >= 4096 && !dkt_variant_env("DKT_GRAM_SMALL_LDS")) pad = 40960u;
 #define DKT_SM_LAUNCH(K)                                                                                              \
     do {                                                                                                              \
         if (N <= 16) hipLaunchKernelGGL((gram_small_kernel<K, 1, 0>), grid, block, pad, st, Z, E, B, N, D, lengthscale);   \
@@ -332,14 +319,6 @@ bool dkt_gram_small_launch(const float* Z, float* E, int B, int N, int D, int ki
         else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 0, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
     } else
 #endif
-    if (pf8 && xr == 3 && wgt == 4 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 3, false, 8>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else if (pf8 && !xr && wgt == 4 && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4, 0, false, 8>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else
-    if (coal && xr == 3 && wgt == 4 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 3, true>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else if (coal && !xr && wgt == 4 && kind == DKT_KERNEL_RBF) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 0, true>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else if (coal && !xr && wgt == 4 && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 4, 0, true>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else if (coal && !xr && wgt == 0 && N > 16 && kind == DKT_KERNEL_LINEAR) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_LINEAR, 2, 0, 0, true>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
-    else
     if (xr && wgt && kind == DKT_KERNEL_RBF) {
         if (xr == 3) hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 3>), grid, block, pad, st, Z, E, B, N, D, lengthscale);
         else hipLaunchKernelGGL((gram_small_kernel<DKT_KERNEL_RBF, 2, 4, 4>), grid, block, pad, st, Z, E, B, N, D, lengthscale);

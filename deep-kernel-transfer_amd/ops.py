@@ -117,7 +117,7 @@ _VARIANT_SWITCHES = ("DKT_GRAM_EP", "DKT_GRAM_SPLIT", "DKT_GRAM_EP_BK", "DKT_GRA
                      "DKT_GRAM_BWD_SPLIT_VAR", "DKT_GRAM_BWD_UNIT_MIND", "DKT_GRAM_BWD_SPLIT_MIND", "DKT_MLL_TILED_F16", "DKT_GRAM_DIST_EP", "DKT_MLL_P2_GUARD",
                      "DKT_MLL_TILED_WRES", "DKT_MLL_TILED_INVRES", "DKT_GRAM_BIG_EP", "DKT_MLL_TILED_WGS", "DKT_GRAM_BWD_ROWS8", "DKT_MLL_TILED_WDMA", "DKT_CLASS_BWD_V4",
                      "DKT_MLL_TILED_WNW", "DKT_GRAM_SMALL", "DKT_BIG_NB", "DKT_GRAM_BN_F16", "DKT_LDS_STAGE_OLD", "DKT_GRAM_SMALL_WG", "DKT_CLASS_BWD_N128", "DKT_GRAM_FEWEP",
-                     "DKT_GRAM_SMALL_XR", "DKT_GRAM_SMALL_LDS", "DKT_GRAM_SMALL_COAL", "DKT_GRAM_SMALL_PF")
+                     "DKT_GRAM_SMALL_XR", "DKT_GRAM_SMALL_LDS")
 _ENV_SWITCHES = _PRODUCT_SWITCHES + _VARIANT_SWITCHES
 _env_seen = {}
 

@@ -1,4 +1,5 @@
-"""A/B of the N <= 32 Gram forward's prefetch depth (dkt_gram_small.hip; twins library): DKT_GRAM_SMALL_PF=8 (eight 16-feature steps in flight per wave instead of four)
+"""(The DKT_GRAM_SMALL_PF instances were removed after this measurement -- commit 06c82cc has them; the script still sweeps the cap for the shipped depth.)
+A/B of the N <= 32 Gram forward's prefetch depth (dkt_gram_small.hip; twins library): DKT_GRAM_SMALL_PF=8 (eight 16-feature steps in flight per wave instead of four)
 under the workgroups-per-CU cap DKT_GRAM_SMALL_LDS.   python tools/small_pf_ab.py"""
 import importlib
 import os

@@ -1,4 +1,5 @@
-"""A/B of the N <= 32 Gram forward with the rows beyond sixteen on the VALU (dkt_gram_small.hip, template parameter XR; 17 <= N <= 20: the QMUL head's 19 frames) against
+"""(The "c" column = DKT_GRAM_SMALL_COAL, coalesced loads + a lane transpose, was removed after this measurement -- commit 06c82cc has it; the switch is ignored now.)
+A/B of the N <= 32 Gram forward with the rows beyond sixteen on the VALU (dkt_gram_small.hip, template parameter XR; 17 <= N <= 20: the QMUL head's 19 frames) against
 the three-MFMA-tile form (twins library, DKT_GRAM_SMALL_XR=0); errors of both against float64.   python tools/small_xr_ab.py"""
 import importlib
 import os
