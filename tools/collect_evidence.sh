@@ -2,7 +2,7 @@
 # The evidence of a round in one GPU call (gpurun): rocprofv3 stats + PMC passes per config, the band path's timings / kernel breakdown / phase clocks, the GPU suite,
 # the graded bench line, the small-batch probes, train_loop per episode.  Everything lands under gpurun_out/; copy what is to be judged into profiles/r0N/.
 cd $GRAFT_REPO_ROOT
-bash tools/prof_all.sh cfg4 cfg4_n320 cfg2 cfg1 cfg1_20way > gpurun_out/prof_all.log 2>&1
+bash tools/prof_all.sh cfg4 cfg4_n320 cfg2 cfg1 cfg1_20way cfg0 cfg3 > gpurun_out/prof_all.log 2>&1
 timeout 400 python tools/check_band.py time > gpurun_out/band_final_check_band.log 2>&1
 bash tools/prof_band.sh final > /dev/null 2>&1
 timeout 300 python tools/band_phase_clocks.py > gpurun_out/band_final_phase_clocks.log 2>&1
