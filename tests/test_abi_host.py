@@ -71,7 +71,8 @@ def test_twins_library_is_the_same_abi_and_the_product_has_no_variant_switches()
     upath = os.path.join(os.path.dirname(dkt_amd._lib.LIB_PATH), "build", "libdkt_hip.so.resource_usage.json")       # written by the build in this checkout
     if os.path.exists(upath):
         usage = __import__("json").load(open(upath))
-        assert len(usage) <= 246 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
+        # (250: + the four RBF instances of the N <= 32 Gram forward that form rows 17 .. 20 on the VALU, end of round 6)
+        assert len(usage) <= 250 and max(u.get("vgpr_spill", 0) for u in usage.values()) <= 28
         assert dkt_amd._lib.check_resources(usage) == []
 
 
