@@ -1026,12 +1026,12 @@ void launch_gram_bn(const float* X, const float* A, const float* S, long abs, fl
     } else if (bo) {
         if constexpr (NT >= 3) {
             if (bn_train_f16()) {                        // f16 split under the a-priori bound, then the fix-up pass over the episodes it flagged
-                hipLaunchKernelGGL((gram_bn_train_f16_kernel<NT>), dim3(B), dim3(256), 0, st, X, A, S, E, rnorm, N, D, *bo);
-                hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo, 1);
+                hipLaunchKernelGGL((gram_bn_train_f16_kernel<NT>), dim3(B), dim3(256), dkt_lds_pad("DKT_PAD_FE_FWD"), st, X, A, S, E, rnorm, N, D, *bo);
+                hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), dkt_lds_pad("DKT_PAD_FE_FWD"), st, X, A, S, 0L, E, rnorm, N, D, *bo, 1);
                 return;
             }
         }
-        hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), 0, st, X, A, S, 0L, E, rnorm, N, D, *bo, 0);
+        hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, true>), dim3(B), dim3(256), dkt_lds_pad("DKT_PAD_FE_FWD"), st, X, A, S, 0L, E, rnorm, N, D, *bo, 0);
     } else hipLaunchKernelGGL((gram_bn_sym_ep_kernel<NT, false>), dim3(B), dim3(256), 0, st, X, A, S, abs, E, rnorm, N, D, BnTrainOut{}, 0);
 }
 
