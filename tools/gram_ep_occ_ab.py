@@ -27,13 +27,14 @@ def timed(fn, reps=10):
 
 
 g = torch.Generator(device=dev).manual_seed(1)
-for (b, n, d) in [(8192, 105, 1600), (8192, 85, 512), (2048, 105, 1600), (8192, 128, 1600)]:
+SHAPES = [(8192, 105, 1600), (8192, 85, 512), (2048, 105, 1600), (8192, 128, 1600)] if len(sys.argv) < 2 else [(8192, 85, 512), (8192, 105, 512), (8192, 96, 256), (2048, 85, 512), (8192, 85, 1024)]
+for (b, n, d) in SHAPES:
     z = torch.nn.functional.normalize(torch.randn(b, n, d, generator=g, device=dev), dim=2).contiguous()
     w = torch.randn(b, n, n, generator=g, device=dev)
     w = (w + w.transpose(1, 2)).contiguous()
     fw, bw = {}, {}
     pads_f = ("0", "20000", "40000", "70000")          # forward: 48 KB static: 3 / 2 (68 KB) / 1 (88 KB) / 1 workgroups per CU
-    pads_b = ("0", "10000", "20000")                   # backward: 72 KB static: 2 / 1 / 1
+    pads_b = ("0", "10000", "20000") if len(sys.argv) < 2 else ("0", "6000", "12000", "20000", "32000", "60000")     # backward <7,2,2,1>: 72 KB static: 2 / 1 / 1; the one-image instance below D = 1024: ~50 KB
     for rnd in range(3):
         for p in pads_f:
             os.environ["DKT_PAD_GRAM_EP"] = p
