@@ -86,7 +86,10 @@ int dkt_abi_version(void);
 
 /* The library reads its measurement / validation switches (environment variables) once, at the first call that needs
  * them; a host that changed one inside a running process (tests, A/B tools) calls this to have them re-read.  No effect on results of the
- * default configuration.  (Exported since round 2; declared here since ABI 4.) */
+ * default configuration.  (Exported since round 2; declared here since ABI 4.)
+ * Threads: every entry point is re-entrant on its arguments (no buffers, handles or streams are kept between calls); the only process-wide state is this cache of the
+ * environment's dispatch thresholds -- plain ints, filled lazily and idempotently (concurrent first calls store the same value), which the environment being per-process
+ * makes process-wide by nature.  dkt_reload_env() itself is for single-threaded harnesses: do not call it while another thread is inside a dkt_* call. */
 void dkt_reload_env(void);
 
 /* Device query used by the host side to fail loudly on a non-gfx950 box: returns the number of
