@@ -42,9 +42,30 @@ def poll(stop, out):
         time.sleep(0.05)
 
 
+# the fused front end of the drop-in class (2048 episodes from trunk features), the 20-way band path (1024 episodes of 420 rows) and the QMUL head's small kernels
+x = (torch.randn(2048, n, d, generator=g, device=dev).abs() + 1.0)
+gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+fe = ops.gram_bn_train(x, gamma, beta)
+z4 = torch.nn.functional.normalize(torch.randn(1024, 420, 512, generator=g, device=dev), dim=2).contiguous()
+e4 = ops.gram(z4, None, ops.KERNEL_LINEAR_UNIT)
+w4 = torch.randn(1024, 420, 420, generator=g, device=dev)
+w4 = (w4 + w4.transpose(1, 2)).contiguous()
+cls4 = torch.arange(20, device=dev).repeat_interleave(21)
+y4 = torch.where(cls4.unsqueeze(0) == torch.arange(20, device=dev).unsqueeze(1), 1.0, -1.0).contiguous()
+sv4, mean4, noise4, cw4 = torch.linspace(0.8, 1.4, 20, device=dev), torch.zeros(20, device=dev), torch.full((20,), 0.1, device=dev), torch.full((20,), -1.0 / 8400, device=dev)
+z0 = torch.randn(8192, 19, 2916, generator=g, device=dev) * 0.05
+w0 = torch.randn(8192, 19, 19, generator=g, device=dev) * 0.1
+ls0 = torch.tensor([1.3], device=dev)
+
 for name, fn in (("dkt_gram_f32", lambda: ops.gram(z, None, ops.KERNEL_LINEAR_UNIT)),
                  ("dkt_gram_bwd_f32", lambda: ops.gram_bwd(w, z, None, unit_rows=True, w_symmetric=True)),
-                 ("dkt_mll_f32", lambda: ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw))):
+                 ("dkt_mll_f32", lambda: ops.mll(e, y, sv, mean, noise, want_grad=True, cls_weight=cw)),
+                 ("gram_bn_train 2048", lambda: ops.gram_bn_train(x, gamma, beta)),
+                 ("gram N=420 x1024", lambda: ops.gram(z4, None, ops.KERNEL_LINEAR_UNIT)),
+                 ("gram_bwd N=420", lambda: ops.gram_bwd(w4, z4, None, unit_rows=True, w_symmetric=True)),
+                 ("mll band N=420", lambda: ops.mll(e4, y4, sv4, mean4, noise4, want_grad=True, cls_weight=cw4)),
+                 ("gram 19x2916 rbf", lambda: ops.gram(z0, None, ops.KERNEL_RBF, ls0)),
+                 ("gram_bwd 19x2916", lambda: ops.gram_bwd(w0, z0))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -55,10 +76,10 @@ for name, fn in (("dkt_gram_f32", lambda: ops.gram(z, None, ops.KERNEL_LINEAR_UN
     reps = 0
     t0.record()
     tw = time.perf_counter()
-    while time.perf_counter() - tw < 3.0:
-        for _ in range(50):
+    while time.perf_counter() - tw < 2.5:
+        for _ in range(10):
             fn()
-        reps += 50
+        reps += 10
         torch.cuda.synchronize()
     t1.record()
     torch.cuda.synchronize()
