@@ -53,7 +53,11 @@ __device__ __forceinline__ void split2h(const float4& v, float scale, f16x4& h, 
         const float xs = x[i] * scale;
         const _Float16 hi = (_Float16)xs;
         h[i] = hi;
+#ifdef DKT_PROBE_NO_SPLIT         // measurement builds only: no low plane arithmetic
+        m[i] = (_Float16)0.f;
+#else
         m[i] = (_Float16)(xs - (float)hi);
+#endif
     }
 }
 
@@ -63,10 +67,15 @@ __device__ __forceinline__ void sym_tiles_mfma_f16x2(f32x4* acc, const _Float16*
     auto frag = [&](int plane, int blk) { return *reinterpret_cast<const f16x8*>(base + plane * PLANE + blk * 16 * SPLD); };
     auto tile = [&](f32x4& c, const f16x8& ah, const f16x8& am, int tj) {     // two-level accumulation as in the bf16 variant
         const f16x8 bh = frag(0, tj), bm = frag(1, tj);
+#ifdef DKT_PROBE_ONE_PRODUCT      // measurement builds only (tools/experiments/forward_energy_probe.sh): the hh product alone -- WRONG results, the time of a third of the MFMAs
+        (void)bm; (void)am;
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+#else
         f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
         c += t;
+#endif
     };
     {
         const f16x8 ah = frag(0, RA), am = frag(1, RA);
